@@ -1,0 +1,132 @@
+/*
+ * ntru_engine.h -- C ABI of the MI355X NTRU polynomial-ring engine.
+ *
+ * This is the drop-in boundary for the hot path of numtel/ntru-circom (reference file index.js):
+ * the linear product (multiplyPolynomials, index.js:319-355), the quotient/remainder split by
+ * I = 1 - x^N (dividePolynomials with b = I, index.js:358-401), the coefficient-wise reductions
+ * (addPolynomials index.js:235-244, centred lift index.js:117) and the three scheme methods built
+ * from them (encryptBits :87-110, decryptBits :111-140, verifyKeysInputs :141-197).
+ *
+ * The reference has no FFI of its own (it is a single ES module); the bindings a maintainer adds
+ * are shown in INTEGRATION.md (N-API addon in ntru-circom_amd/js/, ctypes in ntru-circom_amd/engine.py).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, caller-owned buffers, nothing allocated across the ABI.
+ *   - every batch array is row-major [B][N] with a fixed stride of N elements, zero padded: row b holds
+ *     the N coefficients of item b.  The reference's witness arrays of length N+1 always end in 0
+ *     (index.js:101-102,127-130,174-175): that element and the trimming of `value`
+ *     (trimPolynomial, index.js:218-221) are added by the host-side shim, not stored on the device.
+ *   - mod-q coefficients are uint16_t (q a power of two, 2 <= q <= 65536); ternary / mod-p coefficients
+ *     are uint8_t; signed ternary key material f, g is int8_t in {-1, 0, 1}.
+ *   - every function returns 0 on success or one of the NTRU_ERR_* codes; ntru_last_error() then
+ *     returns a message for the calling thread.
+ *   - *_dev entry points take DEVICE pointers and enqueue work on the engine's stream without
+ *     synchronising; the same names without _dev take HOST pointers, copy in/out and return when
+ *     the results are in the caller's buffers.
+ *   - there is no CPU fallback: without a usable HIP device ntru_engine_create fails.
+ */
+#ifndef NTRU_ENGINE_H
+#define NTRU_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTRU_OK 0
+#define NTRU_ERR_NO_DEVICE 1   /* no HIP device / device id out of range */
+#define NTRU_ERR_ARG 2         /* NULL pointer, negative size, ...       */
+#define NTRU_ERR_UNSUPPORTED 3 /* parameter set outside what the kernels implement */
+#define NTRU_ERR_HIP 4         /* a HIP runtime call failed               */
+
+/* bits of the per-item flags byte written by ntru_verify_keys_batch: set when the reference's
+ * verifyKeysInputs would throw 'invalid fq' / 'invalid fp' / 'invalid h' (index.js:159-166). */
+#define NTRU_FLAG_INVALID_FQ 1
+#define NTRU_FLAG_INVALID_FP 2
+#define NTRU_FLAG_INVALID_H 4
+
+typedef struct ntru_engine ntru_engine_t;
+
+/* Number of HIP devices visible to the process (0 if none / runtime unusable). */
+int ntru_engine_device_count(void);
+
+/* Create an engine bound to HIP device `device`.  Work is enqueued on the NULL stream until
+ * ntru_engine_set_stream is called. */
+int ntru_engine_create(int device, ntru_engine_t **out);
+void ntru_engine_destroy(ntru_engine_t *eng);
+
+/* Use `hip_stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) for all later calls.
+ * The engine never owns the stream. */
+int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
+/* Block until everything enqueued on the engine's stream has finished. */
+int ntru_engine_synchronize(ntru_engine_t *eng);
+
+/* Message describing the last error on this thread ("" if none). */
+const char *ntru_last_error(void);
+
+/* 1 if (N, mod) is a parameter set the kernels implement: mod a power of two <= 65536, or a small
+ * modulus with N*(mod-1)^2 < 65536 (p = 3 for every NTRU set); 2 <= N <= NTRU_MAX_N. */
+int ntru_engine_supports(int N, int mod);
+#define NTRU_MAX_N 1920
+
+/* ---- generic product + split: replaces multiplyPolynomials(a,b,mod) followed by
+ *      dividePolynomials(.,I,mod) (index.js:319-355, 358-401) for per-item operands.
+ *      a, b: [B][N] values (any uint16, reduced or not when mod is a power of two; < mod otherwise).
+ *      quot[b][k] = (mod - c[N+k]) % mod,  rem[b][k] = (c[k] + c[N+k]) % mod,  c = linear product. */
+int ntru_polymul_split(ntru_engine_t *eng, int N, int mod, const uint16_t *a, const uint16_t *b,
+                       int64_t B, uint16_t *quot, uint16_t *rem);
+int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b,
+                           int64_t B, uint16_t *d_quot, uint16_t *d_rem);
+
+/* ---- stand-alone split: dividePolynomials(a, I, mod) (index.js:358-401 with b = I = 1 - x^N) for dividends that
+ *      are already reduced into [0,mod).  a: [B][2N] (row b = the dividend's coefficients 0..2N-1, zero padded).
+ *      quot[b][k] = (mod - a[N+k]) % mod, rem[b][k] = (a[k] + a[N+k]) % mod   (SURVEY.md 0.3). */
+int ntru_split_by_I(ntru_engine_t *eng, int N, int mod, const uint16_t *a, int64_t B, uint16_t *quot, uint16_t *rem);
+int ntru_split_by_I_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, int64_t B, uint16_t *d_quot,
+                        uint16_t *d_rem);
+
+/* ---- coefficient-wise sum: addPolynomials(a, b, mod) (index.js:235-244) on [B][N] rows, e.g. the additive
+ *      homomorphism on ciphertexts of test/reference.test.js:46-61.  out[b][k] = (a[b][k] + b[b][k]) % mod. */
+int ntru_add_batch(ntru_engine_t *eng, int N, int mod, const uint16_t *a, const uint16_t *b, int64_t B, uint16_t *out);
+int ntru_add_batch_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B,
+                       uint16_t *d_out);
+
+/* ---- encryptBits (index.js:87-110) for B plaintexts under one public key.
+ *      h[N] in [0,q); r[B][N] in {0,1,2} (the sampler output with -1 already mapped to p-1, index.js:89);
+ *      m[B][N] plaintext coefficients (README: 0/1/2; any byte is accepted and added mod q).
+ *      e = remainderE (the ciphertext), quotE = quotientE (may be NULL when the witness is not wanted). */
+int ntru_encrypt_batch(ntru_engine_t *eng, int N, int q, const uint16_t *h, const uint8_t *r, const uint8_t *m,
+                       int64_t B, uint16_t *e, uint16_t *quotE);
+int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const uint16_t *d_h, const uint8_t *d_r,
+                           const uint8_t *d_m, int64_t B, uint16_t *d_e, uint16_t *d_quotE);
+
+/* ---- decryptBits (index.js:111-140) for B ciphertexts under one private key.
+ *      f[N] in {-1,0,1}; fp[N] in [0,p); e[B][N] in [0,q).
+ *      value = remainder2; quot1 / rem1 / quot2 = quotient1 / remainder1 / quotient2 (each may be NULL).
+ *      The centred lift is the reference's `x > q/2 ? (x+1)%p : x%p` verbatim. */
+int ntru_decrypt_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, const uint8_t *fp,
+                       const uint16_t *e, int64_t B, uint8_t *value, uint16_t *quot1, uint16_t *rem1,
+                       uint8_t *quot2);
+int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp,
+                           const uint16_t *d_e, int64_t B, uint8_t *d_value, uint16_t *d_quot1,
+                           uint16_t *d_rem1, uint8_t *d_quot2);
+
+/* ---- verifyKeysInputs (index.js:141-197) for B independent key pairs (per-item operands).
+ *      f, g [B][N] in {-1,0,1}; fq, h [B][N] in [0,q); fp [B][N] in [0,p).
+ *      Three witnesses per item: fq*f mod q, fp*f mod p, (p*fq)*g mod q, each as quotient + remainder;
+ *      flags[B] gets the NTRU_FLAG_* bits. */
+int ntru_verify_keys_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, const int8_t *g,
+                           const uint16_t *fq, const uint8_t *fp, const uint16_t *h, int64_t B,
+                           uint16_t *quot_fq, uint16_t *rem_fq, uint8_t *quot_fp, uint8_t *rem_fp,
+                           uint16_t *quot_h, uint16_t *rem_h, uint8_t *flags);
+int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, const int8_t *d_g,
+                               const uint16_t *d_fq, const uint8_t *d_fp, const uint16_t *d_h, int64_t B,
+                               uint16_t *d_quot_fq, uint16_t *d_rem_fq, uint8_t *d_quot_fp, uint8_t *d_rem_fp,
+                               uint16_t *d_quot_h, uint16_t *d_rem_h, uint8_t *d_flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTRU_ENGINE_H */

@@ -1,0 +1,15 @@
+"""MI355X-native NTRU polynomial-ring engine: host-side mirror of the reference's hot-path interface.
+
+Layout
+  csrc/ntru_engine.hip   HIP kernels (gfx950) + the C ABI declared in include/ntru_engine.h
+  lib/libntru_engine.so  built artefact (make -C csrc, or __graft_entry__.build())
+  engine.py              ctypes binding of the C ABI (numpy host buffers or raw device pointers)
+  ntru.py                `NTRU` class + pure functions with the reference's names and semantics (index.js)
+  js/                    N-API addon + ES-module shim exposing the same surface to Node.js
+
+There is no CPU implementation in this package: everything that computes goes through the HIP library and
+raises `EngineError` when it (or a GPU) is missing.
+"""
+from .engine import Engine, EngineError, library_path, load_library  # noqa: F401
+from .ntru import (NTRU, addCiphertexts, addPolynomials, degree, dividePolynomials, expandArray, generateCustomArray,  # noqa: F401
+                   multiplyPolynomials, stringToBits, bitsToString, trimPolynomial)

@@ -1,0 +1,884 @@
+// ntru_engine.hip -- MI355X (gfx950) kernels and C ABI of the NTRU polynomial-ring engine.
+//
+// Hot path of numtel/ntru-circom re-designed for CDNA4 (reference: index.js):
+//   multiplyPolynomials (index.js:319-355)  -> exact integer schoolbook in Z/2^16 (q | 2^16, so natural u16
+//                                              wrap-around IS the mod-q residue; mod-p sums stay < 2^16)
+//   dividePolynomials by I=1-x^N (:358-401) -> closed form fused into the product's epilogue
+//   addPolynomials (:235-244), lift (:117)  -> fused into the same epilogue
+//
+// Work decomposition ("one ciphertext per wavefront"):
+//   * an item (one polynomial product) is owned by nl = ceil(N / 2K) consecutive lanes of a wave; lane s owns
+//     the 2K outputs k in [2K s, 2K s + 2K) as K packed u16 pairs (v_pk_mad_u16: 2 MACs per lane-instruction).
+//     For small N several items share a wave (G = 64 / nl).
+//   * the "window" operand b lives in LDS as EO[u] = { E[u] = (bc[2u], bc[2u+1]), O[u] = (bc[2u-1], bc[2u]) },
+//     bc = b extended cyclically with period N, so that for step i the K pairs a lane needs are K consecutive
+//     8-byte entries, and going from step i to i+2 slides that window by exactly one entry: one ds_read_b64 per
+//     lane per two steps, lane stride K entries (K odd => conflict-free, profiles/r01_microbench_valu_lds.txt).
+//   * the "broadcast" operand a is read from LDS two coefficients at a time and applied with op_sel splats.
+//   * T[k] = sum_i a[i] bc[k-i] is the cyclic product = remainder; the low half c[k] of the LINEAR product (needed
+//     for the quotient) is T's value just before the lane's own block of i plus an in-block
+//     triangle; high = T - low; quotient = -high.  (tools/lane_model.py is the executable spec of this indexing.)
+//
+// No CPU fallback exists in this file: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "ntru_engine.h"
+
+typedef unsigned short u16;
+typedef unsigned int u32;
+typedef u16 u16x2 __attribute__((ext_vector_type(2)));
+
+#define WAVES_PER_BLOCK 4
+#define BLOCK_THREADS (WAVES_PER_BLOCK * 64)
+
+struct Geom {
+  int N;       // ring size
+  int nl;      // lanes per item = ceil(N / 2K)
+  int G;       // items per wave = 64 / nl
+  int off;     // K*nl: position of logical entry u = 0 inside an EO array
+  int eo_len;  // 2*K*nl 8-byte entries per EO array
+  int a_len;   // K*nl dwords (2K*nl u16) per staged a-operand
+};
+
+static __device__ __forceinline__ u16x2 as_pair(u32 v) { return __builtin_bit_cast(u16x2, v); }
+static __device__ __forceinline__ u32 as_u32(u16x2 v) { return __builtin_bit_cast(u32, v); }
+
+// x mod a small runtime modulus; p = 3 (every NTRU parameter set) gets the constant-divisor sequence.
+static __device__ __forceinline__ u32 mod_small(u32 x, u32 m) { return m == 3u ? x % 3u : x % m; }
+
+// Order this wave's LDS writes before its later LDS reads (regions touched here are private to one wave).
+static __device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- operand value functors: coefficient j of an operand, already mapped into its u16 representation ----------
+struct ValU16 {            // e, h, fq, generic a/b
+  const u16 *p;
+  __device__ __forceinline__ u32 operator()(int j) const { return p[j]; }
+};
+struct ValU16x3 {          // fqp = p*fq left unreduced (index.js:155); 3*8191 < 2^16
+  const u16 *p; u32 mul;
+  __device__ __forceinline__ u32 operator()(int j) const { return (u32)p[j] * mul; }
+};
+struct ValU8 {             // r, fp, m
+  const uint8_t *p;
+  __device__ __forceinline__ u32 operator()(int j) const { return p[j]; }
+};
+struct ValTernary {        // f, g in {-1,0,1}: -1 -> mod-1 (index.js:112,151,152,156)
+  const int8_t *p; u32 neg;
+  __device__ __forceinline__ u32 operator()(int j) const { int v = p[j]; return v < 0 ? neg : (u32)v; }
+};
+
+// Build one EO array (see header) from `val`; executed by `nthr` cooperating threads, this one being `tid`.
+template <class F>
+static __device__ __forceinline__ void build_eo(uint2 *eo, const Geom &g, F val, int tid, int nthr) {
+  const int N = g.N;
+  for (int x = tid; x < g.eo_len; x += nthr) {
+    int j = 2 * (x - g.off);                 // |j| < 2*off <= N + 2K <= 2N
+    j += j < 0 ? N : 0; j += j < 0 ? N : 0;
+    j -= j >= N ? N : 0; j -= j >= N ? N : 0;
+    int jm = j == 0 ? N - 1 : j - 1;
+    int jp = j + 1 == N ? 0 : j + 1;
+    u32 c0 = val(j) & 0xFFFFu, cm = val(jm) & 0xFFFFu, cp = val(jp) & 0xFFFFu;
+    eo[x] = make_uint2(c0 | (cp << 16), cm | (c0 << 16));
+  }
+}
+
+// Stage the broadcast operand as zero-padded u16s: a16[i] = i < N ? val(i) : 0 for i < 2*a_len.
+template <class F>
+static __device__ __forceinline__ void stage_a(u16 *a16, const Geom &g, F val, int sub, bool active) {
+  if (!active) return;
+  const int n2 = 2 * g.a_len;
+  for (int i = sub; i < n2; i += g.nl) a16[i] = i < g.N ? (u16)val(i) : (u16)0;
+}
+
+// The O(N^2) accumulate.  eo: this item's EO array, a32: its staged a-operand (packed pairs), sub: lane's index in item.
+template <int K>
+static __device__ __forceinline__ void mac_core(const uint2 *__restrict__ eo, const u32 *__restrict__ a32,
+                                                const Geom &g, int sub, bool want_low,
+                                                u16x2 (&T)[K], u16x2 (&low)[K]) {
+  u32 WE[K], WO[K];
+  const uint2 *nb = eo + (K * sub + g.off);     // logical entry K*sub - K*m, m = 0
+#pragma unroll
+  for (int x = 0; x < K; x++) { uint2 v = nb[x]; WE[x] = v.x; WO[x] = v.y; }
+#pragma unroll
+  for (int t = 0; t < K; t++) { T[t] = (u16x2){0, 0}; low[t] = (u16x2){0, 0}; }
+  const int nblk = g.nl;
+  for (int m = 0; m < nblk; m++) {
+    if (want_low && m == sub) {                 // snapshot: everything accumulated so far has i < 2K*sub <= k
+#pragma unroll
+      for (int t = 0; t < K; t++) low[t] = T[t];
+    }
+    uint2 nw[K]; u32 av[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) nw[s] = nb[-1 - s];
+#pragma unroll
+    for (int s = 0; s < K; s++) av[s] = a32[K * m + s];
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const u16x2 ap = as_pair(av[s]);
+#pragma unroll
+      for (int t = 0; t < K; t++) T[t] = ap.xx * as_pair(WE[(t - s + K) % K]) + T[t];   // i = 2(Km+s)
+#pragma unroll
+      for (int t = 0; t < K; t++) T[t] = ap.yy * as_pair(WO[(t - s + K) % K]) + T[t];   // i + 1
+      WE[K - 1 - s] = nw[s].x; WO[K - 1 - s] = nw[s].y;
+    }
+    nb -= K;
+  }
+}
+
+// In-block triangle: d[k0+j] = sum_{u<=j} a[k0+u] * b[j-u] for the lane's own 2K outputs (k0 = 2K*sub).
+template <int K>
+static __device__ __forceinline__ void diag_core(const uint2 *__restrict__ eo, const u32 *__restrict__ a32,
+                                                 const Geom &g, int sub, u16x2 (&d)[K]) {
+  u32 ZE[K], ZO[K];
+#pragma unroll
+  for (int x = 0; x < K; x++) { uint2 v = eo[g.off + x]; ZE[x] = v.x; ZO[x] = v.y; }
+  ZO[0] &= 0xFFFF0000u;                          // O[0] = (b[-1], b[0]): b[-1] does not exist in the linear product
+#pragma unroll
+  for (int t = 0; t < K; t++) d[t] = (u16x2){0, 0};
+#pragma unroll
+  for (int s = 0; s < K; s++) {
+    const u16x2 ap = as_pair(a32[K * sub + s]);
+#pragma unroll
+    for (int t = s; t < K; t++) {
+      d[t] = ap.xx * as_pair(ZE[t - s]) + d[t];
+      d[t] = ap.yy * as_pair(ZO[t - s]) + d[t];
+    }
+  }
+}
+
+// One product a*b with split by 1-x^N, results left in registers as K pairs per lane.
+//   rem  = (T + addend) mod `mod`      quot = (-high) mod `mod`
+// POW2: mod is a power of two (mask arithmetic on the wrapped u16 sums); otherwise sums are exact and `mod` small.
+template <int K, bool POW2>
+static __device__ __forceinline__ void product_split(const uint2 *eo, const u32 *a32, const Geom &g, int sub,
+                                                     bool want_quot, u32 mod, u16x2 (&rem)[K], u16x2 (&quot)[K]) {
+  u16x2 T[K], low[K];
+  mac_core<K>(eo, a32, g, sub, want_quot, T, low);
+  if (want_quot) {
+    u16x2 d[K];
+    diag_core<K>(eo, a32, g, sub, d);
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      u16x2 hi = T[t] - (low[t] + d[t]);
+      if (POW2) {
+        quot[t] = ((u16x2){0, 0} - hi) & (u16)(mod - 1);
+      } else {
+        u32 h0 = mod_small(hi.x, mod), h1 = mod_small(hi.y, mod);
+        quot[t] = (u16x2){(u16)(h0 ? mod - h0 : 0), (u16)(h1 ? mod - h1 : 0)};
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    if (POW2) rem[t] = T[t];                       // masked by the caller after the optional addend
+    else rem[t] = (u16x2){(u16)mod_small(T[t].x, mod), (u16)mod_small(T[t].y, mod)};
+  }
+}
+
+template <int K, class OutT>
+static __device__ __forceinline__ void store_pairs(OutT *row, const Geom &g, int sub, const u16x2 (&v)[K]) {
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    int k = 2 * K * sub + 2 * t;
+    if (k < g.N) row[k] = (OutT)v[t].x;
+    if (k + 1 < g.N) row[k + 1] = (OutT)v[t].y;
+  }
+}
+
+struct LaneId {
+  int wave, lane, grp, sub; bool active;
+};
+static __device__ __forceinline__ LaneId lane_id(const Geom &g) {
+  LaneId L;
+  L.wave = threadIdx.x >> 6; L.lane = threadIdx.x & 63;
+  L.active = L.lane < g.G * g.nl;
+  L.grp = L.active ? L.lane / g.nl : 0;
+  L.sub = L.active ? L.lane - L.grp * g.nl : 0;
+  return L;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------
+// dynamic LDS: [shared EO arrays][per-wave regions]; per-wave = G a-operands (+ G EO arrays for per-item windows)
+
+// encryptBits, index.js:87-110: e = (m + r*h) mod q split by I.
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_encrypt(Geom g, u32 q, const u16 *__restrict__ h,
+                                                           const uint8_t *__restrict__ r,
+                                                           const uint8_t *__restrict__ m, long B,
+                                                           u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint2 *eo_h = (uint2 *)lds;
+  const LaneId L = lane_id(g);
+  u32 *a_wave = (u32 *)(lds + (size_t)g.eo_len * 8) + (size_t)L.wave * g.G * g.a_len;
+  u32 *a32 = a_wave + (size_t)L.grp * g.a_len;
+  build_eo(eo_h, g, ValU16{h}, threadIdx.x, BLOCK_THREADS);
+  __syncthreads();
+  const long ngroups = (B + g.G - 1) / g.G;
+  const bool want_quot = quotE != nullptr;
+  for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
+    const long item = grp * g.G + L.grp;
+    const bool valid = L.active && item < B;
+    const long row = (valid ? item : 0) * g.N;
+    stage_a((u16 *)a32, g, ValU8{r + row}, L.sub, L.active);
+    wave_lds_fence();
+    u16x2 rem[K], quot[K];
+    product_split<K, true>(eo_h, a32, g, L.sub, want_quot, q, rem, quot);
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      int k = 2 * K * L.sub + 2 * t;
+      u16x2 add = {(u16)(k < g.N ? m[row + k] : 0), (u16)(k + 1 < g.N ? m[row + k + 1] : 0)};
+      rem[t] = (rem[t] + add) & (u16)(q - 1);
+    }
+    if (valid) {
+      store_pairs<K>(e + row, g, L.sub, rem);
+      if (want_quot) store_pairs<K>(quotE + row, g, L.sub, quot);
+    }
+    wave_lds_fence();
+  }
+}
+
+// decryptBits, index.js:111-140: a = f*e mod q; split; lift; c = fp*b mod p; split.
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt(Geom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                           const uint8_t *__restrict__ fp,
+                                                           const u16 *__restrict__ e, long B,
+                                                           uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                           u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint2 *eo_f = (uint2 *)lds;
+  uint2 *eo_fp = eo_f + g.eo_len;
+  const LaneId L = lane_id(g);
+  u32 *a_wave = (u32 *)(lds + (size_t)g.eo_len * 16) + (size_t)L.wave * g.G * g.a_len;
+  u32 *a32 = a_wave + (size_t)L.grp * g.a_len;
+  build_eo(eo_f, g, ValTernary{f, q - 1}, threadIdx.x, BLOCK_THREADS);
+  build_eo(eo_fp, g, ValU8{fp}, threadIdx.x, BLOCK_THREADS);
+  __syncthreads();
+  const long ngroups = (B + g.G - 1) / g.G;
+  const bool want_q1 = quot1 != nullptr, want_q2 = quot2 != nullptr;
+  for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
+    const long item = grp * g.G + L.grp;
+    const bool valid = L.active && item < B;
+    const long row = (valid ? item : 0) * g.N;
+    stage_a((u16 *)a32, g, ValU16{e + row}, L.sub, L.active);
+    wave_lds_fence();
+    u16x2 r1[K], q1[K];
+    product_split<K, true>(eo_f, a32, g, L.sub, want_q1, q, r1, q1);
+#pragma unroll
+    for (int t = 0; t < K; t++) r1[t] = r1[t] & (u16)(q - 1);
+    if (valid) {
+      if (rem1) store_pairs<K>(rem1 + row, g, L.sub, r1);
+      if (want_q1) store_pairs<K>(quot1 + row, g, L.sub, q1);
+    }
+    // centred lift, index.js:117 verbatim: x > q/2 ? (x+1)%p : x%p ; zero beyond N so the padding stays zero
+    wave_lds_fence();
+    if (L.active) {
+#pragma unroll
+      for (int t = 0; t < K; t++) {
+        int k = 2 * K * L.sub + 2 * t;
+        u32 x0 = r1[t].x, x1 = r1[t].y;
+        u32 b0 = mod_small(2 * x0 > q ? x0 + 1 : x0, p), b1 = mod_small(2 * x1 > q ? x1 + 1 : x1, p);
+        b0 = k < g.N ? b0 : 0; b1 = k + 1 < g.N ? b1 : 0;
+        a32[K * L.sub + t] = b0 | (b1 << 16);
+      }
+    }
+    wave_lds_fence();
+    u16x2 r2[K], q2[K];
+    product_split<K, false>(eo_fp, a32, g, L.sub, want_q2, p, r2, q2);
+    if (valid) {
+      store_pairs<K>(value + row, g, L.sub, r2);
+      if (want_q2) store_pairs<K>(quot2 + row, g, L.sub, q2);
+    }
+    wave_lds_fence();
+  }
+}
+
+// generic a*b mod `mod` split by I with per-item operands (multiplyPolynomials + dividePolynomials(.,I,.)).
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod, int pow2,
+                                                                 const u16 *__restrict__ a, const u16 *__restrict__ b,
+                                                                 long B, u16 *__restrict__ quot, u16 *__restrict__ rem) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const LaneId L = lane_id(g);
+  const size_t per_wave = (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4);
+  unsigned char *wbase = lds + (size_t)L.wave * per_wave;
+  uint2 *eo = (uint2 *)wbase + (size_t)L.grp * g.eo_len;
+  u32 *a32 = (u32 *)(wbase + (size_t)g.G * g.eo_len * 8) + (size_t)L.grp * g.a_len;
+  const long ngroups = (B + g.G - 1) / g.G;
+  for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
+    const long item = grp * g.G + L.grp;
+    const bool valid = L.active && item < B;
+    const long row = (valid ? item : 0) * g.N;
+    if (L.active) build_eo(eo, g, ValU16{b + row}, L.sub, g.nl);
+    stage_a((u16 *)a32, g, ValU16{a + row}, L.sub, L.active);
+    wave_lds_fence();
+    u16x2 r[K], qv[K];
+    if (pow2) {
+      product_split<K, true>(eo, a32, g, L.sub, true, mod, r, qv);
+#pragma unroll
+      for (int t = 0; t < K; t++) r[t] = r[t] & (u16)(mod - 1);
+    } else {
+      product_split<K, false>(eo, a32, g, L.sub, true, mod, r, qv);
+    }
+    if (valid) {
+      store_pairs<K>(rem + row, g, L.sub, r);
+      store_pairs<K>(quot + row, g, L.sub, qv);
+    }
+    wave_lds_fence();
+  }
+}
+
+// Does any active lane of this lane's item have `pred` set?  (items occupy nl consecutive lanes of the wave)
+static __device__ __forceinline__ bool item_any(bool pred, const Geom &g, const LaneId &L) {
+  unsigned long long bal = __ballot(pred && L.active);
+  unsigned long long msk = (g.nl >= 64 ? ~0ull : ((1ull << g.nl) - 1)) << (L.grp * g.nl);
+  return (bal & msk) != 0;
+}
+
+// verifyKeysInputs, index.js:141-197, per-item key material; three products per item.
+template <int K>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys(
+    Geom g, u32 q, u32 p, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
+    const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
+    u16 *__restrict__ rem_fq, uint8_t *__restrict__ quot_fp, uint8_t *__restrict__ rem_fp, u16 *__restrict__ quot_h,
+    u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const LaneId L = lane_id(g);
+  const size_t per_wave = (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4);
+  unsigned char *wbase = lds + (size_t)L.wave * per_wave;
+  uint2 *eo = (uint2 *)wbase + (size_t)L.grp * g.eo_len;
+  u32 *a32 = (u32 *)(wbase + (size_t)g.G * g.eo_len * 8) + (size_t)L.grp * g.a_len;
+  const long ngroups = (B + g.G - 1) / g.G;
+  for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
+    const long item = grp * g.G + L.grp;
+    const bool valid = L.active && item < B;
+    const long row = (valid ? item : 0) * g.N;
+    u32 fl = 0;
+    u16x2 r[K], qv[K];
+    // ---- fq * f mod q (index.js:158-160)
+    if (L.active) build_eo(eo, g, ValTernary{f + row, q - 1}, L.sub, g.nl);
+    stage_a((u16 *)a32, g, ValU16{fq + row}, L.sub, L.active);
+    wave_lds_fence();
+    product_split<K, true>(eo, a32, g, L.sub, true, q, r, qv);
+    {
+      bool nz_hi = false;                             // any remainder coefficient beyond index 0 non-zero?
+#pragma unroll
+      for (int t = 0; t < K; t++) {
+        r[t] = r[t] & (u16)(q - 1);
+        int k = 2 * K * L.sub + 2 * t;
+        nz_hi |= (k >= 1 && k < g.N && r[t].x != 0) || (k + 1 < g.N && r[t].y != 0);
+      }
+      bool first_not_one = item_any(L.sub == 0 && r[0].x != 1, g, L);
+      if (item_any(nz_hi, g, L) && first_not_one) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
+    }
+    if (valid) { store_pairs<K>(rem_fq + row, g, L.sub, r); store_pairs<K>(quot_fq + row, g, L.sub, qv); }
+    wave_lds_fence();
+    // ---- fp * f mod p (index.js:161-163)
+    if (L.active) build_eo(eo, g, ValTernary{f + row, p - 1}, L.sub, g.nl);
+    stage_a((u16 *)a32, g, ValU8{fp + row}, L.sub, L.active);
+    wave_lds_fence();
+    product_split<K, false>(eo, a32, g, L.sub, true, p, r, qv);
+    {
+      bool nz_hi = false;
+#pragma unroll
+      for (int t = 0; t < K; t++) {
+        int k = 2 * K * L.sub + 2 * t;
+        nz_hi |= (k >= 1 && k < g.N && r[t].x != 0) || (k + 1 < g.N && r[t].y != 0);
+      }
+      bool first_not_one = item_any(L.sub == 0 && r[0].x != 1, g, L);
+      if (item_any(nz_hi, g, L) && first_not_one) fl |= NTRU_FLAG_INVALID_FP;
+    }
+    if (valid) { store_pairs<K>(rem_fp + row, g, L.sub, r); store_pairs<K>(quot_fp + row, g, L.sub, qv); }
+    wave_lds_fence();
+    // ---- (p*fq) * g mod q (index.js:155,164-166)
+    if (L.active) build_eo(eo, g, ValTernary{gg + row, q - 1}, L.sub, g.nl);
+    stage_a((u16 *)a32, g, ValU16x3{fq + row, p}, L.sub, L.active);
+    wave_lds_fence();
+    product_split<K, true>(eo, a32, g, L.sub, true, q, r, qv);
+    {
+      // 'invalid h' iff some index below h's trimmed length differs from the remainder (index.js:165)
+      int top = -1; bool differs_any[2 * K];
+#pragma unroll
+      for (int t = 0; t < K; t++) {
+        r[t] = r[t] & (u16)(q - 1);
+        int k = 2 * K * L.sub + 2 * t;
+        u32 h0 = k < g.N ? h[row + k] : 0, h1 = k + 1 < g.N ? h[row + k + 1] : 0;
+        if (h0) top = k;
+        if (h1) top = k + 1;
+        differs_any[2 * t] = k < g.N && h0 != r[t].x;
+        differs_any[2 * t + 1] = k + 1 < g.N && h1 != r[t].y;
+      }
+      // degree of h over the item's lanes: highest lane holding a non-zero coefficient wins
+      unsigned long long bal = __ballot(top >= 0 && L.active);
+      unsigned long long msk = (g.nl >= 64 ? ~0ull : ((1ull << g.nl) - 1)) << (L.grp * g.nl);
+      bal &= msk;
+      int hl = 1;                                       // trimmed length of the zero polynomial is 1
+      int src = bal ? 63 - __builtin_clzll(bal) : (int)L.lane;
+      int top_src = __shfl(top, src);
+      if (bal) hl = top_src + 1;
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 2 * K; j++) bad |= differs_any[j] && (2 * K * L.sub + j) < hl;
+      if (item_any(bad, g, L)) fl |= NTRU_FLAG_INVALID_H;
+    }
+    if (valid) {
+      store_pairs<K>(rem_h + row, g, L.sub, r); store_pairs<K>(quot_h + row, g, L.sub, qv);
+      if (L.sub == 0) flags[item] = (uint8_t)fl;
+    }
+    wave_lds_fence();
+  }
+}
+
+// dividePolynomials(a, I, mod) for reduced dividends, elementwise (HBM-bound): a is [B][2N].
+__global__ void k_split_by_I(int N, u32 mod, const u16 *__restrict__ a, long B, u16 *__restrict__ quot,
+                             u16 *__restrict__ rem) {
+  const long total = B * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / N; const int k = (int)(idx - row * N);
+    const u32 lo = a[row * 2 * N + k], hi = a[row * 2 * N + N + k];
+    quot[idx] = (u16)((mod - hi % mod) % mod);
+    rem[idx] = (u16)((lo + hi) % mod);
+  }
+}
+
+// addPolynomials(a, b, mod) on [B][N] rows, elementwise (HBM-bound).
+__global__ void k_add_mod(u32 mod, const u16 *__restrict__ a, const u16 *__restrict__ b, long total,
+                          u16 *__restrict__ out) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+    out[idx] = (u16)(((u32)a[idx] + (u32)b[idx]) % mod);
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+struct ntru_engine {
+  int device;
+  hipStream_t stream;
+  int cus;
+};
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(NTRU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static int pick_K(int N) {
+  for (int K = 1; K <= 15; K += 2)
+    if ((N + 2 * K - 1) / (2 * K) <= 64) return K;
+  return 0;
+}
+
+extern "C" int ntru_engine_supports(int N, int mod) {
+  if (N < 2 || N > NTRU_MAX_N || mod < 2) return 0;
+  if (is_pow2(mod)) return mod <= 65536;
+  return (long)N * (mod - 1) * (mod - 1) < 65536;
+}
+
+static Geom make_geom(int N, int K) {
+  Geom g;
+  g.N = N;
+  g.nl = (N + 2 * K - 1) / (2 * K);
+  g.G = 64 / g.nl;
+  g.off = K * g.nl;
+  g.eo_len = 2 * K * g.nl;
+  g.a_len = K * g.nl;
+  return g;
+}
+
+extern "C" int ntru_engine_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char *ntru_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
+  if (!out) return fail(NTRU_ERR_ARG, "ntru_engine_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(NTRU_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                        "); this engine has no CPU fallback");
+  if (device < 0 || device >= n) return fail(NTRU_ERR_NO_DEVICE, "device id out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  ntru_engine *eng = new ntru_engine;
+  eng->device = device;
+  eng->stream = nullptr;
+  eng->cus = prop.multiProcessorCount;
+  *out = eng;
+  return NTRU_OK;
+}
+
+extern "C" void ntru_engine_destroy(ntru_engine_t *eng) { delete eng; }
+
+extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  eng->stream = (hipStream_t)hip_stream;
+  return NTRU_OK;
+}
+
+extern "C" int ntru_engine_synchronize(ntru_engine_t *eng) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipStreamSynchronize(eng->stream));
+  return NTRU_OK;
+}
+
+struct Launch { Geom g; int K; dim3 grid; size_t lds; };
+
+// shared_eo: number of EO arrays shared by the workgroup; per_item_eo: whether each item also needs its own EO array.
+static int plan(const ntru_engine *eng, int N, long B, int shared_eo, bool per_item_eo, Launch *L) {
+  int K = pick_K(N);
+  if (!K) return fail(NTRU_ERR_UNSUPPORTED, "N too large");
+  L->K = K;
+  L->g = make_geom(N, K);
+  size_t per_wave = (size_t)L->g.G * ((size_t)L->g.a_len * 4 + (per_item_eo ? (size_t)L->g.eo_len * 8 : 0));
+  L->lds = (size_t)shared_eo * L->g.eo_len * 8 + WAVES_PER_BLOCK * per_wave;
+  if (L->lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "parameter set needs more than 160 KiB of LDS");
+  long ngroups = (B + L->g.G - 1) / L->g.G;
+  long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  size_t by_lds = (160 * 1024) / (L->lds ? L->lds : 1);
+  long resident = (long)eng->cus * (long)(by_lds < 8 ? (by_lds ? by_lds : 1) : 8);
+  if (blocks > resident) blocks = resident;     // persistent: waves stride over the batch
+  if (blocks < 1) blocks = 1;
+  L->grid = dim3((unsigned)blocks);
+  return NTRU_OK;
+}
+
+template <class Kern>
+static int allow_lds(Kern kern, size_t bytes) {
+  if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return NTRU_OK;
+}
+
+#define DISPATCH_K(Kv, ...)                                                                       \
+  switch (Kv) {                                                                                     \
+    case 1: { constexpr int KK = 1; __VA_ARGS__; } break;                                                  \
+    case 3: { constexpr int KK = 3; __VA_ARGS__; } break;                                                  \
+    case 5: { constexpr int KK = 5; __VA_ARGS__; } break;                                                  \
+    case 7: { constexpr int KK = 7; __VA_ARGS__; } break;                                                  \
+    case 9: { constexpr int KK = 9; __VA_ARGS__; } break;                                                  \
+    case 11: { constexpr int KK = 11; __VA_ARGS__; } break;                                                \
+    case 13: { constexpr int KK = 13; __VA_ARGS__; } break;                                                \
+    case 15: { constexpr int KK = 15; __VA_ARGS__; } break;                                                \
+    default: return fail(NTRU_ERR_UNSUPPORTED, "no kernel for this K");                             \
+  }
+
+static int check_common(const ntru_engine *eng, int N, int q, long B) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  if (!is_pow2(q) || !ntru_engine_supports(N, q))
+    return fail(NTRU_ERR_UNSUPPORTED, "unsupported (N, q): need 2 <= N <= 1920 and q a power of two <= 65536");
+  return NTRU_OK;
+}
+
+extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const uint16_t *d_h, const uint8_t *d_r,
+                                      const uint8_t *d_m, int64_t B, uint16_t *d_e, uint16_t *d_quotE) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!d_h || !d_r || !d_m || !d_e) return fail(NTRU_ERR_ARG, "ntru_encrypt_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  Launch L;
+  if (int rc = plan(eng, N, B, 1, false, &L)) return rc;
+  DISPATCH_K(L.K, {
+    if (int rc = allow_lds(k_encrypt<KK>, L.lds)) return rc;
+    hipLaunchKernelGGL(k_encrypt<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, d_h, d_r, d_m,
+                       (long)B, d_e, d_quotE);
+  });
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f,
+                                      const uint8_t *d_fp, const uint16_t *d_e, int64_t B, uint8_t *d_value,
+                                      uint16_t *d_quot1, uint16_t *d_rem1, uint8_t *d_quot2) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (is_pow2(p) || !ntru_engine_supports(N, p))
+    return fail(NTRU_ERR_UNSUPPORTED, "unsupported p: need a small non-power-of-two modulus with N*(p-1)^2 < 65536");
+  if (B == 0) return NTRU_OK;
+  if (!d_f || !d_fp || !d_e || !d_value) return fail(NTRU_ERR_ARG, "ntru_decrypt_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  Launch L;
+  if (int rc = plan(eng, N, B, 2, false, &L)) return rc;
+  DISPATCH_K(L.K, {
+    if (int rc = allow_lds(k_decrypt<KK>, L.lds)) return rc;
+    hipLaunchKernelGGL(k_decrypt<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p, d_f, d_fp,
+                       d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
+  });
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b,
+                                      int64_t B, uint16_t *d_quot, uint16_t *d_rem) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  if (!ntru_engine_supports(N, mod))
+    return fail(NTRU_ERR_UNSUPPORTED, "unsupported (N, mod): mod must be a power of two <= 65536 or satisfy N*(mod-1)^2 < 65536");
+  if (B == 0) return NTRU_OK;
+  if (!d_a || !d_b || !d_quot || !d_rem) return fail(NTRU_ERR_ARG, "ntru_polymul_split: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  Launch L;
+  if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
+  DISPATCH_K(L.K, {
+    if (int rc = allow_lds(k_polymul_split<KK>, L.lds)) return rc;
+    hipLaunchKernelGGL(k_polymul_split<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)mod,
+                       (int)is_pow2(mod), d_a, d_b, (long)B, d_quot, d_rem);
+  });
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f,
+                                          const int8_t *d_g, const uint16_t *d_fq, const uint8_t *d_fp,
+                                          const uint16_t *d_h, int64_t B, uint16_t *d_quot_fq, uint16_t *d_rem_fq,
+                                          uint8_t *d_quot_fp, uint8_t *d_rem_fp, uint16_t *d_quot_h,
+                                          uint16_t *d_rem_h, uint8_t *d_flags) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (is_pow2(p) || !ntru_engine_supports(N, p))
+    return fail(NTRU_ERR_UNSUPPORTED, "unsupported p: need a small non-power-of-two modulus with N*(p-1)^2 < 65536");
+  if ((long)(q - 1) * p > 65535) return fail(NTRU_ERR_UNSUPPORTED, "p*(q-1) must fit 16 bits");
+  if (B == 0) return NTRU_OK;
+  if (!d_f || !d_g || !d_fq || !d_fp || !d_h || !d_quot_fq || !d_rem_fq || !d_quot_fp || !d_rem_fp || !d_quot_h ||
+      !d_rem_h || !d_flags)
+    return fail(NTRU_ERR_ARG, "ntru_verify_keys_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  Launch L;
+  if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
+  DISPATCH_K(L.K, {
+    if (int rc = allow_lds(k_verify_keys<KK>, L.lds)) return rc;
+    hipLaunchKernelGGL(k_verify_keys<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p, d_f, d_g,
+                       d_fq, d_fp, d_h, (long)B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h, d_flags);
+  });
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+static int check_elementwise(const ntru_engine *eng, int N, int mod, long B) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  if (N < 1 || mod < 2 || mod > 65536) return fail(NTRU_ERR_UNSUPPORTED, "need N >= 1 and 2 <= mod <= 65536");
+  return NTRU_OK;
+}
+
+static dim3 elementwise_grid(const ntru_engine *eng, long total) {
+  long blocks = (total + 255) / 256, cap = (long)eng->cus * 8;
+  return dim3((unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks)));
+}
+
+extern "C" int ntru_split_by_I_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, int64_t B,
+                                   uint16_t *d_quot, uint16_t *d_rem) {
+  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!d_a || !d_quot || !d_rem) return fail(NTRU_ERR_ARG, "ntru_split_by_I: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_split_by_I, elementwise_grid(eng, B * N), dim3(256), 0, eng->stream, N, (u32)mod, d_a, (long)B,
+                     d_quot, d_rem);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_add_batch_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b,
+                                  int64_t B, uint16_t *d_out) {
+  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!d_a || !d_b || !d_out) return fail(NTRU_ERR_ARG, "ntru_add_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_add_mod, elementwise_grid(eng, B * N), dim3(256), 0, eng->stream, (u32)mod, d_a, d_b,
+                     (long)B * N, d_out);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+// ---- host-pointer convenience entry points: stage through device buffers in bounded chunks -------------------
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { p = nullptr; return fail(NTRU_ERR_HIP, "hipMalloc failed"); }
+    return NTRU_OK;
+  }
+};
+
+static const int64_t HOST_CHUNK = 1 << 16;   // items per staged chunk
+
+#define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst).p, (src), (bytes), hipMemcpyHostToDevice, eng->stream))
+#define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src).p, (bytes), hipMemcpyDeviceToHost, eng->stream))
+
+extern "C" int ntru_encrypt_batch(ntru_engine_t *eng, int N, int q, const uint16_t *h, const uint8_t *r,
+                                  const uint8_t *m, int64_t B, uint16_t *e, uint16_t *quotE) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!h || !r || !m || !e) return fail(NTRU_ERR_ARG, "ntru_encrypt_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
+  DevBuf dh, dr, dm, de, dq;
+  if (dh.alloc((size_t)N * 2) || dr.alloc((size_t)C * N) || dm.alloc((size_t)C * N) || de.alloc((size_t)C * N * 2) ||
+      (quotE && dq.alloc((size_t)C * N * 2)))
+    return NTRU_ERR_HIP;
+  H2D(dh, h, (size_t)N * 2);
+  for (int64_t o = 0; o < B; o += C) {
+    const int64_t n = B - o < C ? B - o : C;
+    H2D(dr, r + o * N, (size_t)n * N);
+    H2D(dm, m + o * N, (size_t)n * N);
+    if (int rc = ntru_encrypt_batch_dev(eng, N, q, (const uint16_t *)dh.p, (const uint8_t *)dr.p, (const uint8_t *)dm.p,
+                                        n, (uint16_t *)de.p, quotE ? (uint16_t *)dq.p : nullptr))
+      return rc;
+    D2H(e + o * N, de, (size_t)n * N * 2);
+    if (quotE) D2H(quotE + o * N, dq, (size_t)n * N * 2);
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+  }
+  return NTRU_OK;
+}
+
+extern "C" int ntru_decrypt_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, const uint8_t *fp,
+                                  const uint16_t *e, int64_t B, uint8_t *value, uint16_t *quot1, uint16_t *rem1,
+                                  uint8_t *quot2) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!f || !fp || !e || !value) return fail(NTRU_ERR_ARG, "ntru_decrypt_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
+  DevBuf df, dfp, de, dv, dq1, dr1, dq2;
+  if (df.alloc(N) || dfp.alloc(N) || de.alloc((size_t)C * N * 2) || dv.alloc((size_t)C * N) ||
+      (quot1 && dq1.alloc((size_t)C * N * 2)) || (rem1 && dr1.alloc((size_t)C * N * 2)) ||
+      (quot2 && dq2.alloc((size_t)C * N)))
+    return NTRU_ERR_HIP;
+  H2D(df, f, (size_t)N);
+  H2D(dfp, fp, (size_t)N);
+  for (int64_t o = 0; o < B; o += C) {
+    const int64_t n = B - o < C ? B - o : C;
+    H2D(de, e + o * N, (size_t)n * N * 2);
+    if (int rc = ntru_decrypt_batch_dev(eng, N, q, p, (const int8_t *)df.p, (const uint8_t *)dfp.p,
+                                        (const uint16_t *)de.p, n, (uint8_t *)dv.p, quot1 ? (uint16_t *)dq1.p : nullptr,
+                                        rem1 ? (uint16_t *)dr1.p : nullptr, quot2 ? (uint8_t *)dq2.p : nullptr))
+      return rc;
+    D2H(value + o * N, dv, (size_t)n * N);
+    if (quot1) D2H(quot1 + o * N, dq1, (size_t)n * N * 2);
+    if (rem1) D2H(rem1 + o * N, dr1, (size_t)n * N * 2);
+    if (quot2) D2H(quot2 + o * N, dq2, (size_t)n * N);
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+  }
+  return NTRU_OK;
+}
+
+extern "C" int ntru_polymul_split(ntru_engine_t *eng, int N, int mod, const uint16_t *a, const uint16_t *b,
+                                  int64_t B, uint16_t *quot, uint16_t *rem) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  if (!ntru_engine_supports(N, mod))
+    return fail(NTRU_ERR_UNSUPPORTED, "unsupported (N, mod): mod must be a power of two <= 65536 or satisfy N*(mod-1)^2 < 65536");
+  if (B == 0) return NTRU_OK;
+  if (!a || !b || !quot || !rem) return fail(NTRU_ERR_ARG, "ntru_polymul_split: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
+  DevBuf da, db, dq, dr;
+  const size_t row = (size_t)N * 2;
+  if (da.alloc(C * row) || db.alloc(C * row) || dq.alloc(C * row) || dr.alloc(C * row)) return NTRU_ERR_HIP;
+  for (int64_t o = 0; o < B; o += C) {
+    const int64_t n = B - o < C ? B - o : C;
+    H2D(da, a + o * N, n * row);
+    H2D(db, b + o * N, n * row);
+    if (int rc = ntru_polymul_split_dev(eng, N, mod, (const uint16_t *)da.p, (const uint16_t *)db.p, n,
+                                        (uint16_t *)dq.p, (uint16_t *)dr.p))
+      return rc;
+    D2H(quot + o * N, dq, n * row);
+    D2H(rem + o * N, dr, n * row);
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+  }
+  return NTRU_OK;
+}
+
+extern "C" int ntru_verify_keys_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, const int8_t *g,
+                                      const uint16_t *fq, const uint8_t *fp, const uint16_t *h, int64_t B,
+                                      uint16_t *quot_fq, uint16_t *rem_fq, uint8_t *quot_fp, uint8_t *rem_fp,
+                                      uint16_t *quot_h, uint16_t *rem_h, uint8_t *flags) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!f || !g || !fq || !fp || !h || !quot_fq || !rem_fq || !quot_fp || !rem_fp || !quot_h || !rem_h || !flags)
+    return fail(NTRU_ERR_ARG, "ntru_verify_keys_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
+  const size_t r8 = (size_t)N, r16 = (size_t)N * 2;
+  DevBuf df, dg, dfq, dfp, dh, o1, o2, o3, o4, o5, o6, dfl;
+  if (df.alloc(C * r8) || dg.alloc(C * r8) || dfq.alloc(C * r16) || dfp.alloc(C * r8) || dh.alloc(C * r16) ||
+      o1.alloc(C * r16) || o2.alloc(C * r16) || o3.alloc(C * r8) || o4.alloc(C * r8) || o5.alloc(C * r16) ||
+      o6.alloc(C * r16) || dfl.alloc((size_t)C))
+    return NTRU_ERR_HIP;
+  for (int64_t o = 0; o < B; o += C) {
+    const int64_t n = B - o < C ? B - o : C;
+    H2D(df, f + o * N, n * r8); H2D(dg, g + o * N, n * r8); H2D(dfq, fq + o * N, n * r16);
+    H2D(dfp, fp + o * N, n * r8); H2D(dh, h + o * N, n * r16);
+    if (int rc = ntru_verify_keys_batch_dev(eng, N, q, p, (const int8_t *)df.p, (const int8_t *)dg.p,
+                                            (const uint16_t *)dfq.p, (const uint8_t *)dfp.p, (const uint16_t *)dh.p, n,
+                                            (uint16_t *)o1.p, (uint16_t *)o2.p, (uint8_t *)o3.p, (uint8_t *)o4.p,
+                                            (uint16_t *)o5.p, (uint16_t *)o6.p, (uint8_t *)dfl.p))
+      return rc;
+    D2H(quot_fq + o * N, o1, n * r16); D2H(rem_fq + o * N, o2, n * r16);
+    D2H(quot_fp + o * N, o3, n * r8); D2H(rem_fp + o * N, o4, n * r8);
+    D2H(quot_h + o * N, o5, n * r16); D2H(rem_h + o * N, o6, n * r16);
+    D2H(flags + o, dfl, (size_t)n);
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+  }
+  return NTRU_OK;
+}
+
+extern "C" int ntru_split_by_I(ntru_engine_t *eng, int N, int mod, const uint16_t *a, int64_t B, uint16_t *quot,
+                               uint16_t *rem) {
+  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!a || !quot || !rem) return fail(NTRU_ERR_ARG, "ntru_split_by_I: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
+  const size_t row = (size_t)N * 2;
+  DevBuf da, dq, dr;
+  if (da.alloc(C * row * 2) || dq.alloc(C * row) || dr.alloc(C * row)) return NTRU_ERR_HIP;
+  for (int64_t o = 0; o < B; o += C) {
+    const int64_t n = B - o < C ? B - o : C;
+    H2D(da, a + o * 2 * N, n * row * 2);
+    if (int rc = ntru_split_by_I_dev(eng, N, mod, (const uint16_t *)da.p, n, (uint16_t *)dq.p, (uint16_t *)dr.p)) return rc;
+    D2H(quot + o * N, dq, n * row);
+    D2H(rem + o * N, dr, n * row);
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+  }
+  return NTRU_OK;
+}
+
+extern "C" int ntru_add_batch(ntru_engine_t *eng, int N, int mod, const uint16_t *a, const uint16_t *b, int64_t B,
+                              uint16_t *out) {
+  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!a || !b || !out) return fail(NTRU_ERR_ARG, "ntru_add_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
+  const size_t row = (size_t)N * 2;
+  DevBuf da, db, dout;
+  if (da.alloc(C * row) || db.alloc(C * row) || dout.alloc(C * row)) return NTRU_ERR_HIP;
+  for (int64_t o = 0; o < B; o += C) {
+    const int64_t n = B - o < C ? B - o : C;
+    H2D(da, a + o * N, n * row);
+    H2D(db, b + o * N, n * row);
+    if (int rc = ntru_add_batch_dev(eng, N, mod, (const uint16_t *)da.p, (const uint16_t *)db.p, n, (uint16_t *)dout.p)) return rc;
+    D2H(out + o * N, dout, n * row);
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+  }
+  return NTRU_OK;
+}

@@ -1,0 +1,211 @@
+"""ctypes binding of include/ntru_engine.h (the engine's C ABI).  No computation happens here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ERR_NAMES = {1: "NTRU_ERR_NO_DEVICE", 2: "NTRU_ERR_ARG", 3: "NTRU_ERR_UNSUPPORTED", 4: "NTRU_ERR_HIP"}
+FLAG_INVALID_FQ, FLAG_INVALID_FP, FLAG_INVALID_H = 1, 2, 4
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, "error %d" % code), msg))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libntru_engine.so")
+
+
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+_SIGS = {
+    "ntru_engine_device_count": (C.c_int, []),
+    "ntru_engine_create": (C.c_int, [_i, C.POINTER(_vp)]),
+    "ntru_engine_destroy": (None, [_vp]),
+    "ntru_engine_set_stream": (C.c_int, [_vp, _vp]),
+    "ntru_engine_synchronize": (C.c_int, [_vp]),
+    "ntru_last_error": (C.c_char_p, []),
+    "ntru_engine_supports": (C.c_int, [_i, _i]),
+}
+for _sfx in ("", "_dev"):
+    _SIGS["ntru_polymul_split" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _i64, _vp, _vp])
+    _SIGS["ntru_split_by_I" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i64, _vp, _vp])
+    _SIGS["ntru_add_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _i64, _vp])
+    _SIGS["ntru_encrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
+    _SIGS["ntru_decrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
+    _SIGS["ntru_verify_keys_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i] + [_vp] * 5 + [_i64] + [_vp] * 7)
+
+
+def _preload_hip_runtime():
+    """Keep ONE HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (same SONAME as
+    /opt/rocm's, found through an RPATH under the plain name); if the engine pulled /opt/rocm's copy in first, a
+    later `import torch` would load a second runtime that sees no device.  When torch is installed, load its copy
+    first: the engine's NEEDED libamdhip64.so.7 then binds to it by SONAME.  Without torch (C, Node.js) the
+    engine's RUNPATH finds /opt/rocm as usual."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def load_library():
+    """dlopen the HIP engine.  Fails loudly when it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise EngineError(0, "HIP engine library %s is missing; run `python -c 'import __graft_entry__ as g; "
+                                 "g.build()'` or `make -C ntru-circom_amd/csrc`" % path)
+        _preload_hip_runtime()
+        lib = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+def _np(a, dt, shape=None):
+    arr = np.ascontiguousarray(np.asarray(a, dtype=dt))
+    return arr.reshape(shape) if shape is not None else arr
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One engine per HIP device.  Host-buffer methods take/return numpy arrays; *_dev methods take raw
+    device pointers (ints, e.g. torch.Tensor.data_ptr()) and only enqueue work on the engine's stream."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        self._h = None
+        self._chk(self._lib.ntru_engine_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def _chk(self, rc):
+        if rc:
+            raise EngineError(rc, self._lib.ntru_last_error().decode())
+
+    def close(self):
+        if self._h is not None:
+            self._lib.ntru_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self._chk(self._lib.ntru_engine_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
+
+    def synchronize(self):
+        self._chk(self._lib.ntru_engine_synchronize(self._h))
+
+    def supports(self, N, mod):
+        return bool(self._lib.ntru_engine_supports(int(N), int(mod)))
+
+    # ---- host buffers ------------------------------------------------------------------------------------
+    def polymul_split(self, N, mod, a, b):
+        a, b = _np(a, np.uint16).reshape(-1, N), _np(b, np.uint16).reshape(-1, N)
+        B = a.shape[0]
+        quot, rem = np.empty((B, N), np.uint16), np.empty((B, N), np.uint16)
+        self._chk(self._lib.ntru_polymul_split(self._h, N, mod, _ptr(a), _ptr(b), B, _ptr(quot), _ptr(rem)))
+        return quot, rem
+
+    def split_by_I(self, N, mod, a):
+        a = _np(a, np.uint16).reshape(-1, 2 * N)
+        B = a.shape[0]
+        quot, rem = np.empty((B, N), np.uint16), np.empty((B, N), np.uint16)
+        self._chk(self._lib.ntru_split_by_I(self._h, N, mod, _ptr(a), B, _ptr(quot), _ptr(rem)))
+        return quot, rem
+
+    def add_batch(self, N, mod, a, b):
+        a, b = _np(a, np.uint16).reshape(-1, N), _np(b, np.uint16).reshape(-1, N)
+        B = a.shape[0]
+        out = np.empty((B, N), np.uint16)
+        self._chk(self._lib.ntru_add_batch(self._h, N, mod, _ptr(a), _ptr(b), B, _ptr(out)))
+        return out
+
+    def encrypt_batch(self, N, q, h, r, m, want_quot=True):
+        h = _np(h, np.uint16, (N,))
+        r, m = _np(r, np.uint8).reshape(-1, N), _np(m, np.uint8).reshape(-1, N)
+        B = r.shape[0]
+        e = np.empty((B, N), np.uint16)
+        quot = np.empty((B, N), np.uint16) if want_quot else None
+        self._chk(self._lib.ntru_encrypt_batch(self._h, N, q, _ptr(h), _ptr(r), _ptr(m), B, _ptr(e), _ptr(quot)))
+        return e, quot
+
+    def decrypt_batch(self, N, q, p, f, fp, e, want_witness=True):
+        f, fp = _np(f, np.int8, (N,)), _np(fp, np.uint8, (N,))
+        e = _np(e, np.uint16).reshape(-1, N)
+        B = e.shape[0]
+        value = np.empty((B, N), np.uint8)
+        q1 = np.empty((B, N), np.uint16) if want_witness else None
+        r1 = np.empty((B, N), np.uint16) if want_witness else None
+        q2 = np.empty((B, N), np.uint8) if want_witness else None
+        self._chk(self._lib.ntru_decrypt_batch(self._h, N, q, p, _ptr(f), _ptr(fp), _ptr(e), B, _ptr(value),
+                                               _ptr(q1), _ptr(r1), _ptr(q2)))
+        return value, q1, r1, q2
+
+    def verify_keys_batch(self, N, q, p, f, g, fq, fp, h):
+        f, g = _np(f, np.int8).reshape(-1, N), _np(g, np.int8).reshape(-1, N)
+        fq, h = _np(fq, np.uint16).reshape(-1, N), _np(h, np.uint16).reshape(-1, N)
+        fp = _np(fp, np.uint8).reshape(-1, N)
+        B = f.shape[0]
+        out = {"quot_fq": np.empty((B, N), np.uint16), "rem_fq": np.empty((B, N), np.uint16),
+               "quot_fp": np.empty((B, N), np.uint8), "rem_fp": np.empty((B, N), np.uint8),
+               "quot_h": np.empty((B, N), np.uint16), "rem_h": np.empty((B, N), np.uint16),
+               "flags": np.empty(B, np.uint8)}
+        self._chk(self._lib.ntru_verify_keys_batch(self._h, N, q, p, _ptr(f), _ptr(g), _ptr(fq), _ptr(fp), _ptr(h), B,
+                                                   _ptr(out["quot_fq"]), _ptr(out["rem_fq"]), _ptr(out["quot_fp"]),
+                                                   _ptr(out["rem_fp"]), _ptr(out["quot_h"]), _ptr(out["rem_h"]),
+                                                   _ptr(out["flags"])))
+        return out
+
+    # ---- device pointers (asynchronous) -------------------------------------------------------------------
+    @staticmethod
+    def _dp(x):
+        return C.c_void_p(int(x)) if x else None
+
+    def polymul_split_dev(self, N, mod, d_a, d_b, B, d_quot, d_rem):
+        dp = self._dp
+        self._chk(self._lib.ntru_polymul_split_dev(self._h, N, mod, dp(d_a), dp(d_b), B, dp(d_quot), dp(d_rem)))
+
+    def split_by_I_dev(self, N, mod, d_a, B, d_quot, d_rem):
+        dp = self._dp
+        self._chk(self._lib.ntru_split_by_I_dev(self._h, N, mod, dp(d_a), B, dp(d_quot), dp(d_rem)))
+
+    def add_batch_dev(self, N, mod, d_a, d_b, B, d_out):
+        dp = self._dp
+        self._chk(self._lib.ntru_add_batch_dev(self._h, N, mod, dp(d_a), dp(d_b), B, dp(d_out)))
+
+    def encrypt_batch_dev(self, N, q, d_h, d_r, d_m, B, d_e, d_quotE=None):
+        dp = self._dp
+        self._chk(self._lib.ntru_encrypt_batch_dev(self._h, N, q, dp(d_h), dp(d_r), dp(d_m), B, dp(d_e), dp(d_quotE)))
+
+    def decrypt_batch_dev(self, N, q, p, d_f, d_fp, d_e, B, d_value, d_quot1=None, d_rem1=None, d_quot2=None):
+        dp = self._dp
+        self._chk(self._lib.ntru_decrypt_batch_dev(self._h, N, q, p, dp(d_f), dp(d_fp), dp(d_e), B, dp(d_value),
+                                                   dp(d_quot1), dp(d_rem1), dp(d_quot2)))
+
+    def verify_keys_batch_dev(self, N, q, p, d_f, d_g, d_fq, d_fp, d_h, B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp,
+                              d_quot_h, d_rem_h, d_flags):
+        dp = self._dp
+        self._chk(self._lib.ntru_verify_keys_batch_dev(self._h, N, q, p, dp(d_f), dp(d_g), dp(d_fq), dp(d_fp), dp(d_h),
+                                                       B, dp(d_quot_fq), dp(d_rem_fq), dp(d_quot_fp), dp(d_rem_fp),
+                                                       dp(d_quot_h), dp(d_rem_h), dp(d_flags)))

@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol the header declares, does its
+argument checking on the host, and fails loudly (no fallback) without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+ROOT = ge.ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    ge.build()
+    return pkg.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ntru_engine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ntru_[a-zA-Z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), "libntru_engine.so does not export %s" % n
+
+
+def test_supports_matrix(lib):
+    ok = [(821, 4096), (701, 8192), (509, 2048), (167, 128), (17, 32), (821, 3), (2, 2), (1920, 65536), (167, 7)]
+    bad = [(1, 32), (1921, 2048), (821, 131072), (821, 11), (821, 1), (821, 0), (821, 6000)]
+    for N, mod in ok:
+        assert lib.ntru_engine_supports(N, mod) == 1, (N, mod)
+    for N, mod in bad:
+        assert lib.ntru_engine_supports(N, mod) == 0, (N, mod)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    if lib.ntru_engine_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.EngineError) as ei:
+        pkg.Engine(0)
+    assert ei.value.code == 1 and "no CPU fallback" in str(ei.value)
+    ntru = pkg.NTRU({"N": 17, "q": 32, "dr": 2, "h": [1, 2, 3]})
+    with pytest.raises(pkg.EngineError):
+        ntru.encryptBits([1, 0, 1])
+
+
+def test_null_engine_is_rejected(lib):
+    rc = lib.ntru_encrypt_batch(None, 17, 32, None, None, None, 1, None, None)
+    assert rc == 2 and b"NULL" in lib.ntru_last_error()
+
+
+def test_product_package_never_touches_the_oracle():
+    # the shipped path must not import / dlopen anything under oracle/
+    for dirpath, _, files in os.walk(ge.PKG_DIR):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".c", ".h", ".mjs", ".js")):
+                src = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in src.replace("SURVEY", ""), "%s mentions the oracle" % fn
+
+
+def test_host_helpers_match_reference(pure_golden):
+    for v in pure_golden["misc"]["trim"]:
+        assert pkg.trimPolynomial(v["a"]) == v["out"]
+    for v in pure_golden["misc"]["degree"]:
+        assert pkg.degree(v["a"]) == v["out"]
+    for v in pure_golden["add"]:
+        assert pkg.addPolynomials(v["a"], v["b"], v["p"]) == v["out"]
+    for v in pure_golden["sampler"]:
+        if v.get("error"):
+            with pytest.raises(ValueError, match="cannot exceed"):
+                pkg.generateCustomArray(v["len"], v["n1"], v["nm1"])
+            continue
+        it = iter(v["draws"])
+        assert pkg.generateCustomArray(v["len"], v["n1"], v["nm1"], rand_u32=lambda: next(it)) == v["out"]
+    g = pure_golden["misc"]["stringToBits"][0]
+    assert pkg.stringToBits(g["s"]) == g["out"] and pkg.bitsToString(g["out"]) == g["s"]
+    for v in pure_golden["misc"]["NqNp"]:
+        n = pkg.NTRU({"N": v["N"], "q": v["q"]})
+        assert (n.calculateNq(), n.calculateNp()) == (v["Nq"], v["Np"])
+    with pytest.raises(ValueError, match="Invalid array length"):
+        pkg.expandArray([1, 2, 3], 2)
