@@ -50,11 +50,6 @@ def load_key(profile):
     return o, pad(key["h"], np.uint16), pad(key["f"], np.int8), pad(key["fp"], np.uint8)
 
 
-def shard_seed(base, rank):
-    """Per-rank seed of the synthetic shard (printed in the report so the run can be replayed)."""
-    return base + 7919 * rank
-
-
 def make_inputs(torch, dev, B, N, d, seed):
     """m iid uniform {0,1}; r = d ones and d twos per row, shuffled."""
     gen = torch.Generator(device=dev)
@@ -122,7 +117,8 @@ def main():
     o, h_np, f_np, fp_np = load_key(args.profile)
     N, q, p, d = o["N"], o["q"], o["p"], o["dr"]
     B = 1 << args.batch_log2
-    seed = shard_seed(20240, rank)
+    sh = pkg.sharding
+    seed = sh.shard_seed(20240, rank)
     r, m = make_inputs(torch, dev, B, N, d, seed)
     h = torch.from_numpy(h_np.view(np.int16)).to(dev)
     f = torch.from_numpy(f_np).to(dev)
@@ -148,20 +144,12 @@ def main():
     for _ in range(args.warmup):
         step()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def run_steps():
+        for k in range(args.steps):
+            step(events[k])
+
+    elapsed = sh.timed_region(run_steps, torch.cuda.synchronize, dist, dev)
     enc_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events]))
     dec_ms = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in events]))
 
@@ -180,11 +168,10 @@ def main():
 
     gathered = None
     if args.gather and dist:
-        outs = [torch.empty_like(value) for _ in range(world)]
         torch.cuda.synchronize(); tg = time.perf_counter()
-        dist.all_gather(outs, value)
+        allv = sh.gather_rows(value, dist)
         torch.cuda.synchronize()
-        gathered = {"bytes_per_rank": int(value.numel()), "seconds": time.perf_counter() - tg}
+        gathered = {"rows": int(allv.shape[0]), "bytes_per_rank": int(value.numel()), "seconds": time.perf_counter() - tg}
 
     if rank == 0:
         total = world * B * args.steps

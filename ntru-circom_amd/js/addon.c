@@ -1,0 +1,200 @@
+/*
+ * addon.c -- N-API binding of include/ntru_engine.h for Node.js (N-API v3+, works on Node 12).
+ *
+ * Thin by design: every exported function unpacks TypedArray arguments into the plain pointers the C ABI takes
+ * (napi_get_typedarray_info), calls the engine, and throws a JS Error carrying ntru_last_error() on failure.
+ * All reference-shaped behaviour (padding, trimming, {value, inputs, params} objects) lives in index.mjs.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ntru_engine.h"
+
+#define NAPI_OK(call)                                                              \
+  do {                                                                             \
+    if ((call) != napi_ok) {                                                       \
+      napi_throw_error(env, NULL, "N-API call failed: " #call);                    \
+      return NULL;                                                                 \
+    }                                                                              \
+  } while (0)
+
+static ntru_engine_t *g_engine = NULL;
+
+static napi_value throw_engine(napi_env env, int rc) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "ntru engine error %d: %s", rc, ntru_last_error());
+  napi_throw_error(env, NULL, buf);
+  return NULL;
+}
+
+static int get_i32(napi_env env, napi_value v, int32_t *out) { return napi_get_value_int32(env, v, out) == napi_ok; }
+
+/* Returns the data pointer of a TypedArray of the wanted element type holding at least `need` elements;
+ * null/undefined gives NULL when `optional`. */
+static int get_buf(napi_env env, napi_value v, napi_typedarray_type want, size_t need, int optional, void **out) {
+  napi_valuetype vt;
+  *out = NULL;
+  if (napi_typeof(env, v, &vt) != napi_ok) return 0;
+  if (vt == napi_null || vt == napi_undefined) return optional;
+  bool is_ta = false;
+  if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) return 0;
+  napi_typedarray_type t; size_t len; void *data;
+  if (napi_get_typedarray_info(env, v, &t, &len, &data, NULL, NULL) != napi_ok) return 0;
+  if (t != want || len < need) return 0;
+  *out = data;
+  return 1;
+}
+
+#define ARGS(n)                                                                    \
+  size_t argc = (n);                                                               \
+  napi_value argv[(n)];                                                            \
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));                   \
+  if (argc < (n)) { napi_throw_type_error(env, NULL, "too few arguments"); return NULL; }
+
+#define BAD_ARGS() do { napi_throw_type_error(env, NULL, "bad argument types / sizes"); return NULL; } while (0)
+
+static napi_value undefined(napi_env env) { napi_value u; napi_get_undefined(env, &u); return u; }
+
+static int ensure_engine(napi_env env) {
+  if (g_engine) return 1;
+  napi_throw_error(env, NULL, "ntru engine not created: call create(device) first (there is no CPU fallback)");
+  return 0;
+}
+
+static napi_value DeviceCount(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value r; NAPI_OK(napi_create_int32(env, ntru_engine_device_count(), &r)); return r;
+}
+
+static napi_value Create(napi_env env, napi_callback_info info) {
+  ARGS(1)
+  int32_t dev;
+  if (!get_i32(env, argv[0], &dev)) BAD_ARGS();
+  if (g_engine) { ntru_engine_destroy(g_engine); g_engine = NULL; }
+  int rc = ntru_engine_create(dev, &g_engine);
+  if (rc) return throw_engine(env, rc);
+  return undefined(env);
+}
+
+static napi_value Destroy(napi_env env, napi_callback_info info) {
+  (void)info;
+  if (g_engine) { ntru_engine_destroy(g_engine); g_engine = NULL; }
+  return undefined(env);
+}
+
+static napi_value Supports(napi_env env, napi_callback_info info) {
+  ARGS(2)
+  int32_t N, mod;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &mod)) BAD_ARGS();
+  napi_value r; NAPI_OK(napi_get_boolean(env, ntru_engine_supports(N, mod) != 0, &r)); return r;
+}
+
+/* polymulSplit(N, mod, a:Uint16Array, b:Uint16Array, B, quot:Uint16Array, rem:Uint16Array) */
+static napi_value PolymulSplit(napi_env env, napi_callback_info info) {
+  ARGS(7)
+  int32_t N, mod, B; void *a, *b, *quot, *rem;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &mod) || !get_i32(env, argv[4], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[2], napi_uint16_array, n, 0, &a) || !get_buf(env, argv[3], napi_uint16_array, n, 0, &b) ||
+      !get_buf(env, argv[5], napi_uint16_array, n, 0, &quot) || !get_buf(env, argv[6], napi_uint16_array, n, 0, &rem)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_polymul_split(g_engine, N, mod, a, b, B, quot, rem);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* splitByI(N, mod, a:Uint16Array[B*2N], B, quot, rem) */
+static napi_value SplitByI(napi_env env, napi_callback_info info) {
+  ARGS(6)
+  int32_t N, mod, B; void *a, *quot, *rem;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &mod) || !get_i32(env, argv[3], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[2], napi_uint16_array, 2 * n, 0, &a) || !get_buf(env, argv[4], napi_uint16_array, n, 0, &quot) ||
+      !get_buf(env, argv[5], napi_uint16_array, n, 0, &rem)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_split_by_I(g_engine, N, mod, a, B, quot, rem);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* addBatch(N, mod, a, b, B, out) */
+static napi_value AddBatch(napi_env env, napi_callback_info info) {
+  ARGS(6)
+  int32_t N, mod, B; void *a, *b, *out;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &mod) || !get_i32(env, argv[4], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[2], napi_uint16_array, n, 0, &a) || !get_buf(env, argv[3], napi_uint16_array, n, 0, &b) ||
+      !get_buf(env, argv[5], napi_uint16_array, n, 0, &out)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_add_batch(g_engine, N, mod, a, b, B, out);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* encryptBatch(N, q, h:Uint16Array[N], r:Uint8Array[B*N], m:Uint8Array[B*N], B, e:Uint16Array, quotE:Uint16Array|null) */
+static napi_value EncryptBatch(napi_env env, napi_callback_info info) {
+  ARGS(8)
+  int32_t N, q, B; void *h, *r, *m, *e, *quot;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[5], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[2], napi_uint16_array, (size_t)N, 0, &h) || !get_buf(env, argv[3], napi_uint8_array, n, 0, &r) ||
+      !get_buf(env, argv[4], napi_uint8_array, n, 0, &m) || !get_buf(env, argv[6], napi_uint16_array, n, 0, &e) ||
+      !get_buf(env, argv[7], napi_uint16_array, n, 1, &quot)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_encrypt_batch(g_engine, N, q, h, r, m, B, e, quot);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* decryptBatch(N, q, p, f:Int8Array[N], fp:Uint8Array[N], e:Uint16Array[B*N], B, value:Uint8Array,
+ *              quot1:Uint16Array|null, rem1:Uint16Array|null, quot2:Uint8Array|null) */
+static napi_value DecryptBatch(napi_env env, napi_callback_info info) {
+  ARGS(11)
+  int32_t N, q, p, B; void *f, *fp, *e, *value, *q1, *r1, *q2;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) ||
+      !get_i32(env, argv[6], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[3], napi_int8_array, (size_t)N, 0, &f) || !get_buf(env, argv[4], napi_uint8_array, (size_t)N, 0, &fp) ||
+      !get_buf(env, argv[5], napi_uint16_array, n, 0, &e) || !get_buf(env, argv[7], napi_uint8_array, n, 0, &value) ||
+      !get_buf(env, argv[8], napi_uint16_array, n, 1, &q1) || !get_buf(env, argv[9], napi_uint16_array, n, 1, &r1) ||
+      !get_buf(env, argv[10], napi_uint8_array, n, 1, &q2)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_decrypt_batch(g_engine, N, q, p, f, fp, e, B, value, q1, r1, q2);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* verifyKeysBatch(N, q, p, f:Int8Array, g:Int8Array, fq:Uint16Array, fp:Uint8Array, h:Uint16Array, B,
+ *                 quotFq, remFq :Uint16Array, quotFp, remFp :Uint8Array, quotH, remH :Uint16Array, flags:Uint8Array[B]) */
+static napi_value VerifyKeysBatch(napi_env env, napi_callback_info info) {
+  ARGS(16)
+  int32_t N, q, p, B; void *f, *g, *fq, *fp, *h, *o1, *o2, *o3, *o4, *o5, *o6, *fl;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) ||
+      !get_i32(env, argv[8], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[3], napi_int8_array, n, 0, &f) || !get_buf(env, argv[4], napi_int8_array, n, 0, &g) ||
+      !get_buf(env, argv[5], napi_uint16_array, n, 0, &fq) || !get_buf(env, argv[6], napi_uint8_array, n, 0, &fp) ||
+      !get_buf(env, argv[7], napi_uint16_array, n, 0, &h) || !get_buf(env, argv[9], napi_uint16_array, n, 0, &o1) ||
+      !get_buf(env, argv[10], napi_uint16_array, n, 0, &o2) || !get_buf(env, argv[11], napi_uint8_array, n, 0, &o3) ||
+      !get_buf(env, argv[12], napi_uint8_array, n, 0, &o4) || !get_buf(env, argv[13], napi_uint16_array, n, 0, &o5) ||
+      !get_buf(env, argv[14], napi_uint16_array, n, 0, &o6) || !get_buf(env, argv[15], napi_uint8_array, (size_t)B, 0, &fl)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_verify_keys_batch(g_engine, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  napi_property_descriptor props[] = {
+    {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
+    {"create", NULL, Create, NULL, NULL, NULL, napi_default, NULL},
+    {"destroy", NULL, Destroy, NULL, NULL, NULL, napi_default, NULL},
+    {"supports", NULL, Supports, NULL, NULL, NULL, napi_default, NULL},
+    {"polymulSplit", NULL, PolymulSplit, NULL, NULL, NULL, napi_default, NULL},
+    {"splitByI", NULL, SplitByI, NULL, NULL, NULL, napi_default, NULL},
+    {"addBatch", NULL, AddBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"encryptBatch", NULL, EncryptBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"decryptBatch", NULL, DecryptBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"verifyKeysBatch", NULL, VerifyKeysBatch, NULL, NULL, NULL, napi_default, NULL},
+  };
+  if (napi_define_properties(env, exports, sizeof props / sizeof props[0], props) != napi_ok) return NULL;
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

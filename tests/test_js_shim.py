@@ -1,0 +1,48 @@
+"""The Node.js side of the boundary: N-API addon + ES-module shim (ntru-circom_amd/js)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import __graft_entry__ as ge
+
+NODE = shutil.which("node")
+JS = os.path.join(ge.PKG_DIR, "js")
+
+
+def _node(args, **kw):
+    return subprocess.run([NODE] + args, cwd=ge.ROOT, capture_output=True, text=True, timeout=600, **kw)
+
+
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_addon_builds_loads_and_fails_loudly_without_gpu():
+    ge.build()
+    assert os.path.exists(os.path.join(JS, "ntru_addon.node"))
+    code = ("import NTRU, * as lib from '../../ntru-circom_amd/js/index.mjs';"
+            "const names=['degree','trimPolynomial','addPolynomials','multiplyPolynomials','dividePolynomials',"
+            "'expandArray','expandArrayToMultiple','generateCustomArray','stringToBits','bitsToString'];"
+            "for (const n of names) if (typeof lib[n] !== 'function') throw new Error('missing export '+n);"
+            "const n = new NTRU({N:17,q:32,dr:2,h:[1,2,3]});"
+            "if (n.I.length !== 18 || n.I[17] !== -1 || n.calculateNq() !== 15) throw new Error('ctor');"
+            "console.log('devices', lib.deviceCount());"
+            "if (lib.deviceCount() === 0) { try { n.encryptBits([1,0,1]); throw new Error('no throw'); }"
+            " catch (e) { if (!/no CPU fallback/.test(e.message)) throw e; console.log('loud failure ok'); } }")
+    path = os.path.join(ge.ROOT, "tests", "js", "_probe.mjs")
+    with open(path, "w") as fh:
+        fh.write(code)
+    try:
+        r = _node([path])
+    finally:
+        os.remove(path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "devices" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_shim_reproduces_reference_witnesses():
+    ge.build()
+    r = _node([os.path.join(ge.ROOT, "tests", "js", "shim_golden.mjs")])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "shim_golden:" in r.stdout
