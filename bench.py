@@ -37,6 +37,8 @@ def parse_args():
                     help="witness: every array the reference returns; value: ciphertext / plaintext only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-path", choices=["auto", "mac", "add"], default="auto",
+                    help="kernel family: packed-u16 MAC, ternary add path, or the engine's choice (same results)")
     ap.add_argument("--gather", action="store_true", help="after timing, all_gather the decrypted values (RCCL)")
     return ap.parse_args()
 
@@ -133,6 +135,7 @@ def main():
     eng = pkg.Engine(local_rank)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
+    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2}[args.kernel_path])
 
     def step(ev=None):
         if ev: ev[0].record(stream)
@@ -188,7 +191,7 @@ def main():
             "config": {"workload": "N=%d q=%d p=%d d=%d, batch=2^%d round trips per GPU per step, shared golden key, "
                                    "%s outputs" % (N, q, p, d, args.batch_log2,
                                                    "full-witness" if witness else "value-only"),
-                       "mode": args.mode, "seed": 20240, "parallelism": "batch-sharded x%d, no collective" % world},
+                       "mode": args.mode, "kernel_path": args.kernel_path, "seed": 20240, "parallelism": "batch-sharded x%d, no collective" % world},
             "verified_bit_exact_rows": int(rows.numel()),
             "kernels_ms": {"k_encrypt": enc_ms, "k_decrypt": dec_ms},
             "roofline": {"bound": "hbm", "kernel": "k_decrypt", "achieved": dec_gbs, "peak": HBM_PEAK_GBS,

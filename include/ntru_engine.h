@@ -60,6 +60,9 @@ void ntru_engine_destroy(ntru_engine_t *eng);
 /* Use `hip_stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) for all later calls.
  * The engine never owns the stream. */
 int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
+/* Tuning / test knob: 0 = pick the fastest applicable kernel family (default), 1 = always the packed-u16 MAC
+ * kernels, 2 = the ternary add path wherever it applies.  Results are identical. */
+int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
 /* Block until everything enqueued on the engine's stream has finished. */
 int ntru_engine_synchronize(ntru_engine_t *eng);
 

@@ -335,6 +335,613 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod
   }
 }
 
+
+// ================================================================================================================
+// Ternary-stepping kernels ("add path").
+//
+// Every product on the hot path has one TERNARY operand (r, f, g, the lifted message), and on gfx950 every packed /
+// multiply VALU op issues at 4 cycles per wave while a plain v_add_u32 issues at 2 (profiles/r01_microbench_valu_lds.txt).
+// So the ternary operand becomes the stepping operand: it is turned into 2-bit codes (0 skip, 1 "+w into S1",
+// 2 "+w into S2"; the other symbol c = 2 or -1 is applied once at the end, T = S1 + c*S2), the codes of one block of
+// 2K steps live in one wave-uniform dword, zero steps are skipped by a scalar branch, and the windowed operand is
+// accumulated with v_add_u32 on two packed 16-bit fields.  A field may only hold `limit` additions of values < q on
+// top of a masked value before it could carry into its neighbour; popcounts of the code word keep that budget and
+// the accumulators are masked (mod q is free: q | 2^16) only when the next K steps could exceed it.
+// Needs one item per wave (nl > 32), K <= 7 (2K codes in a dword) and (K+1)*(q-1) <= 65535; otherwise the MAC
+// kernels above are used.
+// ================================================================================================================
+
+// bit j: step j adds into S1 (value 1); bit 16+j: step j adds into S2 (the other non-zero symbol)
+static __device__ __forceinline__ u32 step_bits(u32 v, int j) { return v == 0 ? 0u : (v == 1 ? 1u << j : 1u << (16 + j)); }
+
+template <int K> struct TernOps;
+template <>
+struct TernOps<1> {
+  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
+  template <int BIT>
+  static __device__ __forceinline__ void add_if(u32 (&S)[1], const u32 (&W)[1], u32 word) {
+    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
+                 "1:\n"
+                 : [s0] "+v"(S[0])
+                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<3> {
+  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
+  template <int BIT>
+  static __device__ __forceinline__ void add_if(u32 (&S)[3], const u32 (&W)[3], u32 word) {
+    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
+                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
+                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
+                 "1:\n"
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2])
+                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<5> {
+  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
+  template <int BIT>
+  static __device__ __forceinline__ void add_if(u32 (&S)[5], const u32 (&W)[5], u32 word) {
+    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
+                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
+                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
+                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
+                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
+                 "1:\n"
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4])
+                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<7> {
+  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
+  template <int BIT>
+  static __device__ __forceinline__ void add_if(u32 (&S)[7], const u32 (&W)[7], u32 word) {
+    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
+                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
+                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
+                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
+                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
+                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
+                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
+                 "1:\n"
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6])
+                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6])
+                 : "scc");
+  }
+};
+
+// Steps J .. 2K-1 of one block (compile-time recursion so every bit index / register index is an immediate).
+// word: bit j = "step j adds into S1", bit 16+j = "step j adds into S2".  ME: mask both sets every ME steps
+// (0 = never: exact small sums).  At most ME additions of values < q land on a masked field between masks.
+template <int K, int ME, int J>
+static __device__ __forceinline__ void tern_steps(u32 (&S1)[K], u32 (&S2)[K], u32 (&WE)[K], u32 (&WO)[K],
+                                                  const uint2 (&nw)[K], u32 word, u32 fmask) {
+  if constexpr (J < 2 * K) {
+    if constexpr (ME > 0 && J % (ME > 0 ? ME : 1) == 0) {
+#pragma unroll
+      for (int t = 0; t < K; t++) { S1[t] &= fmask; S2[t] &= fmask; }
+    }
+    constexpr int s = J >> 1;
+    u32 W[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) W[t] = (J & 1) ? WO[(t - s + K) % K] : WE[(t - s + K) % K];
+    TernOps<K>::template add_if<J>(S1, W, word);
+    TernOps<K>::template add_if<16 + J>(S2, W, word);
+    if constexpr ((J & 1) != 0) { WE[K - 1 - s] = nw[s].x; WO[K - 1 - s] = nw[s].y; }
+    tern_steps<K, ME, J + 1>(S1, S2, WE, WO, nw, word, fmask);
+  }
+}
+
+template <int K, int ME>
+static __device__ __forceinline__ void tern_core(const uint2 *__restrict__ eo, const u32 *__restrict__ codes,
+                                                 const Geom &g, int sub, bool want_low, u32 fmask,
+                                                 u32 (&S1)[K], u32 (&S2)[K], u32 (&L1)[K], u32 (&L2)[K]) {
+  u32 WE[K], WO[K];
+  const uint2 *nb = eo + (K * sub + g.off);
+#pragma unroll
+  for (int x = 0; x < K; x++) { uint2 v = nb[x]; WE[x] = v.x; WO[x] = v.y; }
+#pragma unroll
+  for (int t = 0; t < K; t++) { S1[t] = 0; S2[t] = 0; L1[t] = 0; L2[t] = 0; }
+  const int nblk = g.nl;
+  u32 word = __builtin_amdgcn_readfirstlane(codes[0]);
+  for (int m = 0; m < nblk; m++) {
+    const u32 next_raw = codes[m + 1 < nblk ? m + 1 : m];
+    if (want_low && m == sub) {
+#pragma unroll
+      for (int t = 0; t < K; t++) { L1[t] = S1[t]; L2[t] = S2[t]; }
+    }
+    uint2 nw[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) nw[s] = nb[-1 - s];
+    tern_steps<K, ME, 0>(S1, S2, WE, WO, nw, word, fmask);
+    word = __builtin_amdgcn_readfirstlane(next_raw);
+    nb -= K;
+  }
+}
+
+// T = S1 + c*S2 per 16-bit field, as a u16 pair (mod 2^16 from here on).  NEG: c = -1 (mod q), else c = 2.
+template <bool NEG>
+static __device__ __forceinline__ u16x2 tern_combine(u32 s1, u32 s2, u32 fmask, u32 qq) {
+  s1 &= fmask; s2 &= fmask;
+  return as_pair(NEG ? s1 + (qq - s2) : s1 + (s2 << 1));
+}
+
+// Finish one ternary-stepped product: remainder / quotient pairs like product_split.
+//   av: the lane's own 2K stepping-operand values (numeric, as u16 pairs) for the in-block triangle.
+template <int K, int ME, bool NEG>
+static __device__ __forceinline__ void tern_product_split(const uint2 *eo, const u32 *codes, const u32 (&av)[K],
+                                                          const Geom &g, int sub, bool want_quot, u32 mod,
+                                                          u16x2 (&rem)[K], u16x2 (&quot)[K]) {
+  constexpr bool POW2 = ME > 0;
+  u32 S1[K], S2[K], L1[K], L2[K];
+  const u32 fmask = POW2 ? (mod - 1) * 0x00010001u : 0xFFFFFFFFu;
+  const u32 qq = mod * 0x00010001u;
+  tern_core<K, ME>(eo, codes, g, sub, want_quot, fmask, S1, S2, L1, L2);
+  u16x2 T[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) T[t] = tern_combine<NEG>(S1[t], S2[t], fmask, qq);
+  if (want_quot) {
+    u32 ZE[K], ZO[K];
+#pragma unroll
+    for (int x = 0; x < K; x++) { uint2 v = eo[g.off + x]; ZE[x] = v.x; ZO[x] = v.y; }
+    ZO[0] &= 0xFFFF0000u;
+    u16x2 d[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) d[t] = (u16x2){0, 0};
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const u16x2 ap = as_pair(av[s]);
+#pragma unroll
+      for (int t = s; t < K; t++) {
+        d[t] = ap.xx * as_pair(ZE[t - s]) + d[t];
+        d[t] = ap.yy * as_pair(ZO[t - s]) + d[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      u16x2 hi = T[t] - (tern_combine<NEG>(L1[t], L2[t], fmask, qq) + d[t]);
+      if (POW2) {
+        quot[t] = ((u16x2){0, 0} - hi) & (u16)(mod - 1);
+      } else {
+        u32 h0 = mod_small(hi.x, mod), h1 = mod_small(hi.y, mod);
+        quot[t] = (u16x2){(u16)(h0 ? mod - h0 : 0), (u16)(h1 ? mod - h1 : 0)};
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    if (POW2) rem[t] = T[t];
+    else rem[t] = (u16x2){(u16)mod_small(T[t].x, mod), (u16)mod_small(T[t].y, mod)};
+  }
+}
+
+// Load the lane's block of the stepping operand: numeric u16 pairs for the triangle + the block's code word.
+template <int K, class F>
+static __device__ __forceinline__ u32 load_block(F val, const Geom &g, int sub, u32 (&av)[K]) {
+  u32 word = 0;
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    const int k = 2 * K * sub + 2 * t;
+    const u32 v0 = k < g.N ? (val(k) & 0xFFFFu) : 0u, v1 = k + 1 < g.N ? (val(k + 1) & 0xFFFFu) : 0u;
+    av[t] = v0 | (v1 << 16);
+    word |= step_bits(v0, 2 * t) | step_bits(v1, 2 * t + 1);
+  }
+  return word;
+}
+
+// encryptBits on the add path: stepping operand r in {0,1,2}, window h (shared).
+template <int K, int ME>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_encrypt_t(Geom g, u32 q, const u16 *__restrict__ h,
+                                                             const uint8_t *__restrict__ r,
+                                                             const uint8_t *__restrict__ m, long B,
+                                                             u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint2 *eo_h = (uint2 *)lds;
+  const LaneId L = lane_id(g);
+  u32 *codes = (u32 *)(lds + (size_t)g.eo_len * 8) + (size_t)L.wave * g.nl;
+  build_eo(eo_h, g, ValU16{h}, threadIdx.x, BLOCK_THREADS);
+  __syncthreads();
+  const bool want_quot = quotE != nullptr;
+  for (long item = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; item < B; item += (long)gridDim.x * WAVES_PER_BLOCK) {
+    const long row = item * g.N;
+    u32 av[K];
+    const u32 word = load_block<K>(ValU8{r + row}, g, L.sub, av);
+    if (L.active) codes[L.sub] = word;
+    wave_lds_fence();
+    u16x2 rem[K], quot[K];
+    tern_product_split<K, ME, false>(eo_h, codes, av, g, L.sub, want_quot, q, rem, quot);
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      int k = 2 * K * L.sub + 2 * t;
+      u16x2 add = {(u16)(k < g.N ? m[row + k] : 0), (u16)(k + 1 < g.N ? m[row + k + 1] : 0)};
+      rem[t] = (rem[t] + add) & (u16)(q - 1);
+    }
+    if (L.active) {
+      store_pairs<K>(e + row, g, L.sub, rem);
+      if (want_quot) store_pairs<K>(quotE + row, g, L.sub, quot);
+    }
+    wave_lds_fence();
+  }
+}
+
+// decryptBits on the add path: product 1 steps over f (shared, codes built once) with a per-item window of e;
+// product 2 steps over the lifted message (per item, in registers) with the shared window of fp.  Needs p == 3.
+template <int K, int ME>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt_t(Geom g, u32 q, u32 p,
+                                                             const int8_t *__restrict__ f,
+                                                             const uint8_t *__restrict__ fp,
+                                                             const u16 *__restrict__ e, long B,
+                                                             uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                             u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint2 *eo_fp = (uint2 *)lds;
+  u32 *codes_f = (u32 *)(lds + (size_t)g.eo_len * 8);
+  const LaneId L = lane_id(g);
+  const size_t per_wave = (size_t)g.eo_len * 8 + (size_t)g.nl * 4;
+  unsigned char *wbase = lds + (size_t)g.eo_len * 8 + (size_t)g.nl * 4 + (size_t)L.wave * per_wave;
+  uint2 *eo_e = (uint2 *)wbase;
+  u32 *codes_b = (u32 *)(wbase + (size_t)g.eo_len * 8);
+  build_eo(eo_fp, g, ValU8{fp}, threadIdx.x, BLOCK_THREADS);
+  u32 av_f[K];                                           // this lane's block of f, the same for every item
+  {
+    const u32 wf = load_block<K>(ValTernary{f, q - 1}, g, L.sub, av_f);
+    if (L.wave == 0 && L.active) codes_f[L.sub] = wf;
+  }
+  __syncthreads();
+  const bool want_q1 = quot1 != nullptr, want_q2 = quot2 != nullptr;
+  for (long item = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; item < B; item += (long)gridDim.x * WAVES_PER_BLOCK) {
+    const long row = item * g.N;
+    if (L.active) build_eo(eo_e, g, ValU16{e + row}, L.sub, g.nl);
+    wave_lds_fence();
+    u16x2 r1[K], q1[K];
+    tern_product_split<K, ME, true>(eo_e, codes_f, av_f, g, L.sub, want_q1, q, r1, q1);
+#pragma unroll
+    for (int t = 0; t < K; t++) r1[t] = r1[t] & (u16)(q - 1);
+    if (L.active) {
+      if (rem1) store_pairs<K>(rem1 + row, g, L.sub, r1);
+      if (want_q1) store_pairs<K>(quot1 + row, g, L.sub, q1);
+    }
+    // centred lift, index.js:117 verbatim; the lifted block is this lane's slice of the second stepping operand
+    u32 av_b[K], wb = 0;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      int k = 2 * K * L.sub + 2 * t;
+      u32 x0 = r1[t].x, x1 = r1[t].y;
+      u32 b0 = mod_small(2 * x0 > q ? x0 + 1 : x0, p), b1 = mod_small(2 * x1 > q ? x1 + 1 : x1, p);
+      b0 = k < g.N ? b0 : 0; b1 = k + 1 < g.N ? b1 : 0;
+      av_b[t] = b0 | (b1 << 16);
+      wb |= step_bits(b0, 2 * t) | step_bits(b1, 2 * t + 1);
+    }
+    if (L.active) codes_b[L.sub] = wb;
+    wave_lds_fence();
+    u16x2 r2[K], q2[K];
+    tern_product_split<K, 0, false>(eo_fp, codes_b, av_b, g, L.sub, want_q2, p, r2, q2);
+    if (L.active) {
+      store_pairs<K>(value + row, g, L.sub, r2);
+      if (want_q2) store_pairs<K>(quot2 + row, g, L.sub, q2);
+    }
+    wave_lds_fence();
+  }
+}
+
+template <>
+struct TernOps<9> {
+  template <int BIT>
+  static __device__ __forceinline__ void add_if(u32 (&S)[9], const u32 (&W)[9], u32 word) {
+    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
+                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
+                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
+                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
+                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
+                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
+                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
+                 "v_add_u32 %[s7], %[s7], %[w7]\n\t"
+                 "v_add_u32 %[s8], %[s8], %[w8]\n\t"
+                 "1:\n"
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6]), [s7] "+v"(S[7]), [s8] "+v"(S[8])
+                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<11> {
+  template <int BIT>
+  static __device__ __forceinline__ void add_if(u32 (&S)[11], const u32 (&W)[11], u32 word) {
+    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
+                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
+                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
+                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
+                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
+                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
+                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
+                 "v_add_u32 %[s7], %[s7], %[w7]\n\t"
+                 "v_add_u32 %[s8], %[s8], %[w8]\n\t"
+                 "v_add_u32 %[s9], %[s9], %[w9]\n\t"
+                 "v_add_u32 %[s10], %[s10], %[w10]\n\t"
+                 "1:\n"
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6]), [s7] "+v"(S[7]), [s8] "+v"(S[8]), [s9] "+v"(S[9]), [s10] "+v"(S[10])
+                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8]), [w9] "v"(W[9]), [w10] "v"(W[10])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<13> {
+  template <int BIT>
+  static __device__ __forceinline__ void add_if(u32 (&S)[13], const u32 (&W)[13], u32 word) {
+    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
+                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
+                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
+                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
+                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
+                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
+                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
+                 "v_add_u32 %[s7], %[s7], %[w7]\n\t"
+                 "v_add_u32 %[s8], %[s8], %[w8]\n\t"
+                 "v_add_u32 %[s9], %[s9], %[w9]\n\t"
+                 "v_add_u32 %[s10], %[s10], %[w10]\n\t"
+                 "v_add_u32 %[s11], %[s11], %[w11]\n\t"
+                 "v_add_u32 %[s12], %[s12], %[w12]\n\t"
+                 "1:\n"
+                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6]), [s7] "+v"(S[7]), [s8] "+v"(S[8]), [s9] "+v"(S[9]), [s10] "+v"(S[10]), [s11] "+v"(S[11]), [s12] "+v"(S[12])
+                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8]), [w9] "v"(W[9]), [w10] "v"(W[10]), [w11] "v"(W[11]), [w12] "v"(W[12])
+                 : "scc");
+  }
+};
+
+// ================================================================================================================
+// Shared-stepping add path (decrypt).  Both products of decryptBits can step over a SHARED key operand (f, then fp),
+// so every wave of the launch follows the same step masks.  That allows two items per wave (32 lanes x K pairs each,
+// K = 9 / 11 / 13) under one scalar control stream -- the scalar unit, not the VALU, is what limits the add path
+// (profiles/r01_microbench_step_rate.txt).  The per-item operand (e, then the lifted message) is the window; it is kept
+// in LDS as ONE cyclic array of aligned pairs E[u] = (bc[2u], bc[2u+1]); the odd-aligned pairs are derived on the fly,
+// O[u] = alignbit(E[u], E[u-1], 16).  N must be odd (so that the cyclic wrap turns aligned pairs into odd-aligned ones).
+// ================================================================================================================
+
+static __device__ __forceinline__ u32 odd_pair(u32 e_u, u32 e_um1) { return __builtin_amdgcn_alignbit(e_u, e_um1, 16); }
+
+// Fill this item's cyclic pair array from the K aligned pairs P[t] = (x[2v], x[(2v+1) mod N]), v = K*sub + t, held in
+// registers by the item's lanes.  E points at logical entry u = -off (one spare entry sits in front of it).
+template <int K>
+static __device__ __forceinline__ void build_cyclic_pairs(u32 *E, const Geom &g, int sub, bool active, const u32 (&P)[K],
+                                                          bool patch_wrap, u32 x0) {
+  const int N = g.N, H = (N + 1) >> 1, off = g.off, top = K * g.nl;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const int v = K * sub + t;
+      if (v < H) {
+        E[v + off] = P[t];
+        if (v - N + off >= -1) E[v - N + off] = P[t];
+      }
+    }
+  }
+  wave_lds_fence();
+  if (patch_wrap && active && sub == 0) ((u16 *)E)[2 * (H - 1 + off) + 1] = (u16)x0;   // P[H-1] = (x[N-1], x[0])
+  wave_lds_fence();
+  if (active) {
+    const int v0 = K * sub;
+    const u32 prev0 = v0 == 0 ? (E[H - 1 + off] << 16) : E[v0 - 1 + off];     // hi half = the coefficient before x[2*v0]
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const int v = v0 + t;
+      if (v < H) {
+        const u32 Q = odd_pair(P[t], t == 0 ? prev0 : P[t > 0 ? t - 1 : 0]);  // (x[2v-1], x[2v])
+        E[v - H + off] = Q;
+        if (v >= 1 && v + H - 1 < top) E[v + H - 1 + off] = Q;
+      }
+    }
+  }
+  wave_lds_fence();
+}
+
+template <int K, int ME, int J>
+static __device__ __forceinline__ void shared_steps(u32 (&S1)[K], u32 (&S2)[K], u32 (&WE)[K], u32 (&WO)[K],
+                                                    const u32 (&nw)[K + 1], u32 ones, u32 twos, u32 fmask) {
+  if constexpr (J < 2 * K) {
+    if constexpr (ME > 0 && J % (ME > 0 ? ME : 1) == 0) {
+#pragma unroll
+      for (int t = 0; t < K; t++) { S1[t] &= fmask; S2[t] &= fmask; }
+    }
+    constexpr int s = J >> 1;
+    u32 W[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) W[t] = (J & 1) ? WO[(t - s + K) % K] : WE[(t - s + K) % K];
+    TernOps<K>::template add_if<J>(S1, W, ones);
+    TernOps<K>::template add_if<J>(S2, W, twos);
+    if constexpr ((J & 1) != 0) { WE[K - 1 - s] = nw[s]; WO[K - 1 - s] = odd_pair(nw[s], nw[s + 1]); }
+    shared_steps<K, ME, J + 1>(S1, S2, WE, WO, nw, ones, twos, fmask);
+  }
+}
+
+// masks: one uint2 per block (x: steps adding into S1, y: steps adding into S2), identical for every item.
+template <int K, int ME>
+static __device__ __forceinline__ void shared_core(const u32 *__restrict__ E, const uint2 *__restrict__ masks,
+                                                   const Geom &g, int sub, bool want_low, u32 fmask,
+                                                   u32 (&S1)[K], u32 (&S2)[K], u32 (&L1)[K], u32 (&L2)[K]) {
+  u32 WE[K], WO[K];
+  const u32 *nb = E + (K * sub + g.off);
+  {
+    u32 prev = nb[-1];
+#pragma unroll
+    for (int x = 0; x < K; x++) { const u32 v = nb[x]; WE[x] = v; WO[x] = odd_pair(v, prev); prev = v; }
+  }
+#pragma unroll
+  for (int t = 0; t < K; t++) { S1[t] = 0; S2[t] = 0; L1[t] = 0; L2[t] = 0; }
+  const int nblk = g.nl;
+  uint2 mk = masks[0];
+  for (int m = 0; m < nblk; m++) {
+    const u32 ones = __builtin_amdgcn_readfirstlane(mk.x), twos = __builtin_amdgcn_readfirstlane(mk.y);
+    mk = masks[m + 1 < nblk ? m + 1 : m];
+    if (want_low && m == sub) {
+#pragma unroll
+      for (int t = 0; t < K; t++) { L1[t] = S1[t]; L2[t] = S2[t]; }
+    }
+    u32 nw[K + 1];
+#pragma unroll
+    for (int s = 0; s <= K; s++) nw[s] = nb[-1 - s];
+    shared_steps<K, ME, 0>(S1, S2, WE, WO, nw, ones, twos, fmask);
+    nb -= K;
+  }
+}
+
+// Finish a shared-stepped product (same contract as tern_product_split; av = the lane's block of the stepping operand).
+template <int K, int ME, bool NEG>
+static __device__ __forceinline__ void shared_product_split(const u32 *E, const uint2 *masks, const u32 *av,
+                                                            const Geom &g, int sub, bool want_quot, u32 mod,
+                                                            u16x2 (&rem)[K], u16x2 (&quot)[K]) {
+  constexpr bool POW2 = ME > 0;
+  u32 S1[K], S2[K], L1[K], L2[K];
+  const u32 fmask = POW2 ? (mod - 1) * 0x00010001u : 0xFFFFFFFFu;
+  const u32 qq = mod * 0x00010001u;
+  shared_core<K, ME>(E, masks, g, sub, want_quot, fmask, S1, S2, L1, L2);
+  u16x2 T[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) T[t] = tern_combine<NEG>(S1[t], S2[t], fmask, qq);
+  if (want_quot) {
+    u32 ZE[K], ZO[K];
+    {
+      u32 prev = 0;                                  // the linear product has no coefficient before index 0
+#pragma unroll
+      for (int x = 0; x < K; x++) { const u32 v = E[g.off + x]; ZE[x] = v; ZO[x] = odd_pair(v, prev); prev = v; }
+    }
+    u16x2 d[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) d[t] = (u16x2){0, 0};
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const u16x2 ap = as_pair(av[s]);
+#pragma unroll
+      for (int t = s; t < K; t++) {
+        d[t] = ap.xx * as_pair(ZE[t - s]) + d[t];
+        d[t] = ap.yy * as_pair(ZO[t - s]) + d[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      u16x2 hi = T[t] - (tern_combine<NEG>(L1[t], L2[t], fmask, qq) + d[t]);
+      if (POW2) {
+        quot[t] = ((u16x2){0, 0} - hi) & (u16)(mod - 1);
+      } else {
+        u32 h0 = mod_small(hi.x, mod), h1 = mod_small(hi.y, mod);
+        quot[t] = (u16x2){(u16)(h0 ? mod - h0 : 0), (u16)(h1 ? mod - h1 : 0)};
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    if (POW2) rem[t] = T[t];
+    else rem[t] = (u16x2){(u16)mod_small(T[t].x, mod), (u16)mod_small(T[t].y, mod)};
+  }
+}
+
+// The lane's block of a shared stepping operand: numeric pairs + the block's two step masks.
+template <int K, class F>
+static __device__ __forceinline__ uint2 load_block_masks(F val, const Geom &g, int sub, u32 (&av)[K]) {
+  uint2 mk = make_uint2(0u, 0u);
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    const int k = 2 * K * sub + 2 * t;
+    const u32 v0 = k < g.N ? (val(k) & 0xFFFFu) : 0u, v1 = k + 1 < g.N ? (val(k + 1) & 0xFFFFu) : 0u;
+    av[t] = v0 | (v1 << 16);
+    if (v0 == 1) mk.x |= 1u << (2 * t); else if (v0) mk.y |= 1u << (2 * t);
+    if (v1 == 1) mk.x |= 1u << (2 * t + 1); else if (v1) mk.y |= 1u << (2 * t + 1);
+  }
+  return mk;
+}
+
+// decryptBits with both products stepping over the shared key (f, then fp); two items per wave.  p must be 3.
+template <int K, int ME>
+__global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                             const uint8_t *__restrict__ fp,
+                                                             const u16 *__restrict__ e, long B,
+                                                             uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                             u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint2 *masks_f = (uint2 *)lds;
+  uint2 *masks_fp = masks_f + g.nl;
+  u32 *blk_f = (u32 *)(masks_fp + g.nl);                                // [nl][K] numeric pairs of f (for the triangles)
+  u32 *blk_fp = blk_f + (size_t)g.nl * K;
+  const LaneId L = lane_id(g);
+  const int e_alloc = g.eo_len + 1;                                     // dwords per item incl. the spare front entry
+  u32 *E = blk_fp + (size_t)g.nl * K + ((size_t)L.wave * g.G + L.grp) * e_alloc + 1;
+  if (L.wave == 0 && L.active && L.grp == 0) {                          // key-dependent tables, once per workgroup
+    u32 av[K];
+    masks_f[L.sub] = load_block_masks<K>(ValTernary{f, q - 1}, g, L.sub, av);
+#pragma unroll
+    for (int t = 0; t < K; t++) blk_f[K * L.sub + t] = av[t];
+    masks_fp[L.sub] = load_block_masks<K>(ValU8{fp}, g, L.sub, av);
+#pragma unroll
+    for (int t = 0; t < K; t++) blk_fp[K * L.sub + t] = av[t];
+  }
+  const u32 *av_f = blk_f + K * L.sub, *av_fp = blk_fp + K * L.sub;
+  __syncthreads();
+  const int N = g.N;
+  const long ngroups = (B + g.G - 1) / g.G;
+  const bool want_q1 = quot1 != nullptr, want_q2 = quot2 != nullptr;
+  for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
+    const long item = grp * g.G + L.grp;
+    const bool valid = L.active && item < B;
+    const long row = (valid ? item : 0) * N;
+    // ---- product 1: a = f * e mod q, window = this item's ciphertext
+    u32 P[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const int j = 2 * (K * L.sub + t);
+      const u32 x0 = j < N ? e[row + j] : 0u;
+      const u32 x1 = j + 1 < N ? e[row + j + 1] : (j + 1 == N ? e[row] : 0u);
+      P[t] = x0 | (x1 << 16);
+    }
+    build_cyclic_pairs<K>(E, g, L.sub, L.active, P, false, 0u);
+    u16x2 r1[K], q1[K];
+    shared_product_split<K, ME, true>(E, masks_f, av_f, g, L.sub, want_q1, q, r1, q1);
+#pragma unroll
+    for (int t = 0; t < K; t++) r1[t] = r1[t] & (u16)(q - 1);
+    if (valid) {
+      if (rem1) store_pairs<K>(rem1 + row, g, L.sub, r1);
+      if (want_q1) store_pairs<K>(quot1 + row, g, L.sub, q1);
+    }
+    // ---- centred lift (index.js:117 verbatim); the lifted message is the window of product 2
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const int k = 2 * (K * L.sub + t);
+      const u32 x0 = r1[t].x, x1 = r1[t].y;
+      u32 b0 = mod_small(2 * x0 > q ? x0 + 1 : x0, p), b1 = mod_small(2 * x1 > q ? x1 + 1 : x1, p);
+      b0 = k < N ? b0 : 0; b1 = k + 1 < N ? b1 : 0;
+      P[t] = b0 | (b1 << 16);
+    }
+    wave_lds_fence();                                                   // everyone is done reading E(e)
+    build_cyclic_pairs<K>(E, g, L.sub, L.active, P, true, P[0] & 0xFFFFu);
+    // ---- product 2: c = fp * b mod p (exact small sums, no masking)
+    u16x2 r2[K], q2[K];
+    shared_product_split<K, 0, false>(E, masks_fp, av_fp, g, L.sub, want_q2, p, r2, q2);
+    if (valid) {
+      store_pairs<K>(value + row, g, L.sub, r2);
+      if (want_q2) store_pairs<K>(quot2 + row, g, L.sub, q2);
+    }
+    wave_lds_fence();
+  }
+}
+
 // Does any active lane of this lane's item have `pred` set?  (items occupy nl consecutive lanes of the wave)
 static __device__ __forceinline__ bool item_any(bool pred, const Geom &g, const LaneId &L) {
   unsigned long long bal = __ballot(pred && L.active);
@@ -464,6 +1071,7 @@ struct ntru_engine {
   int device;
   hipStream_t stream;
   int cus;
+  int path;     // 0 auto, 1 force the MAC kernels, 2 force the add path where it is applicable
 };
 
 #define HIP_TRY(expr)                                                                              \
@@ -522,6 +1130,7 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
   eng->device = device;
   eng->stream = nullptr;
   eng->cus = prop.multiProcessorCount;
+  eng->path = 0;
   *out = eng;
   return NTRU_OK;
 }
@@ -531,6 +1140,13 @@ extern "C" void ntru_engine_destroy(ntru_engine_t *eng) { delete eng; }
 extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
   eng->stream = (hipStream_t)hip_stream;
+  return NTRU_OK;
+}
+
+extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (path < 0 || path > 2) return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC) or 2 (add)");
+  eng->path = path;
   return NTRU_OK;
 }
 
@@ -554,11 +1170,82 @@ static int plan(const ntru_engine *eng, int N, long B, int shared_eo, bool per_i
   if (L->lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "parameter set needs more than 160 KiB of LDS");
   long ngroups = (B + L->g.G - 1) / L->g.G;
   long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  size_t by_lds = (160 * 1024) / (L->lds ? L->lds : 1);
-  long resident = (long)eng->cus * (long)(by_lds < 8 ? (by_lds ? by_lds : 1) : 8);
-  if (blocks > resident) blocks = resident;     // persistent: waves stride over the batch
+  if (blocks < 1) blocks = 1;                   // work blocks; capped to residency by resident_grid()
+  L->grid = dim3((unsigned)blocks);
+  return NTRU_OK;
+}
+
+// The add path needs one item per wave, 2K step bits in half a dword (K <= 7) and at least K values below q fitting
+// a 16-bit field on top of a masked one.  Returns the mask interval ME (2K: once per block, K: twice) or 0.
+static int add_path_me(const ntru_engine *eng, int N, int q) {
+  if (eng->path == 1) return 0;
+  int K = pick_K(N);
+  if (!K || K > 7) return 0;
+  Geom g = make_geom(N, K);
+  if (g.G != 1) return 0;
+  long limit = 65535 / (q - 1) - 1;          // additions of values < q allowed on a masked field
+  if (limit >= 2 * K) return 2 * K;
+  if (limit >= K) return K;
+  return 0;
+}
+
+static int plan_add(const ntru_engine *eng, int N, long B, size_t shared_bytes, size_t per_wave_bytes, Launch *L) {
+  L->K = pick_K(N);
+  L->g = make_geom(N, L->K);
+  L->lds = shared_bytes + WAVES_PER_BLOCK * per_wave_bytes;
+  if (L->lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "parameter set needs more than 160 KiB of LDS");
+  long blocks = (B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   if (blocks < 1) blocks = 1;
   L->grid = dim3((unsigned)blocks);
+  return NTRU_OK;
+}
+
+// Shared-stepping decrypt: two items per wave, K pairs per lane.  Returns K (9/11/13) and the mask interval, or 0.
+static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
+  if (eng->path == 1 || p != 3 || (N & 1) == 0) return 0;
+  int K = (N + 63) / 64;
+  if ((K & 1) == 0) K++;
+  if (K < 9 || K > 13) return 0;
+  if ((long)N * 4 >= 65536) return 0;
+  long limit = 65535 / (q - 1) - 1;
+  if (limit >= K) *me = K; else if (limit >= 7) *me = 7; else return 0;
+  return K;
+}
+
+#define DISPATCH_K_SHARED(Kv, MEv, ...)                                                             \
+  switch ((Kv) * 100 + (MEv)) {                                                                     \
+    case 1313: { constexpr int KK = 13, MM = 13; __VA_ARGS__; } break;                              \
+    case 1307: { constexpr int KK = 13, MM = 7; __VA_ARGS__; } break;                               \
+    case 1111: { constexpr int KK = 11, MM = 11; __VA_ARGS__; } break;                              \
+    case 1107: { constexpr int KK = 11, MM = 7; __VA_ARGS__; } break;                               \
+    case 909: { constexpr int KK = 9, MM = 9; __VA_ARGS__; } break;                                 \
+    case 907: { constexpr int KK = 9, MM = 7; __VA_ARGS__; } break;                                 \
+    default: return fail(NTRU_ERR_UNSUPPORTED, "no shared-step kernel for this (K, mask interval)"); \
+  }
+
+#define DISPATCH_K_ADD(Kv, MEv, ...)                                                                \
+  switch ((Kv) * 100 + (MEv)) {                                                                     \
+    case 714: { constexpr int KK = 7, MM = 14; __VA_ARGS__; } break;                                \
+    case 707: { constexpr int KK = 7, MM = 7; __VA_ARGS__; } break;                                 \
+    case 510: { constexpr int KK = 5, MM = 10; __VA_ARGS__; } break;                                \
+    case 505: { constexpr int KK = 5, MM = 5; __VA_ARGS__; } break;                                 \
+    case 306: { constexpr int KK = 3, MM = 6; __VA_ARGS__; } break;                                 \
+    case 303: { constexpr int KK = 3, MM = 3; __VA_ARGS__; } break;                                 \
+    case 102: { constexpr int KK = 1, MM = 2; __VA_ARGS__; } break;                                 \
+    case 101: { constexpr int KK = 1, MM = 1; __VA_ARGS__; } break;                                 \
+    default: return fail(NTRU_ERR_UNSUPPORTED, "no add-path kernel for this (K, mask interval)");   \
+  }
+
+// Persistent grid: as many workgroups as are co-resident (occupancy query for this kernel and LDS size) x CUs, capped
+// by the work available.  A grid larger than residency would run its tail at a fraction of the chip.
+template <class Kern>
+static int resident_grid(const ntru_engine *eng, Kern kern, size_t lds, long work_blocks, dim3 *grid) {
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK_THREADS, lds));
+  if (per_cu < 1) per_cu = 1;
+  long blocks = (long)eng->cus * per_cu;
+  if (blocks > work_blocks) blocks = work_blocks;
+  *grid = dim3((unsigned)(blocks < 1 ? 1 : blocks));
   return NTRU_OK;
 }
 
@@ -596,9 +1283,22 @@ extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const ui
   if (!d_h || !d_r || !d_m || !d_e) return fail(NTRU_ERR_ARG, "ntru_encrypt_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
+  if (const int me = add_path_me(eng, N, q)) {
+    Geom g0 = make_geom(N, pick_K(N));
+    if (int rc = plan_add(eng, N, B, (size_t)g0.eo_len * 8, (size_t)g0.nl * 4, &L)) return rc;
+    DISPATCH_K_ADD(L.K, me, {
+      if (int rc = allow_lds(k_encrypt_t<KK, MM>, L.lds)) return rc;
+    if (int rc = resident_grid(eng, k_encrypt_t<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+      hipLaunchKernelGGL((k_encrypt_t<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q,
+                         d_h, d_r, d_m, (long)B, d_e, d_quotE);
+    });
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  }
   if (int rc = plan(eng, N, B, 1, false, &L)) return rc;
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_encrypt<KK>, L.lds)) return rc;
+    if (int rc = resident_grid(eng, k_encrypt<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
     hipLaunchKernelGGL(k_encrypt<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, d_h, d_r, d_m,
                        (long)B, d_e, d_quotE);
   });
@@ -616,9 +1316,43 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
   if (!d_f || !d_fp || !d_e || !d_value) return fail(NTRU_ERR_ARG, "ntru_decrypt_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
+  {
+    int me = 0;
+    if (const int KS = shared_path_K(eng, N, q, p, &me)) {
+      L.K = KS;
+      L.g = make_geom(N, KS);
+      const size_t per_wave = (size_t)L.g.G * (L.g.eo_len + 1) * 4;
+      L.lds = (size_t)L.g.nl * 16 + (size_t)L.g.nl * KS * 8 + WAVES_PER_BLOCK * per_wave;
+      const long ngroups = (B + L.g.G - 1) / L.g.G;
+      long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+      L.grid = dim3((unsigned)(blocks < 1 ? 1 : blocks));
+      DISPATCH_K_SHARED(KS, me, {
+        if (int rc = allow_lds(k_decrypt_s<KK, MM>, L.lds)) return rc;
+    if (int rc = resident_grid(eng, k_decrypt_s<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+        hipLaunchKernelGGL((k_decrypt_s<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p,
+                           d_f, d_fp, d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
+      });
+      HIP_TRY(hipGetLastError());
+      return NTRU_OK;
+    }
+  }
+  if (const int me = (p == 3 && eng->path == 2) ? add_path_me(eng, N, q) : 0) {   // per-item stepping: only when forced
+    Geom g0 = make_geom(N, pick_K(N));
+    if (int rc = plan_add(eng, N, B, (size_t)g0.eo_len * 8 + (size_t)g0.nl * 4,
+                          (size_t)g0.eo_len * 8 + (size_t)g0.nl * 4, &L)) return rc;
+    DISPATCH_K_ADD(L.K, me, {
+      if (int rc = allow_lds(k_decrypt_t<KK, MM>, L.lds)) return rc;
+    if (int rc = resident_grid(eng, k_decrypt_t<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+      hipLaunchKernelGGL((k_decrypt_t<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p,
+                         d_f, d_fp, d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
+    });
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  }
   if (int rc = plan(eng, N, B, 2, false, &L)) return rc;
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_decrypt<KK>, L.lds)) return rc;
+    if (int rc = resident_grid(eng, k_decrypt<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
     hipLaunchKernelGGL(k_decrypt<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p, d_f, d_fp,
                        d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
   });
@@ -639,6 +1373,7 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
   if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_polymul_split<KK>, L.lds)) return rc;
+    if (int rc = resident_grid(eng, k_polymul_split<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
     hipLaunchKernelGGL(k_polymul_split<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)mod,
                        (int)is_pow2(mod), d_a, d_b, (long)B, d_quot, d_rem);
   });
@@ -664,6 +1399,7 @@ extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int 
   if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_verify_keys<KK>, L.lds)) return rc;
+    if (int rc = resident_grid(eng, k_verify_keys<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
     hipLaunchKernelGGL(k_verify_keys<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p, d_f, d_g,
                        d_fq, d_fp, d_h, (long)B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h, d_flags);
   });

@@ -28,6 +28,7 @@ _SIGS = {
     "ntru_engine_destroy": (None, [_vp]),
     "ntru_engine_set_stream": (C.c_int, [_vp, _vp]),
     "ntru_engine_synchronize": (C.c_int, [_vp]),
+    "ntru_engine_set_kernel_path": (C.c_int, [_vp, _i]),
     "ntru_last_error": (C.c_char_p, []),
     "ntru_engine_supports": (C.c_int, [_i, _i]),
 }
@@ -112,6 +113,10 @@ class Engine:
 
     def set_stream(self, hip_stream):
         self._chk(self._lib.ntru_engine_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
+
+    def set_kernel_path(self, path):
+        """0 auto, 1 packed-u16 MAC kernels, 2 ternary add path where applicable (same results)."""
+        self._chk(self._lib.ntru_engine_set_kernel_path(self._h, int(path)))
 
     def synchronize(self):
         self._chk(self._lib.ntru_engine_synchronize(self._h))
