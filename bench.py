@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PK_MAC_PEAK_T = 75.6           # measured v_pk_mad_u16 roof, profiles/r01_microbench_valu_lds.txt (T MAC/s)
+ADD_PEAK_T = 134.0             # measured v_add_u32 roof 67 T lane-adds/s x 2 packed 16-bit coefficients per add
 
 
 def parse_args():
@@ -66,6 +67,18 @@ def make_inputs(torch, dev, B, N, d, seed):
         del idx
     m = torch.randint(0, 2, (B, N), dtype=torch.uint8, device=dev, generator=gen)
     return r, m
+
+
+def pmc_traffic(kernel, mode):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_hbm_latest.json:
+    2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950), or None if not collected for it."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")) as fh:
+            d = json.load(fh)
+        k = d["kernels"].get(kernel)
+        return k["hbm_bytes_per_launch"] if k and d.get("mode") == mode else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
@@ -137,11 +150,15 @@ def main():
     eng.set_stream(stream.cuda_stream)
     eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2}[args.kernel_path])
 
+    names = {}
+
     def step(ev=None):
         if ev: ev[0].record(stream)
         eng.encrypt_batch_dev(N, q, ptr(h), ptr(r), ptr(m), B, ptr(e), ptr(quotE))
+        names["encrypt"] = eng.last_kernel()
         if ev: ev[1].record(stream)
         eng.decrypt_batch_dev(N, q, p, ptr(f), ptr(fp), ptr(e), B, ptr(value), ptr(quot1), ptr(rem1), ptr(quot2))
+        names["decrypt"] = eng.last_kernel()
         if ev: ev[2].record(stream)
 
     for _ in range(args.warmup):
@@ -182,7 +199,23 @@ def main():
         dec_bytes = (8 if witness else 3) * N
         enc_bytes = (6 if witness else 4) * N
         dec_gbs = dec_bytes * B / (dec_ms * 1e-3) / 1e9
-        dec_tmac = 2.0 * N * N * B / (dec_ms * 1e-3) / 1e12
+        dec_s = dec_ms * 1e-3
+        dname = names.get("decrypt", "k_decrypt")
+        add_path = dname.startswith(("k_decrypt_s", "k_decrypt_t"))
+        if add_path:
+            # work actually issued by the ternary add path: one packed coefficient-add per (non-zero step, output)
+            nz_f = float(np.count_nonzero(f_np)) / N
+            nz_b = 2.0 / 3.0                                  # the lifted message is ~uniform over {0,1,2}
+            valu = {"kernel": dname, "achieved": (nz_f + nz_b) * N * N * B / dec_s / 1e12, "peak": ADD_PEAK_T,
+                    "unit": "T coefficient-adds/s",
+                    "note": "ternary add path: (non-zero steps) x N packed 16-bit adds per product; peak = measured "
+                            "v_add_u32 issue roof x 2 coefficients; the scalar-issued step control is what keeps it "
+                            "below that roof (DESIGN.md section 4)"}
+        else:
+            valu = {"kernel": dname, "achieved": 2.0 * N * N * B / dec_s / 1e12, "peak": PK_MAC_PEAK_T,
+                    "unit": "T MAC/s", "note": "2*N^2 MACs per decrypt; peak = measured v_pk_mad_u16 issue roof"}
+        valu["frac"] = valu["achieved"] / valu["peak"]
+        valu["mac_equivalent_T_per_s"] = 2.0 * N * N * B / dec_s / 1e12
         out = {
             "metric": "NTRU encrypt+decrypt round trips per second at N=%d, q=%d" % (N, q),
             "value": total / elapsed, "unit": "round_trips/s", "n_gpus": world, "steps": args.steps,
@@ -191,16 +224,15 @@ def main():
             "config": {"workload": "N=%d q=%d p=%d d=%d, batch=2^%d round trips per GPU per step, shared golden key, "
                                    "%s outputs" % (N, q, p, d, args.batch_log2,
                                                    "full-witness" if witness else "value-only"),
-                       "mode": args.mode, "kernel_path": args.kernel_path, "seed": 20240, "parallelism": "batch-sharded x%d, no collective" % world},
+                       "mode": args.mode, "kernel_path": args.kernel_path, "seed": 20240,
+                       "parallelism": "batch-sharded x%d, no collective" % world},
             "verified_bit_exact_rows": int(rows.numel()),
-            "kernels_ms": {"k_encrypt": enc_ms, "k_decrypt": dec_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_decrypt", "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_item": dec_bytes,
-                         "note": "the path is VALU-bound (O(N^2) integer MACs on O(N) bytes); see `valu`"},
-            "valu": {"kernel": "k_decrypt", "achieved": dec_tmac, "peak": PK_MAC_PEAK_T, "unit": "T MAC/s",
-                     "frac": dec_tmac / PK_MAC_PEAK_T,
-                     "note": "2*N^2 MACs per decrypt; peak = measured v_pk_mad_u16 issue roof of this chip"},
+            "kernels_ms": {names.get("encrypt", "k_encrypt"): enc_ms, dname: dec_ms},
+            "roofline": {"bound": "hbm", "kernel": dname, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dname, args.mode),
+                         "algorithmic_bytes_per_item": dec_bytes, "algorithmic_bytes_per_launch": dec_bytes * B,
+                         "note": "the path is VALU/scalar-issue bound (O(N^2) integer work on O(N) bytes); see `valu`"},
+            "valu": valu,
             "hbm_gbs_round_trip": (dec_bytes + enc_bytes) * B / ((dec_ms + enc_ms) * 1e-3) / 1e9,
         }
         if gathered:

@@ -63,6 +63,8 @@ int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
 /* Tuning / test knob: 0 = pick the fastest applicable kernel family (default), 1 = always the packed-u16 MAC
  * kernels, 2 = the ternary add path wherever it applies.  Results are identical. */
 int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
+/* Name of the kernel the last *_dev call on this engine launched, e.g. "k_decrypt_s<13,13>" (for reports). */
+const char *ntru_engine_last_kernel(ntru_engine_t *eng);
 /* Block until everything enqueued on the engine's stream has finished. */
 int ntru_engine_synchronize(ntru_engine_t *eng);
 

@@ -354,6 +354,20 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod
 // bit j: step j adds into S1 (value 1); bit 16+j: step j adds into S2 (the other non-zero symbol)
 static __device__ __forceinline__ u32 step_bits(u32 v, int j) { return v == 0 ? 0u : (v == 1 ? 1u << j : 1u << (16 + j)); }
 
+// Lane-conditional snapshot L1 <- S1, L2 <- S2 as an exec-masked block of in-place full-rate v_mov (hipcc would turn
+// plain assignments into v_cndmask, which is far slower on gfx950: profiles/r01_microbench_exec_rate.txt).
+template <int K>
+static __device__ __forceinline__ void snapshot_if(bool take, u32 (&L1)[K], u32 (&L2)[K], const u32 (&S1)[K],
+                                                   const u32 (&S2)[K]) {
+  if (take) {
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      asm volatile("v_mov_b32 %0, %1" : "+v"(L1[t]) : "v"(S1[t]));
+      asm volatile("v_mov_b32 %0, %1" : "+v"(L2[t]) : "v"(S2[t]));
+    }
+  }
+}
+
 template <int K> struct TernOps;
 template <>
 struct TernOps<1> {
@@ -446,9 +460,9 @@ static __device__ __forceinline__ void tern_steps(u32 (&S1)[K], u32 (&S2)[K], u3
   }
 }
 
-template <int K, int ME>
+template <int K, int ME, bool WL>
 static __device__ __forceinline__ void tern_core(const uint2 *__restrict__ eo, const u32 *__restrict__ codes,
-                                                 const Geom &g, int sub, bool want_low, u32 fmask,
+                                                 const Geom &g, int sub, u32 fmask,
                                                  u32 (&S1)[K], u32 (&S2)[K], u32 (&L1)[K], u32 (&L2)[K]) {
   u32 WE[K], WO[K];
   const uint2 *nb = eo + (K * sub + g.off);
@@ -460,10 +474,7 @@ static __device__ __forceinline__ void tern_core(const uint2 *__restrict__ eo, c
   u32 word = __builtin_amdgcn_readfirstlane(codes[0]);
   for (int m = 0; m < nblk; m++) {
     const u32 next_raw = codes[m + 1 < nblk ? m + 1 : m];
-    if (want_low && m == sub) {
-#pragma unroll
-      for (int t = 0; t < K; t++) { L1[t] = S1[t]; L2[t] = S2[t]; }
-    }
+    if constexpr (WL) snapshot_if<K>(m == sub, L1, L2, S1, S2);
     uint2 nw[K];
 #pragma unroll
     for (int s = 0; s < K; s++) nw[s] = nb[-1 - s];
@@ -482,61 +493,84 @@ static __device__ __forceinline__ u16x2 tern_combine(u32 s1, u32 s2, u32 fmask, 
 
 // Finish one ternary-stepped product: remainder / quotient pairs like product_split.
 //   av: the lane's own 2K stepping-operand values (numeric, as u16 pairs) for the in-block triangle.
-template <int K, int ME, bool NEG>
+// Which lanes may store a whole block of 2K outputs without bounds checks, and which one holds the row's tail.
+struct StorePlan {
+  bool full, tail; int nv;      // nv: number of valid outputs in the tail lane (wave-uniform)
+};
+template <int K>
+static __device__ __forceinline__ StorePlan store_plan(const Geom &g, int sub, bool valid) {
+  StorePlan sp;
+  sp.nv = g.N - 2 * K * (g.nl - 1);
+  sp.full = valid && (sub < g.nl - 1 || sp.nv == 2 * K);
+  sp.tail = valid && !sp.full;
+  return sp;
+}
+// Store output pair t of this lane into its row (`lane_row` already points at the lane's first output).
+template <class OutT>
+static __device__ __forceinline__ void store_pair(OutT *lane_row, const StorePlan &sp, int t, u16x2 v) {
+  if (sp.full) {
+    lane_row[2 * t] = (OutT)v.x; lane_row[2 * t + 1] = (OutT)v.y;
+  } else if (sp.tail) {
+    if (2 * t < sp.nv) lane_row[2 * t] = (OutT)v.x;        // wave-uniform tests
+    if (2 * t + 1 < sp.nv) lane_row[2 * t + 1] = (OutT)v.y;
+  }
+}
+
+// Runs one per-item-stepped product and hands each finished pair to `emit(t, rem_pair, quot_pair)` right away.
+template <int K, int ME, bool NEG, class Emit>
 static __device__ __forceinline__ void tern_product_split(const uint2 *eo, const u32 *codes, const u32 (&av)[K],
-                                                          const Geom &g, int sub, bool want_quot, u32 mod,
-                                                          u16x2 (&rem)[K], u16x2 (&quot)[K]) {
+                                                          const Geom &g, int sub, bool want_quot, u32 mod, Emit emit) {
   constexpr bool POW2 = ME > 0;
-  u32 S1[K], S2[K], L1[K], L2[K];
   const u32 fmask = POW2 ? (mod - 1) * 0x00010001u : 0xFFFFFFFFu;
   const u32 qq = mod * 0x00010001u;
-  tern_core<K, ME>(eo, codes, g, sub, want_quot, fmask, S1, S2, L1, L2);
-  u16x2 T[K];
+  u32 S1[K], S2[K], L1[K], L2[K];
+  if (want_quot) tern_core<K, ME, true>(eo, codes, g, sub, fmask, S1, S2, L1, L2);
+  else tern_core<K, ME, false>(eo, codes, g, sub, fmask, S1, S2, L1, L2);
+  u16x2 low[K];
 #pragma unroll
-  for (int t = 0; t < K; t++) T[t] = tern_combine<NEG>(S1[t], S2[t], fmask, qq);
-  if (want_quot) {
+  for (int t = 0; t < K; t++) low[t] = tern_combine<NEG>(L1[t], L2[t], fmask, qq);
+  if (want_quot) {                                   // in-block triangle
     u32 ZE[K], ZO[K];
 #pragma unroll
     for (int x = 0; x < K; x++) { uint2 v = eo[g.off + x]; ZE[x] = v.x; ZO[x] = v.y; }
     ZO[0] &= 0xFFFF0000u;
-    u16x2 d[K];
-#pragma unroll
-    for (int t = 0; t < K; t++) d[t] = (u16x2){0, 0};
 #pragma unroll
     for (int s = 0; s < K; s++) {
       const u16x2 ap = as_pair(av[s]);
 #pragma unroll
       for (int t = s; t < K; t++) {
-        d[t] = ap.xx * as_pair(ZE[t - s]) + d[t];
-        d[t] = ap.yy * as_pair(ZO[t - s]) + d[t];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < K; t++) {
-      u16x2 hi = T[t] - (tern_combine<NEG>(L1[t], L2[t], fmask, qq) + d[t]);
-      if (POW2) {
-        quot[t] = ((u16x2){0, 0} - hi) & (u16)(mod - 1);
-      } else {
-        u32 h0 = mod_small(hi.x, mod), h1 = mod_small(hi.y, mod);
-        quot[t] = (u16x2){(u16)(h0 ? mod - h0 : 0), (u16)(h1 ? mod - h1 : 0)};
+        low[t] = ap.xx * as_pair(ZE[t - s]) + low[t];
+        low[t] = ap.yy * as_pair(ZO[t - s]) + low[t];
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < K; t++) {
-    if (POW2) rem[t] = T[t];
-    else rem[t] = (u16x2){(u16)mod_small(T[t].x, mod), (u16)mod_small(T[t].y, mod)};
+    const u16x2 T = tern_combine<NEG>(S1[t], S2[t], fmask, qq);
+    u16x2 qv = (u16x2){0, 0};
+    if (want_quot) {
+      const u16x2 hi = T - low[t];
+      if (POW2) {
+        qv = ((u16x2){0, 0} - hi) & (u16)(mod - 1);
+      } else {
+        const u32 h0 = mod_small(hi.x, mod), h1 = mod_small(hi.y, mod);
+        qv = (u16x2){(u16)(h0 ? mod - h0 : 0), (u16)(h1 ? mod - h1 : 0)};
+      }
+    }
+    const u16x2 rv = POW2 ? T : (u16x2){(u16)mod_small(T.x, mod), (u16)mod_small(T.y, mod)};   // POW2: caller masks
+    emit(t, rv, qv);
   }
 }
 
 // Load the lane's block of the stepping operand: numeric u16 pairs for the triangle + the block's code word.
 template <int K, class F>
-static __device__ __forceinline__ u32 load_block(F val, const Geom &g, int sub, u32 (&av)[K]) {
+static __device__ __forceinline__ u32 load_block(F val, int N, int sub, u32 (&av)[K]) {
   u32 word = 0;
 #pragma unroll
   for (int t = 0; t < K; t++) {
     const int k = 2 * K * sub + 2 * t;
-    const u32 v0 = k < g.N ? (val(k) & 0xFFFFu) : 0u, v1 = k + 1 < g.N ? (val(k + 1) & 0xFFFFu) : 0u;
+    const int k0 = k < N ? k : N - 1, k1 = k + 1 < N ? k + 1 : N - 1;          // clamped, then zeroed
+    const u32 v0 = k < N ? (val(k0) & 0xFFFFu) : 0u, v1 = k + 1 < N ? (val(k1) & 0xFFFFu) : 0u;
     av[t] = v0 | (v1 << 16);
     word |= step_bits(v0, 2 * t) | step_bits(v1, 2 * t + 1);
   }
@@ -557,23 +591,26 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_encrypt_t(Geom g, u32 q, cons
   __syncthreads();
   const bool want_quot = quotE != nullptr;
   for (long item = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; item < B; item += (long)gridDim.x * WAVES_PER_BLOCK) {
-    const long row = item * g.N;
+    int sub = L.sub, N = g.N;                            // re-materialised per iteration: keeps the glue out of LICM's reach
+    asm volatile("" : "+v"(sub), "+s"(N));
+    const long row = item * N;
     u32 av[K];
-    const u32 word = load_block<K>(ValU8{r + row}, g, L.sub, av);
-    if (L.active) codes[L.sub] = word;
-    wave_lds_fence();
-    u16x2 rem[K], quot[K];
-    tern_product_split<K, ME, false>(eo_h, codes, av, g, L.sub, want_quot, q, rem, quot);
+    const u32 word = load_block<K>(ValU8{r + row}, N, sub, av);
 #pragma unroll
-    for (int t = 0; t < K; t++) {
-      int k = 2 * K * L.sub + 2 * t;
-      u16x2 add = {(u16)(k < g.N ? m[row + k] : 0), (u16)(k + 1 < g.N ? m[row + k + 1] : 0)};
-      rem[t] = (rem[t] + add) & (u16)(q - 1);
-    }
-    if (L.active) {
-      store_pairs<K>(e + row, g, L.sub, rem);
-      if (want_quot) store_pairs<K>(quotE + row, g, L.sub, quot);
-    }
+    for (int t = 0; t < K; t++) asm volatile("" : "+v"(av[t]));            // pack now: 7 live registers instead of 14+ raw bytes
+    if (L.active) codes[sub] = word;
+    wave_lds_fence();
+    const StorePlan sp = store_plan<K>(g, sub, L.active);
+    const long lane0 = row + 2 * K * sub;
+    tern_product_split<K, ME, false>(eo_h, codes, av, g, sub, want_quot, q, [&](int t, u16x2 rv, u16x2 qv) {
+      const int k = 2 * K * sub + 2 * t;
+      const int k0 = k < N ? k : N - 1, k1 = k + 1 < N ? k + 1 : N - 1;
+      const uint8_t *mr = m + row;
+      asm volatile("" : "+v"(mr));                                          // keep these loads BEHIND the hot loop
+      const u16x2 add = {(u16)mr[k0], (u16)mr[k1]};                         // out-of-row lanes never store
+      store_pair(e + lane0, sp, t, (rv + add) & (u16)(q - 1));
+      if (want_quot) store_pair(quotE + lane0, sp, t, qv);
+    });
     wave_lds_fence();
   }
 }
@@ -598,7 +635,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt_t(Geom g, u32 q, u32 
   build_eo(eo_fp, g, ValU8{fp}, threadIdx.x, BLOCK_THREADS);
   u32 av_f[K];                                           // this lane's block of f, the same for every item
   {
-    const u32 wf = load_block<K>(ValTernary{f, q - 1}, g, L.sub, av_f);
+    const u32 wf = load_block<K>(ValTernary{f, q - 1}, g.N, L.sub, av_f);
     if (L.wave == 0 && L.active) codes_f[L.sub] = wf;
   }
   __syncthreads();
@@ -607,33 +644,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt_t(Geom g, u32 q, u32 
     const long row = item * g.N;
     if (L.active) build_eo(eo_e, g, ValU16{e + row}, L.sub, g.nl);
     wave_lds_fence();
-    u16x2 r1[K], q1[K];
-    tern_product_split<K, ME, true>(eo_e, codes_f, av_f, g, L.sub, want_q1, q, r1, q1);
-#pragma unroll
-    for (int t = 0; t < K; t++) r1[t] = r1[t] & (u16)(q - 1);
-    if (L.active) {
-      if (rem1) store_pairs<K>(rem1 + row, g, L.sub, r1);
-      if (want_q1) store_pairs<K>(quot1 + row, g, L.sub, q1);
-    }
-    // centred lift, index.js:117 verbatim; the lifted block is this lane's slice of the second stepping operand
+    const StorePlan sp = store_plan<K>(g, L.sub, L.active);
+    const long lane0 = row + 2 * K * L.sub;
     u32 av_b[K], wb = 0;
-#pragma unroll
-    for (int t = 0; t < K; t++) {
-      int k = 2 * K * L.sub + 2 * t;
-      u32 x0 = r1[t].x, x1 = r1[t].y;
+    // remainder1 / quotient1 stored pair by pair; centred lift, index.js:117 verbatim -> second stepping operand
+    tern_product_split<K, ME, true>(eo_e, codes_f, av_f, g, L.sub, want_q1, q, [&](int t, u16x2 rv, u16x2 qv) {
+      rv = rv & (u16)(q - 1);
+      if (rem1) store_pair(rem1 + lane0, sp, t, rv);
+      if (want_q1) store_pair(quot1 + lane0, sp, t, qv);
+      const int k = 2 * K * L.sub + 2 * t;
+      const u32 x0 = rv.x, x1 = rv.y;
       u32 b0 = mod_small(2 * x0 > q ? x0 + 1 : x0, p), b1 = mod_small(2 * x1 > q ? x1 + 1 : x1, p);
       b0 = k < g.N ? b0 : 0; b1 = k + 1 < g.N ? b1 : 0;
       av_b[t] = b0 | (b1 << 16);
       wb |= step_bits(b0, 2 * t) | step_bits(b1, 2 * t + 1);
-    }
+    });
     if (L.active) codes_b[L.sub] = wb;
     wave_lds_fence();
-    u16x2 r2[K], q2[K];
-    tern_product_split<K, 0, false>(eo_fp, codes_b, av_b, g, L.sub, want_q2, p, r2, q2);
-    if (L.active) {
-      store_pairs<K>(value + row, g, L.sub, r2);
-      if (want_q2) store_pairs<K>(quot2 + row, g, L.sub, q2);
-    }
+    tern_product_split<K, 0, false>(eo_fp, codes_b, av_b, g, L.sub, want_q2, p, [&](int t, u16x2 rv, u16x2 qv) {
+      store_pair(value + lane0, sp, t, rv);
+      if (want_q2) store_pair(quot2 + lane0, sp, t, qv);
+    });
     wave_lds_fence();
   }
 }
@@ -720,36 +751,33 @@ struct TernOps<13> {
 static __device__ __forceinline__ u32 odd_pair(u32 e_u, u32 e_um1) { return __builtin_amdgcn_alignbit(e_u, e_um1, 16); }
 
 // Fill this item's cyclic pair array from the K aligned pairs P[t] = (x[2v], x[(2v+1) mod N]), v = K*sub + t, held in
-// registers by the item's lanes.  E points at logical entry u = -off (one spare entry sits in front of it).
+// registers by the item's lanes.  E points at logical entry u = -off (one spare entry sits in front of it, one dummy
+// slot behind the array absorbs writes of lanes that have nothing to contribute -- no per-element predication).
+//   phase 1: E[u] = P[u] for u in [0, H), H = (N+1)/2 (the aligned pairs, the last one wrapping to x[0])
+//   phase 2: every other entry is either another aligned pair (2u mod N even) or the odd-aligned pair
+//            (x[j], x[j+1]) = (hi(P[(j-1)/2]), lo(P[(j+1)/2])), j = 2u mod N, read back from phase 1's region
 template <int K>
 static __device__ __forceinline__ void build_cyclic_pairs(u32 *E, const Geom &g, int sub, bool active, const u32 (&P)[K],
                                                           bool patch_wrap, u32 x0) {
   const int N = g.N, H = (N + 1) >> 1, off = g.off, top = K * g.nl;
-  if (active) {
+  const int dummy = top + off;                          // one slot past the last real entry
 #pragma unroll
-    for (int t = 0; t < K; t++) {
-      const int v = K * sub + t;
-      if (v < H) {
-        E[v + off] = P[t];
-        if (v - N + off >= -1) E[v - N + off] = P[t];
-      }
-    }
+  for (int t = 0; t < K; t++) {
+    const int v = K * sub + t;
+    E[(active && v < H) ? v + off : dummy] = P[t];
   }
   wave_lds_fence();
   if (patch_wrap && active && sub == 0) ((u16 *)E)[2 * (H - 1 + off) + 1] = (u16)x0;   // P[H-1] = (x[N-1], x[0])
   wave_lds_fence();
-  if (active) {
-    const int v0 = K * sub;
-    const u32 prev0 = v0 == 0 ? (E[H - 1 + off] << 16) : E[v0 - 1 + off];     // hi half = the coefficient before x[2*v0]
-#pragma unroll
-    for (int t = 0; t < K; t++) {
-      const int v = v0 + t;
-      if (v < H) {
-        const u32 Q = odd_pair(P[t], t == 0 ? prev0 : P[t > 0 ? t - 1 : 0]);  // (x[2v-1], x[2v])
-        E[v - H + off] = Q;
-        if (v >= 1 && v + H - 1 < top) E[v + H - 1 + off] = Q;
-      }
-    }
+  const int below = off + 1, total = below + (top - H);  // entries u in [-off-1, -1] and [H, top)
+  for (int idx = sub; idx < total; idx += g.nl) {
+    const int u = idx < below ? idx - below : H + (idx - below);
+    int j = 2 * u;                                       // reduce 2u into [0, N)
+    j += j < 0 ? N : 0; j += j < 0 ? N : 0; j -= j >= N ? N : 0;
+    const int hi_src = (j + 1) >> 1, lo_src = j >> 1;    // j even: both = j/2 (aligned pair); j odd: neighbours
+    const u32 a = E[hi_src + off], b = E[lo_src + off];
+    const u32 val = (j & 1) ? odd_pair(a, b) : a;
+    E[active ? u + off : dummy] = val;
   }
   wave_lds_fence();
 }
@@ -774,9 +802,9 @@ static __device__ __forceinline__ void shared_steps(u32 (&S1)[K], u32 (&S2)[K], 
 }
 
 // masks: one uint2 per block (x: steps adding into S1, y: steps adding into S2), identical for every item.
-template <int K, int ME>
+template <int K, int ME, bool WL>
 static __device__ __forceinline__ void shared_core(const u32 *__restrict__ E, const uint2 *__restrict__ masks,
-                                                   const Geom &g, int sub, bool want_low, u32 fmask,
+                                                   const Geom &g, int sub, u32 fmask,
                                                    u32 (&S1)[K], u32 (&S2)[K], u32 (&L1)[K], u32 (&L2)[K]) {
   u32 WE[K], WO[K];
   const u32 *nb = E + (K * sub + g.off);
@@ -792,10 +820,7 @@ static __device__ __forceinline__ void shared_core(const u32 *__restrict__ E, co
   for (int m = 0; m < nblk; m++) {
     const u32 ones = __builtin_amdgcn_readfirstlane(mk.x), twos = __builtin_amdgcn_readfirstlane(mk.y);
     mk = masks[m + 1 < nblk ? m + 1 : m];
-    if (want_low && m == sub) {
-#pragma unroll
-      for (int t = 0; t < K; t++) { L1[t] = S1[t]; L2[t] = S2[t]; }
-    }
+    if constexpr (WL) snapshot_if<K>(m == sub, L1, L2, S1, S2);
     u32 nw[K + 1];
 #pragma unroll
     for (int s = 0; s <= K; s++) nw[s] = nb[-1 - s];
@@ -805,52 +830,51 @@ static __device__ __forceinline__ void shared_core(const u32 *__restrict__ E, co
 }
 
 // Finish a shared-stepped product (same contract as tern_product_split; av = the lane's block of the stepping operand).
-template <int K, int ME, bool NEG>
+// Runs one shared-stepped product and hands each finished pair to `emit(t, rem_pair, quot_pair)` right away (so no
+// result arrays stay live: register pressure is what limits this kernel's occupancy).
+template <int K, int ME, bool NEG, class Emit>
 static __device__ __forceinline__ void shared_product_split(const u32 *E, const uint2 *masks, const u32 *av,
-                                                            const Geom &g, int sub, bool want_quot, u32 mod,
-                                                            u16x2 (&rem)[K], u16x2 (&quot)[K]) {
+                                                            const Geom &g, int sub, bool want_quot, u32 mod, Emit emit) {
   constexpr bool POW2 = ME > 0;
-  u32 S1[K], S2[K], L1[K], L2[K];
   const u32 fmask = POW2 ? (mod - 1) * 0x00010001u : 0xFFFFFFFFu;
   const u32 qq = mod * 0x00010001u;
-  shared_core<K, ME>(E, masks, g, sub, want_quot, fmask, S1, S2, L1, L2);
-  u16x2 T[K];
+  u32 S1[K], S2[K], L1[K], L2[K];
+  if (want_quot) shared_core<K, ME, true>(E, masks, g, sub, fmask, S1, S2, L1, L2);
+  else shared_core<K, ME, false>(E, masks, g, sub, fmask, S1, S2, L1, L2);
+  // fold the snapshots into "low" right away (frees L2), then add the in-block triangle
+  u16x2 low[K];
 #pragma unroll
-  for (int t = 0; t < K; t++) T[t] = tern_combine<NEG>(S1[t], S2[t], fmask, qq);
+  for (int t = 0; t < K; t++) low[t] = tern_combine<NEG>(L1[t], L2[t], fmask, qq);
   if (want_quot) {
     u32 ZE[K], ZO[K];
-    {
-      u32 prev = 0;                                  // the linear product has no coefficient before index 0
+    u32 prev = 0;                                    // the linear product has no coefficient before index 0
 #pragma unroll
-      for (int x = 0; x < K; x++) { const u32 v = E[g.off + x]; ZE[x] = v; ZO[x] = odd_pair(v, prev); prev = v; }
-    }
-    u16x2 d[K];
-#pragma unroll
-    for (int t = 0; t < K; t++) d[t] = (u16x2){0, 0};
+    for (int x = 0; x < K; x++) { const u32 v = E[g.off + x]; ZE[x] = v; ZO[x] = odd_pair(v, prev); prev = v; }
 #pragma unroll
     for (int s = 0; s < K; s++) {
       const u16x2 ap = as_pair(av[s]);
 #pragma unroll
       for (int t = s; t < K; t++) {
-        d[t] = ap.xx * as_pair(ZE[t - s]) + d[t];
-        d[t] = ap.yy * as_pair(ZO[t - s]) + d[t];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < K; t++) {
-      u16x2 hi = T[t] - (tern_combine<NEG>(L1[t], L2[t], fmask, qq) + d[t]);
-      if (POW2) {
-        quot[t] = ((u16x2){0, 0} - hi) & (u16)(mod - 1);
-      } else {
-        u32 h0 = mod_small(hi.x, mod), h1 = mod_small(hi.y, mod);
-        quot[t] = (u16x2){(u16)(h0 ? mod - h0 : 0), (u16)(h1 ? mod - h1 : 0)};
+        low[t] = ap.xx * as_pair(ZE[t - s]) + low[t];
+        low[t] = ap.yy * as_pair(ZO[t - s]) + low[t];
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < K; t++) {
-    if (POW2) rem[t] = T[t];
-    else rem[t] = (u16x2){(u16)mod_small(T[t].x, mod), (u16)mod_small(T[t].y, mod)};
+    const u16x2 T = tern_combine<NEG>(S1[t], S2[t], fmask, qq);
+    u16x2 qv = (u16x2){0, 0};
+    if (want_quot) {
+      const u16x2 hi = T - low[t];
+      if (POW2) {
+        qv = ((u16x2){0, 0} - hi) & (u16)(mod - 1);
+      } else {
+        const u32 h0 = mod_small(hi.x, mod), h1 = mod_small(hi.y, mod);
+        qv = (u16x2){(u16)(h0 ? mod - h0 : 0), (u16)(h1 ? mod - h1 : 0)};
+      }
+    }
+    const u16x2 rv = POW2 ? (T & (u16)(mod - 1)) : (u16x2){(u16)mod_small(T.x, mod), (u16)mod_small(T.y, mod)};
+    emit(t, rv, qv);
   }
 }
 
@@ -882,7 +906,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u
   u32 *blk_f = (u32 *)(masks_fp + g.nl);                                // [nl][K] numeric pairs of f (for the triangles)
   u32 *blk_fp = blk_f + (size_t)g.nl * K;
   const LaneId L = lane_id(g);
-  const int e_alloc = g.eo_len + 1;                                     // dwords per item incl. the spare front entry
+  const int e_alloc = g.eo_len + 2;                                     // dwords per item incl. spare front entry + dummy slot
   u32 *E = blk_fp + (size_t)g.nl * K + ((size_t)L.wave * g.G + L.grp) * e_alloc + 1;
   if (L.wave == 0 && L.active && L.grp == 0) {                          // key-dependent tables, once per workgroup
     u32 av[K];
@@ -895,49 +919,50 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u
   }
   const u32 *av_f = blk_f + K * L.sub, *av_fp = blk_fp + K * L.sub;
   __syncthreads();
-  const int N = g.N;
   const long ngroups = (B + g.G - 1) / g.G;
   const bool want_q1 = quot1 != nullptr, want_q2 = quot2 != nullptr;
   for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
+    // Re-materialise the lane index and N every iteration: otherwise the compiler hoists all per-lane address /
+    // predicate arithmetic of the glue below out of this loop and keeps ~100 registers live (and spilled) across
+    // both hot loops.
+    int sub = L.sub, N = g.N;
+    asm volatile("" : "+v"(sub), "+s"(N));
     const long item = grp * g.G + L.grp;
     const bool valid = L.active && item < B;
     const long row = (valid ? item : 0) * N;
     // ---- product 1: a = f * e mod q, window = this item's ciphertext
     u32 P[K];
+    {
+      const u16 *er = e + row;
 #pragma unroll
-    for (int t = 0; t < K; t++) {
-      const int j = 2 * (K * L.sub + t);
-      const u32 x0 = j < N ? e[row + j] : 0u;
-      const u32 x1 = j + 1 < N ? e[row + j + 1] : (j + 1 == N ? e[row] : 0u);
-      P[t] = x0 | (x1 << 16);
+      for (int t = 0; t < K; t++) {                       // clamped indices: lanes past the end load something harmless
+        const int j = 2 * (K * sub + t);
+        const int j0 = j < N ? j : N - 1;
+        const int j1 = j + 1 < N ? j + 1 : (j + 1 == N ? 0 : N - 1);
+        P[t] = (u32)er[j0] | ((u32)er[j1] << 16);
+      }
     }
-    build_cyclic_pairs<K>(E, g, L.sub, L.active, P, false, 0u);
-    u16x2 r1[K], q1[K];
-    shared_product_split<K, ME, true>(E, masks_f, av_f, g, L.sub, want_q1, q, r1, q1);
-#pragma unroll
-    for (int t = 0; t < K; t++) r1[t] = r1[t] & (u16)(q - 1);
-    if (valid) {
-      if (rem1) store_pairs<K>(rem1 + row, g, L.sub, r1);
-      if (want_q1) store_pairs<K>(quot1 + row, g, L.sub, q1);
-    }
-    // ---- centred lift (index.js:117 verbatim); the lifted message is the window of product 2
-#pragma unroll
-    for (int t = 0; t < K; t++) {
-      const int k = 2 * (K * L.sub + t);
-      const u32 x0 = r1[t].x, x1 = r1[t].y;
+    build_cyclic_pairs<K>(E, g, sub, L.active, P, false, 0u);
+    // remainder1 / quotient1 are stored and the centred lift (index.js:117 verbatim) is applied pair by pair; the lifted
+    // message replaces P: it is the window of product 2
+    const StorePlan sp = store_plan<K>(g, sub, valid);
+    const long lane0 = row + 2 * K * sub;                              // this lane's first output
+    shared_product_split<K, ME, true>(E, masks_f, av_f, g, sub, want_q1, q, [&](int t, u16x2 rv, u16x2 qv) {
+      if (rem1) store_pair(rem1 + lane0, sp, t, rv);
+      if (want_q1) store_pair(quot1 + lane0, sp, t, qv);
+      const int k = 2 * (K * sub + t);
+      const u32 x0 = rv.x, x1 = rv.y;
       u32 b0 = mod_small(2 * x0 > q ? x0 + 1 : x0, p), b1 = mod_small(2 * x1 > q ? x1 + 1 : x1, p);
       b0 = k < N ? b0 : 0; b1 = k + 1 < N ? b1 : 0;
       P[t] = b0 | (b1 << 16);
-    }
+    });
     wave_lds_fence();                                                   // everyone is done reading E(e)
-    build_cyclic_pairs<K>(E, g, L.sub, L.active, P, true, P[0] & 0xFFFFu);
+    build_cyclic_pairs<K>(E, g, sub, L.active, P, true, P[0] & 0xFFFFu);
     // ---- product 2: c = fp * b mod p (exact small sums, no masking)
-    u16x2 r2[K], q2[K];
-    shared_product_split<K, 0, false>(E, masks_fp, av_fp, g, L.sub, want_q2, p, r2, q2);
-    if (valid) {
-      store_pairs<K>(value + row, g, L.sub, r2);
-      if (want_q2) store_pairs<K>(quot2 + row, g, L.sub, q2);
-    }
+    shared_product_split<K, 0, false>(E, masks_fp, av_fp, g, sub, want_q2, p, [&](int t, u16x2 rv, u16x2 qv) {
+      store_pair(value + lane0, sp, t, rv);
+      if (want_q2) store_pair(quot2 + lane0, sp, t, qv);
+    });
     wave_lds_fence();
   }
 }
@@ -1072,6 +1097,7 @@ struct ntru_engine {
   hipStream_t stream;
   int cus;
   int path;     // 0 auto, 1 force the MAC kernels, 2 force the add path where it is applicable
+  char last_kernel[64];   // name of the kernel the last *_dev call launched (reporting only)
 };
 
 #define HIP_TRY(expr)                                                                              \
@@ -1131,6 +1157,7 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
   eng->stream = nullptr;
   eng->cus = prop.multiProcessorCount;
   eng->path = 0;
+  eng->last_kernel[0] = 0;
   *out = eng;
   return NTRU_OK;
 }
@@ -1148,6 +1175,13 @@ extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (path < 0 || path > 2) return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC) or 2 (add)");
   eng->path = path;
   return NTRU_OK;
+}
+
+extern "C" const char *ntru_engine_last_kernel(ntru_engine_t *eng) { return eng ? eng->last_kernel : ""; }
+
+static void note_kernel(ntru_engine *eng, const char *family, int K, int me) {
+  if (me >= 0) snprintf(eng->last_kernel, sizeof eng->last_kernel, "%s<%d,%d>", family, K, me);
+  else snprintf(eng->last_kernel, sizeof eng->last_kernel, "%s<%d>", family, K);
 }
 
 extern "C" int ntru_engine_synchronize(ntru_engine_t *eng) {
@@ -1289,6 +1323,7 @@ extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const ui
     DISPATCH_K_ADD(L.K, me, {
       if (int rc = allow_lds(k_encrypt_t<KK, MM>, L.lds)) return rc;
     if (int rc = resident_grid(eng, k_encrypt_t<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+      note_kernel(eng, "k_encrypt_t", KK, MM);
       hipLaunchKernelGGL((k_encrypt_t<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q,
                          d_h, d_r, d_m, (long)B, d_e, d_quotE);
     });
@@ -1299,6 +1334,7 @@ extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const ui
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_encrypt<KK>, L.lds)) return rc;
     if (int rc = resident_grid(eng, k_encrypt<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+    note_kernel(eng, "k_encrypt", KK, -1);
     hipLaunchKernelGGL(k_encrypt<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, d_h, d_r, d_m,
                        (long)B, d_e, d_quotE);
   });
@@ -1321,7 +1357,7 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
     if (const int KS = shared_path_K(eng, N, q, p, &me)) {
       L.K = KS;
       L.g = make_geom(N, KS);
-      const size_t per_wave = (size_t)L.g.G * (L.g.eo_len + 1) * 4;
+      const size_t per_wave = (size_t)L.g.G * (L.g.eo_len + 2) * 4;
       L.lds = (size_t)L.g.nl * 16 + (size_t)L.g.nl * KS * 8 + WAVES_PER_BLOCK * per_wave;
       const long ngroups = (B + L.g.G - 1) / L.g.G;
       long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -1329,6 +1365,7 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
       DISPATCH_K_SHARED(KS, me, {
         if (int rc = allow_lds(k_decrypt_s<KK, MM>, L.lds)) return rc;
     if (int rc = resident_grid(eng, k_decrypt_s<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+        note_kernel(eng, "k_decrypt_s", KK, MM);
         hipLaunchKernelGGL((k_decrypt_s<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p,
                            d_f, d_fp, d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
       });
@@ -1343,6 +1380,7 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
     DISPATCH_K_ADD(L.K, me, {
       if (int rc = allow_lds(k_decrypt_t<KK, MM>, L.lds)) return rc;
     if (int rc = resident_grid(eng, k_decrypt_t<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+      note_kernel(eng, "k_decrypt_t", KK, MM);
       hipLaunchKernelGGL((k_decrypt_t<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p,
                          d_f, d_fp, d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
     });
@@ -1353,6 +1391,7 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_decrypt<KK>, L.lds)) return rc;
     if (int rc = resident_grid(eng, k_decrypt<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+    note_kernel(eng, "k_decrypt", KK, -1);
     hipLaunchKernelGGL(k_decrypt<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p, d_f, d_fp,
                        d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
   });
@@ -1374,6 +1413,7 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_polymul_split<KK>, L.lds)) return rc;
     if (int rc = resident_grid(eng, k_polymul_split<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+    note_kernel(eng, "k_polymul_split", KK, -1);
     hipLaunchKernelGGL(k_polymul_split<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)mod,
                        (int)is_pow2(mod), d_a, d_b, (long)B, d_quot, d_rem);
   });
@@ -1400,6 +1440,7 @@ extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int 
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_verify_keys<KK>, L.lds)) return rc;
     if (int rc = resident_grid(eng, k_verify_keys<KK>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+    note_kernel(eng, "k_verify_keys", KK, -1);
     hipLaunchKernelGGL(k_verify_keys<KK>, L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p, d_f, d_g,
                        d_fq, d_fp, d_h, (long)B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h, d_flags);
   });

@@ -29,6 +29,7 @@ _SIGS = {
     "ntru_engine_set_stream": (C.c_int, [_vp, _vp]),
     "ntru_engine_synchronize": (C.c_int, [_vp]),
     "ntru_engine_set_kernel_path": (C.c_int, [_vp, _i]),
+    "ntru_engine_last_kernel": (C.c_char_p, [_vp]),
     "ntru_last_error": (C.c_char_p, []),
     "ntru_engine_supports": (C.c_int, [_i, _i]),
 }
@@ -117,6 +118,9 @@ class Engine:
     def set_kernel_path(self, path):
         """0 auto, 1 packed-u16 MAC kernels, 2 ternary add path where applicable (same results)."""
         self._chk(self._lib.ntru_engine_set_kernel_path(self._h, int(path)))
+
+    def last_kernel(self):
+        return self._lib.ntru_engine_last_kernel(self._h).decode()
 
     def synchronize(self):
         self._chk(self._lib.ntru_engine_synchronize(self._h))

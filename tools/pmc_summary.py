@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof_*) into the summaries kept under profiles/.
+
+  python tools/pmc_summary.py <tag> [--mode witness|value] [--N 821] [--logB 20]
+
+Reads  gpurun_out/prof_stats/**/**_kernel_stats.csv            (rocprofv3 --kernel-trace --stats)
+       gpurun_out/prof_fetch/**/**_counter_collection.csv      (rocprofv3 --pmc FETCH_SIZE --kernel-trace)
+       gpurun_out/prof_write/**/**_counter_collection.csv      (rocprofv3 --pmc WRITE_SIZE --kernel-trace)
+Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_hbm.json and profiles/pmc_hbm_latest.json.
+HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE counts 64 B per 128-B request on gfx950
+(MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact."""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.match(r"(?:void )?(k_[a-z_]+<[0-9, ]+>)", name)
+    return m.group(1).replace(" ", "") if m else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--mode", default="witness")
+    ap.add_argument("--N", type=int, default=821)
+    ap.add_argument("--logB", type=int, default=20)
+    a = ap.parse_args()
+    out = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.reader(open(sorted(stats)[-1])))
+        with open(os.path.join(out, a.tag + "_kernel_stats.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            for r in rows:
+                w.writerow([r[0][:110]] + r[1:])
+    kern = {}
+    for cname, sub in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
+        files = glob.glob(os.path.join(ROOT, "gpurun_out", sub, "**", "*_counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(sorted(files)[-1])):
+            k = short(r["Kernel_Name"])
+            if k and r["Counter_Name"] == cname:
+                acc[k].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            kern.setdefault(k, {})[cname + "_KiB_per_launch"] = sum(v) / len(v)
+    B = 1 << a.logB
+    per_item = {"k_encrypt": (6, 4), "k_decrypt": (8, 3)}
+    for k, v in kern.items():
+        if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+            v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024
+            for fam, (wit, val) in per_item.items():
+                if k.startswith(fam):
+                    v["algorithmic_bytes_per_launch"] = (wit if a.mode == "witness" else val) * a.N * B
+                    v["ratio_to_algorithmic"] = v["hbm_bytes_per_launch"] / v["algorithmic_bytes_per_launch"]
+    doc = {"tag": a.tag, "mode": a.mode, "N": a.N, "batch_log2": a.logB,
+           "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py",
+           "kernels": kern}
+    for name in (a.tag + "_pmc_hbm.json", "pmc_hbm_latest.json"):
+        with open(os.path.join(out, name), "w") as fh:
+            json.dump(doc, fh, indent=1)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
