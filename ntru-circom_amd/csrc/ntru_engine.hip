@@ -371,69 +371,225 @@ static __device__ __forceinline__ void snapshot_if(bool take, u32 (&L1)[K], u32 
 template <int K> struct TernOps;
 template <>
 struct TernOps<1> {
-  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
-  template <int BIT>
-  static __device__ __forceinline__ void add_if(u32 (&S)[1], const u32 (&W)[1], u32 word) {
-    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
-                 "s_cbranch_scc0 1f\n\t"
-                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
-                 "1:\n"
-                 : [s0] "+v"(S[0])
-                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0])
+  // bit B1 of w1 set: S1[t] += W[t]; else bit B2 of w2 set: S2[t] += W[t]; else nothing.  Wave-uniform scalar tests,
+  // exactly one taken branch per step, in-place full-rate adds.
+  template <int B1, int B2>
+  static __device__ __forceinline__ void step(u32 (&S1)[1], u32 (&S2)[1], const u32 (&W)[1], u32 w1, u32 w2) {
+    asm volatile("s_bitcmp1_b32 %[wd1], %[bit1]\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitcmp1_b32 %[wd2], %[bit2]\n\t"
+                 "s_cbranch_scc0 3f\n\t"
+                 "v_add_u32 %[b0], %[b0], %[w0]\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "v_add_u32 %[a0], %[a0], %[w0]\n\t"
+                 "3:\n"
+                 : [a0] "+v"(S1[0]), [b0] "+v"(S2[0])
+                 : [wd1] "s"(w1), [wd2] "s"(w2), [bit1] "i"(B1), [bit2] "i"(B2), [w0] "v"(W[0])
                  : "scc");
   }
 };
 template <>
 struct TernOps<3> {
-  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
-  template <int BIT>
-  static __device__ __forceinline__ void add_if(u32 (&S)[3], const u32 (&W)[3], u32 word) {
-    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
-                 "s_cbranch_scc0 1f\n\t"
-                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
-                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
-                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
-                 "1:\n"
-                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2])
-                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2])
+  // bit B1 of w1 set: S1[t] += W[t]; else bit B2 of w2 set: S2[t] += W[t]; else nothing.  Wave-uniform scalar tests,
+  // exactly one taken branch per step, in-place full-rate adds.
+  template <int B1, int B2>
+  static __device__ __forceinline__ void step(u32 (&S1)[3], u32 (&S2)[3], const u32 (&W)[3], u32 w1, u32 w2) {
+    asm volatile("s_bitcmp1_b32 %[wd1], %[bit1]\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitcmp1_b32 %[wd2], %[bit2]\n\t"
+                 "s_cbranch_scc0 3f\n\t"
+                 "v_add_u32 %[b0], %[b0], %[w0]\n\t"
+                 "v_add_u32 %[b1], %[b1], %[w1]\n\t"
+                 "v_add_u32 %[b2], %[b2], %[w2]\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "v_add_u32 %[a0], %[a0], %[w0]\n\t"
+                 "v_add_u32 %[a1], %[a1], %[w1]\n\t"
+                 "v_add_u32 %[a2], %[a2], %[w2]\n\t"
+                 "3:\n"
+                 : [a0] "+v"(S1[0]), [a1] "+v"(S1[1]), [a2] "+v"(S1[2]), [b0] "+v"(S2[0]), [b1] "+v"(S2[1]), [b2] "+v"(S2[2])
+                 : [wd1] "s"(w1), [wd2] "s"(w2), [bit1] "i"(B1), [bit2] "i"(B2), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2])
                  : "scc");
   }
 };
 template <>
 struct TernOps<5> {
-  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
-  template <int BIT>
-  static __device__ __forceinline__ void add_if(u32 (&S)[5], const u32 (&W)[5], u32 word) {
-    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
-                 "s_cbranch_scc0 1f\n\t"
-                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
-                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
-                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
-                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
-                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
-                 "1:\n"
-                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4])
-                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4])
+  // bit B1 of w1 set: S1[t] += W[t]; else bit B2 of w2 set: S2[t] += W[t]; else nothing.  Wave-uniform scalar tests,
+  // exactly one taken branch per step, in-place full-rate adds.
+  template <int B1, int B2>
+  static __device__ __forceinline__ void step(u32 (&S1)[5], u32 (&S2)[5], const u32 (&W)[5], u32 w1, u32 w2) {
+    asm volatile("s_bitcmp1_b32 %[wd1], %[bit1]\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitcmp1_b32 %[wd2], %[bit2]\n\t"
+                 "s_cbranch_scc0 3f\n\t"
+                 "v_add_u32 %[b0], %[b0], %[w0]\n\t"
+                 "v_add_u32 %[b1], %[b1], %[w1]\n\t"
+                 "v_add_u32 %[b2], %[b2], %[w2]\n\t"
+                 "v_add_u32 %[b3], %[b3], %[w3]\n\t"
+                 "v_add_u32 %[b4], %[b4], %[w4]\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "v_add_u32 %[a0], %[a0], %[w0]\n\t"
+                 "v_add_u32 %[a1], %[a1], %[w1]\n\t"
+                 "v_add_u32 %[a2], %[a2], %[w2]\n\t"
+                 "v_add_u32 %[a3], %[a3], %[w3]\n\t"
+                 "v_add_u32 %[a4], %[a4], %[w4]\n\t"
+                 "3:\n"
+                 : [a0] "+v"(S1[0]), [a1] "+v"(S1[1]), [a2] "+v"(S1[2]), [a3] "+v"(S1[3]), [a4] "+v"(S1[4]), [b0] "+v"(S2[0]), [b1] "+v"(S2[1]), [b2] "+v"(S2[2]), [b3] "+v"(S2[3]), [b4] "+v"(S2[4])
+                 : [wd1] "s"(w1), [wd2] "s"(w2), [bit1] "i"(B1), [bit2] "i"(B2), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4])
                  : "scc");
   }
 };
 template <>
 struct TernOps<7> {
-  // if (bit BIT of `word`) S[t] += W[t] for all t: one scalar bit test, one forward branch, in-place full-rate adds
-  template <int BIT>
-  static __device__ __forceinline__ void add_if(u32 (&S)[7], const u32 (&W)[7], u32 word) {
-    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
-                 "s_cbranch_scc0 1f\n\t"
-                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
-                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
-                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
-                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
-                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
-                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
-                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
-                 "1:\n"
-                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6])
-                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6])
+  // bit B1 of w1 set: S1[t] += W[t]; else bit B2 of w2 set: S2[t] += W[t]; else nothing.  Wave-uniform scalar tests,
+  // exactly one taken branch per step, in-place full-rate adds.
+  template <int B1, int B2>
+  static __device__ __forceinline__ void step(u32 (&S1)[7], u32 (&S2)[7], const u32 (&W)[7], u32 w1, u32 w2) {
+    asm volatile("s_bitcmp1_b32 %[wd1], %[bit1]\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitcmp1_b32 %[wd2], %[bit2]\n\t"
+                 "s_cbranch_scc0 3f\n\t"
+                 "v_add_u32 %[b0], %[b0], %[w0]\n\t"
+                 "v_add_u32 %[b1], %[b1], %[w1]\n\t"
+                 "v_add_u32 %[b2], %[b2], %[w2]\n\t"
+                 "v_add_u32 %[b3], %[b3], %[w3]\n\t"
+                 "v_add_u32 %[b4], %[b4], %[w4]\n\t"
+                 "v_add_u32 %[b5], %[b5], %[w5]\n\t"
+                 "v_add_u32 %[b6], %[b6], %[w6]\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "v_add_u32 %[a0], %[a0], %[w0]\n\t"
+                 "v_add_u32 %[a1], %[a1], %[w1]\n\t"
+                 "v_add_u32 %[a2], %[a2], %[w2]\n\t"
+                 "v_add_u32 %[a3], %[a3], %[w3]\n\t"
+                 "v_add_u32 %[a4], %[a4], %[w4]\n\t"
+                 "v_add_u32 %[a5], %[a5], %[w5]\n\t"
+                 "v_add_u32 %[a6], %[a6], %[w6]\n\t"
+                 "3:\n"
+                 : [a0] "+v"(S1[0]), [a1] "+v"(S1[1]), [a2] "+v"(S1[2]), [a3] "+v"(S1[3]), [a4] "+v"(S1[4]), [a5] "+v"(S1[5]), [a6] "+v"(S1[6]), [b0] "+v"(S2[0]), [b1] "+v"(S2[1]), [b2] "+v"(S2[2]), [b3] "+v"(S2[3]), [b4] "+v"(S2[4]), [b5] "+v"(S2[5]), [b6] "+v"(S2[6])
+                 : [wd1] "s"(w1), [wd2] "s"(w2), [bit1] "i"(B1), [bit2] "i"(B2), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<9> {
+  // bit B1 of w1 set: S1[t] += W[t]; else bit B2 of w2 set: S2[t] += W[t]; else nothing.  Wave-uniform scalar tests,
+  // exactly one taken branch per step, in-place full-rate adds.
+  template <int B1, int B2>
+  static __device__ __forceinline__ void step(u32 (&S1)[9], u32 (&S2)[9], const u32 (&W)[9], u32 w1, u32 w2) {
+    asm volatile("s_bitcmp1_b32 %[wd1], %[bit1]\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitcmp1_b32 %[wd2], %[bit2]\n\t"
+                 "s_cbranch_scc0 3f\n\t"
+                 "v_add_u32 %[b0], %[b0], %[w0]\n\t"
+                 "v_add_u32 %[b1], %[b1], %[w1]\n\t"
+                 "v_add_u32 %[b2], %[b2], %[w2]\n\t"
+                 "v_add_u32 %[b3], %[b3], %[w3]\n\t"
+                 "v_add_u32 %[b4], %[b4], %[w4]\n\t"
+                 "v_add_u32 %[b5], %[b5], %[w5]\n\t"
+                 "v_add_u32 %[b6], %[b6], %[w6]\n\t"
+                 "v_add_u32 %[b7], %[b7], %[w7]\n\t"
+                 "v_add_u32 %[b8], %[b8], %[w8]\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "v_add_u32 %[a0], %[a0], %[w0]\n\t"
+                 "v_add_u32 %[a1], %[a1], %[w1]\n\t"
+                 "v_add_u32 %[a2], %[a2], %[w2]\n\t"
+                 "v_add_u32 %[a3], %[a3], %[w3]\n\t"
+                 "v_add_u32 %[a4], %[a4], %[w4]\n\t"
+                 "v_add_u32 %[a5], %[a5], %[w5]\n\t"
+                 "v_add_u32 %[a6], %[a6], %[w6]\n\t"
+                 "v_add_u32 %[a7], %[a7], %[w7]\n\t"
+                 "v_add_u32 %[a8], %[a8], %[w8]\n\t"
+                 "3:\n"
+                 : [a0] "+v"(S1[0]), [a1] "+v"(S1[1]), [a2] "+v"(S1[2]), [a3] "+v"(S1[3]), [a4] "+v"(S1[4]), [a5] "+v"(S1[5]), [a6] "+v"(S1[6]), [a7] "+v"(S1[7]), [a8] "+v"(S1[8]), [b0] "+v"(S2[0]), [b1] "+v"(S2[1]), [b2] "+v"(S2[2]), [b3] "+v"(S2[3]), [b4] "+v"(S2[4]), [b5] "+v"(S2[5]), [b6] "+v"(S2[6]), [b7] "+v"(S2[7]), [b8] "+v"(S2[8])
+                 : [wd1] "s"(w1), [wd2] "s"(w2), [bit1] "i"(B1), [bit2] "i"(B2), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<11> {
+  // bit B1 of w1 set: S1[t] += W[t]; else bit B2 of w2 set: S2[t] += W[t]; else nothing.  Wave-uniform scalar tests,
+  // exactly one taken branch per step, in-place full-rate adds.
+  template <int B1, int B2>
+  static __device__ __forceinline__ void step(u32 (&S1)[11], u32 (&S2)[11], const u32 (&W)[11], u32 w1, u32 w2) {
+    asm volatile("s_bitcmp1_b32 %[wd1], %[bit1]\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitcmp1_b32 %[wd2], %[bit2]\n\t"
+                 "s_cbranch_scc0 3f\n\t"
+                 "v_add_u32 %[b0], %[b0], %[w0]\n\t"
+                 "v_add_u32 %[b1], %[b1], %[w1]\n\t"
+                 "v_add_u32 %[b2], %[b2], %[w2]\n\t"
+                 "v_add_u32 %[b3], %[b3], %[w3]\n\t"
+                 "v_add_u32 %[b4], %[b4], %[w4]\n\t"
+                 "v_add_u32 %[b5], %[b5], %[w5]\n\t"
+                 "v_add_u32 %[b6], %[b6], %[w6]\n\t"
+                 "v_add_u32 %[b7], %[b7], %[w7]\n\t"
+                 "v_add_u32 %[b8], %[b8], %[w8]\n\t"
+                 "v_add_u32 %[b9], %[b9], %[w9]\n\t"
+                 "v_add_u32 %[b10], %[b10], %[w10]\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "v_add_u32 %[a0], %[a0], %[w0]\n\t"
+                 "v_add_u32 %[a1], %[a1], %[w1]\n\t"
+                 "v_add_u32 %[a2], %[a2], %[w2]\n\t"
+                 "v_add_u32 %[a3], %[a3], %[w3]\n\t"
+                 "v_add_u32 %[a4], %[a4], %[w4]\n\t"
+                 "v_add_u32 %[a5], %[a5], %[w5]\n\t"
+                 "v_add_u32 %[a6], %[a6], %[w6]\n\t"
+                 "v_add_u32 %[a7], %[a7], %[w7]\n\t"
+                 "v_add_u32 %[a8], %[a8], %[w8]\n\t"
+                 "v_add_u32 %[a9], %[a9], %[w9]\n\t"
+                 "v_add_u32 %[a10], %[a10], %[w10]\n\t"
+                 "3:\n"
+                 : [a0] "+v"(S1[0]), [a1] "+v"(S1[1]), [a2] "+v"(S1[2]), [a3] "+v"(S1[3]), [a4] "+v"(S1[4]), [a5] "+v"(S1[5]), [a6] "+v"(S1[6]), [a7] "+v"(S1[7]), [a8] "+v"(S1[8]), [a9] "+v"(S1[9]), [a10] "+v"(S1[10]), [b0] "+v"(S2[0]), [b1] "+v"(S2[1]), [b2] "+v"(S2[2]), [b3] "+v"(S2[3]), [b4] "+v"(S2[4]), [b5] "+v"(S2[5]), [b6] "+v"(S2[6]), [b7] "+v"(S2[7]), [b8] "+v"(S2[8]), [b9] "+v"(S2[9]), [b10] "+v"(S2[10])
+                 : [wd1] "s"(w1), [wd2] "s"(w2), [bit1] "i"(B1), [bit2] "i"(B2), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8]), [w9] "v"(W[9]), [w10] "v"(W[10])
+                 : "scc");
+  }
+};
+template <>
+struct TernOps<13> {
+  // bit B1 of w1 set: S1[t] += W[t]; else bit B2 of w2 set: S2[t] += W[t]; else nothing.  Wave-uniform scalar tests,
+  // exactly one taken branch per step, in-place full-rate adds.
+  template <int B1, int B2>
+  static __device__ __forceinline__ void step(u32 (&S1)[13], u32 (&S2)[13], const u32 (&W)[13], u32 w1, u32 w2) {
+    asm volatile("s_bitcmp1_b32 %[wd1], %[bit1]\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitcmp1_b32 %[wd2], %[bit2]\n\t"
+                 "s_cbranch_scc0 3f\n\t"
+                 "v_add_u32 %[b0], %[b0], %[w0]\n\t"
+                 "v_add_u32 %[b1], %[b1], %[w1]\n\t"
+                 "v_add_u32 %[b2], %[b2], %[w2]\n\t"
+                 "v_add_u32 %[b3], %[b3], %[w3]\n\t"
+                 "v_add_u32 %[b4], %[b4], %[w4]\n\t"
+                 "v_add_u32 %[b5], %[b5], %[w5]\n\t"
+                 "v_add_u32 %[b6], %[b6], %[w6]\n\t"
+                 "v_add_u32 %[b7], %[b7], %[w7]\n\t"
+                 "v_add_u32 %[b8], %[b8], %[w8]\n\t"
+                 "v_add_u32 %[b9], %[b9], %[w9]\n\t"
+                 "v_add_u32 %[b10], %[b10], %[w10]\n\t"
+                 "v_add_u32 %[b11], %[b11], %[w11]\n\t"
+                 "v_add_u32 %[b12], %[b12], %[w12]\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "v_add_u32 %[a0], %[a0], %[w0]\n\t"
+                 "v_add_u32 %[a1], %[a1], %[w1]\n\t"
+                 "v_add_u32 %[a2], %[a2], %[w2]\n\t"
+                 "v_add_u32 %[a3], %[a3], %[w3]\n\t"
+                 "v_add_u32 %[a4], %[a4], %[w4]\n\t"
+                 "v_add_u32 %[a5], %[a5], %[w5]\n\t"
+                 "v_add_u32 %[a6], %[a6], %[w6]\n\t"
+                 "v_add_u32 %[a7], %[a7], %[w7]\n\t"
+                 "v_add_u32 %[a8], %[a8], %[w8]\n\t"
+                 "v_add_u32 %[a9], %[a9], %[w9]\n\t"
+                 "v_add_u32 %[a10], %[a10], %[w10]\n\t"
+                 "v_add_u32 %[a11], %[a11], %[w11]\n\t"
+                 "v_add_u32 %[a12], %[a12], %[w12]\n\t"
+                 "3:\n"
+                 : [a0] "+v"(S1[0]), [a1] "+v"(S1[1]), [a2] "+v"(S1[2]), [a3] "+v"(S1[3]), [a4] "+v"(S1[4]), [a5] "+v"(S1[5]), [a6] "+v"(S1[6]), [a7] "+v"(S1[7]), [a8] "+v"(S1[8]), [a9] "+v"(S1[9]), [a10] "+v"(S1[10]), [a11] "+v"(S1[11]), [a12] "+v"(S1[12]), [b0] "+v"(S2[0]), [b1] "+v"(S2[1]), [b2] "+v"(S2[2]), [b3] "+v"(S2[3]), [b4] "+v"(S2[4]), [b5] "+v"(S2[5]), [b6] "+v"(S2[6]), [b7] "+v"(S2[7]), [b8] "+v"(S2[8]), [b9] "+v"(S2[9]), [b10] "+v"(S2[10]), [b11] "+v"(S2[11]), [b12] "+v"(S2[12])
+                 : [wd1] "s"(w1), [wd2] "s"(w2), [bit1] "i"(B1), [bit2] "i"(B2), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8]), [w9] "v"(W[9]), [w10] "v"(W[10]), [w11] "v"(W[11]), [w12] "v"(W[12])
                  : "scc");
   }
 };
@@ -453,8 +609,7 @@ static __device__ __forceinline__ void tern_steps(u32 (&S1)[K], u32 (&S2)[K], u3
     u32 W[K];
 #pragma unroll
     for (int t = 0; t < K; t++) W[t] = (J & 1) ? WO[(t - s + K) % K] : WE[(t - s + K) % K];
-    TernOps<K>::template add_if<J>(S1, W, word);
-    TernOps<K>::template add_if<16 + J>(S2, W, word);
+    TernOps<K>::template step<J, 16 + J>(S1, S2, W, word, word);
     if constexpr ((J & 1) != 0) { WE[K - 1 - s] = nw[s].x; WO[K - 1 - s] = nw[s].y; }
     tern_steps<K, ME, J + 1>(S1, S2, WE, WO, nw, word, fmask);
   }
@@ -669,75 +824,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt_t(Geom g, u32 q, u32 
   }
 }
 
-template <>
-struct TernOps<9> {
-  template <int BIT>
-  static __device__ __forceinline__ void add_if(u32 (&S)[9], const u32 (&W)[9], u32 word) {
-    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
-                 "s_cbranch_scc0 1f\n\t"
-                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
-                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
-                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
-                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
-                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
-                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
-                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
-                 "v_add_u32 %[s7], %[s7], %[w7]\n\t"
-                 "v_add_u32 %[s8], %[s8], %[w8]\n\t"
-                 "1:\n"
-                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6]), [s7] "+v"(S[7]), [s8] "+v"(S[8])
-                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8])
-                 : "scc");
-  }
-};
-template <>
-struct TernOps<11> {
-  template <int BIT>
-  static __device__ __forceinline__ void add_if(u32 (&S)[11], const u32 (&W)[11], u32 word) {
-    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
-                 "s_cbranch_scc0 1f\n\t"
-                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
-                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
-                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
-                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
-                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
-                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
-                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
-                 "v_add_u32 %[s7], %[s7], %[w7]\n\t"
-                 "v_add_u32 %[s8], %[s8], %[w8]\n\t"
-                 "v_add_u32 %[s9], %[s9], %[w9]\n\t"
-                 "v_add_u32 %[s10], %[s10], %[w10]\n\t"
-                 "1:\n"
-                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6]), [s7] "+v"(S[7]), [s8] "+v"(S[8]), [s9] "+v"(S[9]), [s10] "+v"(S[10])
-                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8]), [w9] "v"(W[9]), [w10] "v"(W[10])
-                 : "scc");
-  }
-};
-template <>
-struct TernOps<13> {
-  template <int BIT>
-  static __device__ __forceinline__ void add_if(u32 (&S)[13], const u32 (&W)[13], u32 word) {
-    asm volatile("s_bitcmp1_b32 %[wd], %[bit]\n\t"
-                 "s_cbranch_scc0 1f\n\t"
-                 "v_add_u32 %[s0], %[s0], %[w0]\n\t"
-                 "v_add_u32 %[s1], %[s1], %[w1]\n\t"
-                 "v_add_u32 %[s2], %[s2], %[w2]\n\t"
-                 "v_add_u32 %[s3], %[s3], %[w3]\n\t"
-                 "v_add_u32 %[s4], %[s4], %[w4]\n\t"
-                 "v_add_u32 %[s5], %[s5], %[w5]\n\t"
-                 "v_add_u32 %[s6], %[s6], %[w6]\n\t"
-                 "v_add_u32 %[s7], %[s7], %[w7]\n\t"
-                 "v_add_u32 %[s8], %[s8], %[w8]\n\t"
-                 "v_add_u32 %[s9], %[s9], %[w9]\n\t"
-                 "v_add_u32 %[s10], %[s10], %[w10]\n\t"
-                 "v_add_u32 %[s11], %[s11], %[w11]\n\t"
-                 "v_add_u32 %[s12], %[s12], %[w12]\n\t"
-                 "1:\n"
-                 : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [s2] "+v"(S[2]), [s3] "+v"(S[3]), [s4] "+v"(S[4]), [s5] "+v"(S[5]), [s6] "+v"(S[6]), [s7] "+v"(S[7]), [s8] "+v"(S[8]), [s9] "+v"(S[9]), [s10] "+v"(S[10]), [s11] "+v"(S[11]), [s12] "+v"(S[12])
-                 : [wd] "s"(word), [bit] "i"(BIT), [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]), [w8] "v"(W[8]), [w9] "v"(W[9]), [w10] "v"(W[10]), [w11] "v"(W[11]), [w12] "v"(W[12])
-                 : "scc");
-  }
-};
 
 // ================================================================================================================
 // Shared-stepping add path (decrypt).  Both products of decryptBits can step over a SHARED key operand (f, then fp),
@@ -794,8 +880,7 @@ static __device__ __forceinline__ void shared_steps(u32 (&S1)[K], u32 (&S2)[K], 
     u32 W[K];
 #pragma unroll
     for (int t = 0; t < K; t++) W[t] = (J & 1) ? WO[(t - s + K) % K] : WE[(t - s + K) % K];
-    TernOps<K>::template add_if<J>(S1, W, ones);
-    TernOps<K>::template add_if<J>(S2, W, twos);
+    TernOps<K>::template step<J, J>(S1, S2, W, ones, twos);
     if constexpr ((J & 1) != 0) { WE[K - 1 - s] = nw[s]; WO[K - 1 - s] = odd_pair(nw[s], nw[s + 1]); }
     shared_steps<K, ME, J + 1>(S1, S2, WE, WO, nw, ones, twos, fmask);
   }
