@@ -672,8 +672,9 @@ static __device__ __forceinline__ void store_pair(OutT *lane_row, const StorePla
 }
 
 // Runs one per-item-stepped product and hands each finished pair to `emit(t, rem_pair, quot_pair)` right away.
-template <int K, int ME, bool NEG, class Emit>
-static __device__ __forceinline__ void tern_product_split(const uint2 *eo, const u32 *codes, const u32 (&av)[K],
+// av(s): the lane's s-th pair of the stepping operand (numeric), only evaluated for the triangle after the main loop.
+template <int K, int ME, bool NEG, class AV, class Emit>
+static __device__ __forceinline__ void tern_product_split(const uint2 *eo, const u32 *codes, AV av,
                                                           const Geom &g, int sub, bool want_quot, u32 mod, Emit emit) {
   constexpr bool POW2 = ME > 0;
   const u32 fmask = POW2 ? (mod - 1) * 0x00010001u : 0xFFFFFFFFu;
@@ -691,7 +692,7 @@ static __device__ __forceinline__ void tern_product_split(const uint2 *eo, const
     ZO[0] &= 0xFFFF0000u;
 #pragma unroll
     for (int s = 0; s < K; s++) {
-      const u16x2 ap = as_pair(av[s]);
+      const u16x2 ap = as_pair(av(s));
 #pragma unroll
       for (int t = s; t < K; t++) {
         low[t] = ap.xx * as_pair(ZE[t - s]) + low[t];
@@ -734,7 +735,7 @@ static __device__ __forceinline__ u32 load_block(F val, int N, int sub, u32 (&av
 
 // encryptBits on the add path: stepping operand r in {0,1,2}, window h (shared).
 template <int K, int ME>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_encrypt_t(Geom g, u32 q, const u16 *__restrict__ h,
+__global__ __launch_bounds__(BLOCK_THREADS, 7) void k_encrypt_t(Geom g, u32 q, const u16 *__restrict__ h,
                                                              const uint8_t *__restrict__ r,
                                                              const uint8_t *__restrict__ m, long B,
                                                              u16 *__restrict__ e, u16 *__restrict__ quotE) {
@@ -749,19 +750,31 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_encrypt_t(Geom g, u32 q, cons
     int sub = L.sub, N = g.N;                            // re-materialised per iteration: keeps the glue out of LICM's reach
     asm volatile("" : "+v"(sub), "+s"(N));
     const long row = item * N;
-    u32 av[K];
-    const u32 word = load_block<K>(ValU8{r + row}, N, sub, av);
-#pragma unroll
-    for (int t = 0; t < K; t++) asm volatile("" : "+v"(av[t]));            // pack now: 7 live registers instead of 14+ raw bytes
-    if (L.active) codes[sub] = word;
+    {
+      u32 av[K];
+      const u32 word = load_block<K>(ValU8{r + row}, N, sub, av);
+      if (L.active) codes[sub] = word;
+    }
     wave_lds_fence();
-    const StorePlan sp = store_plan<K>(g, sub, L.active);
-    const long lane0 = row + 2 * K * sub;
-    tern_product_split<K, ME, false>(eo_h, codes, av, g, sub, want_quot, q, [&](int t, u16x2 rv, u16x2 qv) {
-      const int k = 2 * K * sub + 2 * t;
+    // everything below runs behind the hot loop; `sub2` is a fresh opaque copy so that none of its index arithmetic
+    // is CSE'd with the pre-loop block load and kept live (spilled) across the loop
+    auto r_pair = [&](int t) -> u32 {                                     // reloaded behind the hot loop (L1/L2 hit)
+      int sub2 = sub;
+      asm volatile("" : "+v"(sub2));
+      const uint8_t *rr = r + row;
+      const int k = 2 * K * sub2 + 2 * t;
+      const int k0 = k < N ? k : N - 1, k1 = k + 1 < N ? k + 1 : N - 1;
+      const u32 v0 = k < N ? rr[k0] : 0u, v1 = k + 1 < N ? rr[k1] : 0u;
+      return v0 | (v1 << 16);
+    };
+    tern_product_split<K, ME, false>(eo_h, codes, r_pair, g, sub, want_quot, q, [&](int t, u16x2 rv, u16x2 qv) {
+      int sub2 = sub;
+      asm volatile("" : "+v"(sub2));
+      const StorePlan sp = store_plan<K>(g, sub2, L.active);
+      const long lane0 = row + 2 * K * sub2;
+      const int k = 2 * K * sub2 + 2 * t;
       const int k0 = k < N ? k : N - 1, k1 = k + 1 < N ? k + 1 : N - 1;
       const uint8_t *mr = m + row;
-      asm volatile("" : "+v"(mr));                                          // keep these loads BEHIND the hot loop
       const u16x2 add = {(u16)mr[k0], (u16)mr[k1]};                         // out-of-row lanes never store
       store_pair(e + lane0, sp, t, (rv + add) & (u16)(q - 1));
       if (want_quot) store_pair(quotE + lane0, sp, t, qv);
@@ -803,7 +816,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt_t(Geom g, u32 q, u32 
     const long lane0 = row + 2 * K * L.sub;
     u32 av_b[K], wb = 0;
     // remainder1 / quotient1 stored pair by pair; centred lift, index.js:117 verbatim -> second stepping operand
-    tern_product_split<K, ME, true>(eo_e, codes_f, av_f, g, L.sub, want_q1, q, [&](int t, u16x2 rv, u16x2 qv) {
+    tern_product_split<K, ME, true>(eo_e, codes_f, [&](int t) { return av_f[t]; }, g, L.sub, want_q1, q, [&](int t, u16x2 rv, u16x2 qv) {
       rv = rv & (u16)(q - 1);
       if (rem1) store_pair(rem1 + lane0, sp, t, rv);
       if (want_q1) store_pair(quot1 + lane0, sp, t, qv);
@@ -816,7 +829,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt_t(Geom g, u32 q, u32 
     });
     if (L.active) codes_b[L.sub] = wb;
     wave_lds_fence();
-    tern_product_split<K, 0, false>(eo_fp, codes_b, av_b, g, L.sub, want_q2, p, [&](int t, u16x2 rv, u16x2 qv) {
+    tern_product_split<K, 0, false>(eo_fp, codes_b, [&](int t) { return av_b[t]; }, g, L.sub, want_q2, p, [&](int t, u16x2 rv, u16x2 qv) {
       store_pair(value + lane0, sp, t, rv);
       if (want_q2) store_pair(quot2 + lane0, sp, t, qv);
     });
@@ -1328,13 +1341,13 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
   if ((long)N * 4 >= 65536) return 0;
   long limit = 65535 / (q - 1) - 1;
   if (limit >= K) *me = K; else if (limit >= 7) *me = 7; else return 0;
+  if (K == 13 && *me == 7) return 0;      // that variant does not fit 128 VGPRs without spilling: use the MAC kernels
   return K;
 }
 
 #define DISPATCH_K_SHARED(Kv, MEv, ...)                                                             \
   switch ((Kv) * 100 + (MEv)) {                                                                     \
     case 1313: { constexpr int KK = 13, MM = 13; __VA_ARGS__; } break;                              \
-    case 1307: { constexpr int KK = 13, MM = 7; __VA_ARGS__; } break;                               \
     case 1111: { constexpr int KK = 11, MM = 11; __VA_ARGS__; } break;                              \
     case 1107: { constexpr int KK = 11, MM = 7; __VA_ARGS__; } break;                               \
     case 909: { constexpr int KK = 9, MM = 9; __VA_ARGS__; } break;                                 \

@@ -120,6 +120,51 @@ def test_encrypt_decrypt_batches_equal_oracle(eng, N, q, d):
     assert np.array_equal(v_only[0], want[0]) and v_only[1] is None
 
 
+@pytest.mark.parametrize("N,q", [(821, 4096), (701, 8192), (509, 2048), (677, 2048), (449, 8192), (128, 16384),
+                                  (384, 32)])
+def test_field_overflow_extremes(eng, N, q):
+    """Worst cases for the add path's 16-bit field budget: every step adds a window of all (q-1) into the same
+    accumulator set (stepping operand all ones / all twos / all -1), on every kernel family."""
+    p = 3
+    hmax = np.full(N, q - 1)
+    r = np.stack([np.ones(N), np.full(N, 2), np.arange(N) % 3, (np.arange(N) + 1) % 2 * 2]).astype(np.int64)
+    m = np.full((4, N), 2)
+    for path in (0, 1, 2):
+        eng.set_kernel_path(path)
+        try:
+            e, quot = eng.encrypt_batch(N, q, hmax, r, m)
+            e_o, quot_o = orc.encrypt_batch(N, q, hmax, r, m)
+            assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), path
+            for fvec in (np.ones(N), -np.ones(N), (np.arange(N) % 3) - 1):
+                for fpvec in (np.full(N, 2), np.ones(N), np.arange(N) % 3):
+                    ein = np.stack([np.full(N, q - 1), np.arange(N) % q, np.full(N, q // 2 + 1), np.zeros(N)]).astype(np.int64)
+                    got = eng.decrypt_batch(N, q, p, fvec, fpvec, ein)
+                    want = orc.decrypt_batch(N, q, p, fvec, fpvec, ein)
+                    for g_, w_ in zip(got, want):
+                        assert np.array_equal(g_, w_), path
+        finally:
+            eng.set_kernel_path(0)
+
+
+def test_kernel_families_agree(eng):
+    rng = np.random.default_rng(99)
+    for N, q, d in ((821, 4096, 273), (701, 8192, 233), (509, 2048, 169)):
+        h = rng.integers(0, q, N); fp = rng.integers(0, 3, N)
+        f = ternary_rows(rng, 1, N, d, d - 1, two=-1)[0]
+        r = ternary_rows(rng, 9, N, d, d); m = rng.integers(0, 2, (9, N))
+        outs, names = [], []
+        for path in (1, 2, 0):
+            eng.set_kernel_path(path)
+            e, quot = eng.encrypt_batch(N, q, h, r, m)
+            names.append(eng.last_kernel() if False else None)
+            dec = eng.decrypt_batch(N, q, 3, f, fp, e)
+            outs.append((e, quot) + dec)
+        eng.set_kernel_path(0)
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 6, 7, 8, 13, 29, 257])
 def test_ragged_batch_sizes(eng, B):
     # N=17 packs 7 items per wavefront, N=167 two: batches that do not fill a wave / a workgroup
