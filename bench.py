@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-path", choices=["auto", "mac", "add"], default="auto",
                     help="kernel family: packed-u16 MAC, ternary add path, or the engine's choice (same results)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only for rehearsing the launch path on one GPU")
+    ap.add_argument("--device", type=int, default=None, help="override the HIP device (default LOCAL_RANK)")
     ap.add_argument("--gather", action="store_true", help="after timing, all_gather the decrypted values (RCCL)")
     return ap.parse_args()
 
@@ -69,14 +72,14 @@ def make_inputs(torch, dev, B, N, d, seed):
     return r, m
 
 
-def pmc_traffic(kernel, mode):
+def pmc_traffic(kernel, mode, batch_log2):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_hbm_latest.json:
     2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950), or None if not collected for it."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")) as fh:
             d = json.load(fh)
         k = d["kernels"].get(kernel)
-        return k["hbm_bytes_per_launch"] if k and d.get("mode") == mode else None
+        return k["hbm_bytes_per_launch"] if k and d.get("mode") == mode and d.get("batch_log2") == batch_log2 else None
     except (OSError, ValueError, KeyError):
         return None
 
@@ -122,12 +125,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if args.dist_backend == "nccl" else None        # where the timing all_reduce lives
 
     o, h_np, f_np, fp_np = load_key(args.profile)
     N, q, p, d = o["N"], o["q"], o["p"], o["dr"]
@@ -145,7 +153,7 @@ def main():
     quotE, quot1, rem1, quot2 = (b16(), b16(), b16(), b8()) if witness else (None, None, None, None)
     ptr = lambda t: t.data_ptr() if t is not None else None
 
-    eng = pkg.Engine(local_rank)
+    eng = pkg.Engine(dev_index)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2}[args.kernel_path])
@@ -169,7 +177,7 @@ def main():
         for k in range(args.steps):
             step(events[k])
 
-    elapsed = sh.timed_region(run_steps, torch.cuda.synchronize, dist, dev)
+    elapsed = sh.timed_region(run_steps, torch.cuda.synchronize, dist, red_dev)
     enc_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events]))
     dec_ms = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in events]))
 
@@ -189,7 +197,7 @@ def main():
     gathered = None
     if args.gather and dist:
         torch.cuda.synchronize(); tg = time.perf_counter()
-        allv = sh.gather_rows(value, dist)
+        allv = sh.gather_rows(value if args.dist_backend == "nccl" else value.cpu(), dist)
         torch.cuda.synchronize()
         gathered = {"rows": int(allv.shape[0]), "bytes_per_rank": int(value.numel()), "seconds": time.perf_counter() - tg}
 
@@ -229,7 +237,7 @@ def main():
             "verified_bit_exact_rows": int(rows.numel()),
             "kernels_ms": {names.get("encrypt", "k_encrypt"): enc_ms, dname: dec_ms},
             "roofline": {"bound": "hbm", "kernel": dname, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dname, args.mode),
+                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dname, args.mode, args.batch_log2),
                          "algorithmic_bytes_per_item": dec_bytes, "algorithmic_bytes_per_launch": dec_bytes * B,
                          "note": "the path is VALU/scalar-issue bound (O(N^2) integer work on O(N) bytes); see `valu`"},
             "valu": valu,
