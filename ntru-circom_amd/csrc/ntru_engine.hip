@@ -75,6 +75,18 @@ struct ValTernary {        // f, g in {-1,0,1}: -1 -> mod-1 (index.js:112,151,15
   __device__ __forceinline__ u32 operator()(int j) const { int v = p[j]; return v < 0 ? neg : (u32)v; }
 };
 
+struct ValLds {            // an operand staged as u16 in LDS (per-item windows: coalesced global loads first)
+  const u16 *p;
+  __device__ __forceinline__ u32 operator()(int j) const { return p[j]; }
+};
+
+// Stage N coefficients of a per-item operand into LDS as u16 (lane `sub` of the item's `nl` lanes; coalesced).
+template <class F>
+static __device__ __forceinline__ void stage_raw(u16 *raw, int N, int nl, F val, int sub, bool active) {
+  if (!active) return;
+  for (int i = sub; i < N; i += nl) raw[i] = (u16)val(i);
+}
+
 // Build one EO array (see header) from `val`; executed by `nthr` cooperating threads, this one being `tid`.
 template <class F>
 static __device__ __forceinline__ void build_eo(uint2 *eo, const Geom &g, F val, int tid, int nthr) {
@@ -307,17 +319,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod
                                                                  long B, u16 *__restrict__ quot, u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const LaneId L = lane_id(g);
-  const size_t per_wave = (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4);
+  const size_t raw_len = ((size_t)g.N + 1) & ~(size_t)1;                 // u16 slots per staged operand (dword aligned)
+  const size_t per_wave = (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4 + raw_len * 2);
   unsigned char *wbase = lds + (size_t)L.wave * per_wave;
   uint2 *eo = (uint2 *)wbase + (size_t)L.grp * g.eo_len;
   u32 *a32 = (u32 *)(wbase + (size_t)g.G * g.eo_len * 8) + (size_t)L.grp * g.a_len;
+  u16 *raw = (u16 *)(wbase + (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4)) + (size_t)L.grp * raw_len;
   const long ngroups = (B + g.G - 1) / g.G;
   for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
     const long item = grp * g.G + L.grp;
     const bool valid = L.active && item < B;
     const long row = (valid ? item : 0) * g.N;
-    if (L.active) build_eo(eo, g, ValU16{b + row}, L.sub, g.nl);
+    stage_raw(raw, g.N, g.nl, ValU16{b + row}, L.sub, L.active);
     stage_a((u16 *)a32, g, ValU16{a + row}, L.sub, L.active);
+    wave_lds_fence();
+    if (L.active) build_eo(eo, g, ValLds{raw}, L.sub, g.nl);
     wave_lds_fence();
     u16x2 r[K], qv[K];
     if (pow2) {
@@ -1081,10 +1097,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys(
     u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const LaneId L = lane_id(g);
-  const size_t per_wave = (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4);
+  const size_t raw_len = ((size_t)g.N + 1) & ~(size_t)1;
+  const size_t per_wave = (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4 + raw_len * 2);
   unsigned char *wbase = lds + (size_t)L.wave * per_wave;
   uint2 *eo = (uint2 *)wbase + (size_t)L.grp * g.eo_len;
   u32 *a32 = (u32 *)(wbase + (size_t)g.G * g.eo_len * 8) + (size_t)L.grp * g.a_len;
+  u16 *raw = (u16 *)(wbase + (size_t)g.G * ((size_t)g.eo_len * 8 + (size_t)g.a_len * 4)) + (size_t)L.grp * raw_len;
   const long ngroups = (B + g.G - 1) / g.G;
   for (long grp = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; grp < ngroups; grp += (long)gridDim.x * WAVES_PER_BLOCK) {
     const long item = grp * g.G + L.grp;
@@ -1093,8 +1111,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys(
     u32 fl = 0;
     u16x2 r[K], qv[K];
     // ---- fq * f mod q (index.js:158-160)
-    if (L.active) build_eo(eo, g, ValTernary{f + row, q - 1}, L.sub, g.nl);
+    stage_raw(raw, g.N, g.nl, ValTernary{f + row, q - 1}, L.sub, L.active);
     stage_a((u16 *)a32, g, ValU16{fq + row}, L.sub, L.active);
+    wave_lds_fence();
+    if (L.active) build_eo(eo, g, ValLds{raw}, L.sub, g.nl);
     wave_lds_fence();
     product_split<K, true>(eo, a32, g, L.sub, true, q, r, qv);
     {
@@ -1111,8 +1131,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys(
     if (valid) { store_pairs<K>(rem_fq + row, g, L.sub, r); store_pairs<K>(quot_fq + row, g, L.sub, qv); }
     wave_lds_fence();
     // ---- fp * f mod p (index.js:161-163)
-    if (L.active) build_eo(eo, g, ValTernary{f + row, p - 1}, L.sub, g.nl);
+    // the staged f only differs in what -1 maps to: patch q-1 -> p-1 in place instead of re-reading it
+    if (q > 2) {
+      if (L.active) for (int i = L.sub; i < g.N; i += g.nl) { const u16 v = raw[i]; raw[i] = v == (u16)(q - 1) ? (u16)(p - 1) : v; }
+    } else {                                              // q = 2: -1 and +1 coincide mod q, so re-stage from the source
+      stage_raw(raw, g.N, g.nl, ValTernary{f + row, p - 1}, L.sub, L.active);
+    }
     stage_a((u16 *)a32, g, ValU8{fp + row}, L.sub, L.active);
+    wave_lds_fence();
+    if (L.active) build_eo(eo, g, ValLds{raw}, L.sub, g.nl);
     wave_lds_fence();
     product_split<K, false>(eo, a32, g, L.sub, true, p, r, qv);
     {
@@ -1128,8 +1155,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys(
     if (valid) { store_pairs<K>(rem_fp + row, g, L.sub, r); store_pairs<K>(quot_fp + row, g, L.sub, qv); }
     wave_lds_fence();
     // ---- (p*fq) * g mod q (index.js:155,164-166)
-    if (L.active) build_eo(eo, g, ValTernary{gg + row, q - 1}, L.sub, g.nl);
+    stage_raw(raw, g.N, g.nl, ValTernary{gg + row, q - 1}, L.sub, L.active);
     stage_a((u16 *)a32, g, ValU16x3{fq + row, p}, L.sub, L.active);
+    wave_lds_fence();
+    if (L.active) build_eo(eo, g, ValLds{raw}, L.sub, g.nl);
     wave_lds_fence();
     product_split<K, true>(eo, a32, g, L.sub, true, q, r, qv);
     {
@@ -1297,7 +1326,8 @@ static int plan(const ntru_engine *eng, int N, long B, int shared_eo, bool per_i
   if (!K) return fail(NTRU_ERR_UNSUPPORTED, "N too large");
   L->K = K;
   L->g = make_geom(N, K);
-  size_t per_wave = (size_t)L->g.G * ((size_t)L->g.a_len * 4 + (per_item_eo ? (size_t)L->g.eo_len * 8 : 0));
+  const size_t raw_len = ((size_t)N + 1) & ~(size_t)1;
+  size_t per_wave = (size_t)L->g.G * ((size_t)L->g.a_len * 4 + (per_item_eo ? (size_t)L->g.eo_len * 8 + raw_len * 2 : 0));
   L->lds = (size_t)shared_eo * L->g.eo_len * 8 + WAVES_PER_BLOCK * per_wave;
   if (L->lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "parameter set needs more than 160 KiB of LDS");
   long ngroups = (B + L->g.G - 1) / L->g.G;

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configs other than the headline (1 GPU, inputs resident in HBM).
+Prints one JSON object per config; bench.py remains the contract benchmark."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+import bench  # noqa: E402
+
+pkg = ge.load_package()
+dev = torch.device("cuda", 0)
+eng = pkg.Engine(0)
+stream = torch.cuda.current_stream()
+eng.set_stream(stream.cuda_stream)
+
+
+def timed(fn, steps=5, warmup=2):
+    for _ in range(warmup):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record(stream)
+    for k in range(steps):
+        fn()
+        ev[k + 1].record(stream)
+    torch.cuda.synchronize()
+    return float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
+
+
+def encrypt_config(profile, logB):
+    o, h_np, f_np, fp_np = bench.load_key(profile)
+    N, q, d = o["N"], o["q"], o["dr"]
+    B = 1 << logB
+    r, m = bench.make_inputs(torch, dev, B, N, d, 1)
+    h = torch.from_numpy(h_np.view(np.int16)).to(dev)
+    e = torch.empty((B, N), dtype=torch.int16, device=dev)
+    quot = torch.empty((B, N), dtype=torch.int16, device=dev)
+    ms = timed(lambda: eng.encrypt_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e.data_ptr(), quot.data_ptr()))
+    return {"config": "N=%d q=%d batch=2^%d encryptBits (full witness), 1 GPU" % (N, q, logB), "kernel": eng.last_kernel(),
+            "ms": ms, "encrypts_per_s": B / (ms * 1e-3), "hbm_GBps": 6 * N * B / (ms * 1e-3) / 1e9}
+
+
+def verify_config(profile, logB):
+    o, _, _, _ = bench.load_key(profile)
+    N, q, p, d = o["N"], o["q"], o["p"], o["dr"]
+    B = 1 << logB
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    tern = lambda: (torch.randint(0, 3, (B, N), device=dev, generator=gen) - 1).to(torch.int8)
+    f, g = tern(), tern()
+    fq = torch.randint(0, q, (B, N), device=dev, generator=gen).to(torch.int16)
+    hh = torch.randint(0, q, (B, N), device=dev, generator=gen).to(torch.int16)
+    fp = torch.randint(0, p, (B, N), device=dev, generator=gen).to(torch.uint8)
+    o16 = lambda: torch.empty((B, N), dtype=torch.int16, device=dev)
+    o8 = lambda: torch.empty((B, N), dtype=torch.uint8, device=dev)
+    outs = [o16(), o16(), o8(), o8(), o16(), o16()]
+    flags = torch.empty(B, dtype=torch.uint8, device=dev)
+    ms = timed(lambda: eng.verify_keys_batch_dev(N, q, p, f.data_ptr(), g.data_ptr(), fq.data_ptr(), fp.data_ptr(),
+                                                 hh.data_ptr(), B, *[t.data_ptr() for t in outs], flags.data_ptr()))
+    return {"config": "N=%d q=%d verifyKeysInputs batch=2^%d synthetic per-item keys, 1 GPU" % (N, q, logB),
+            "kernel": eng.last_kernel(), "ms": ms, "keys_per_s": B / (ms * 1e-3), "hbm_GBps": 17 * N * B / (ms * 1e-3) / 1e9}
+
+
+if __name__ == "__main__":
+    for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
+                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18)):
+        print(json.dumps(res), flush=True)
