@@ -66,6 +66,10 @@ struct ValU16x3 {          // fqp = p*fq left unreduced (index.js:155); 3*8191 <
   const u16 *p; u32 mul;
   __device__ __forceinline__ u32 operator()(int j) const { return (u32)p[j] * mul; }
 };
+struct ValU16x3m {         // (p*fq) mod q: the same window reduced, for the add path's 16-bit field budget
+  const u16 *p; u32 mul, mask;
+  __device__ __forceinline__ u32 operator()(int j) const { return ((u32)p[j] * mul) & mask; }
+};
 struct ValU8 {             // r, fp, m
   const uint8_t *p;
   __device__ __forceinline__ u32 operator()(int j) const { return p[j]; }
@@ -367,8 +371,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod
 // kernels above are used.
 // ================================================================================================================
 
-// bit j: step j adds into S1 (value 1); bit 16+j: step j adds into S2 (the other non-zero symbol)
-static __device__ __forceinline__ u32 step_bits(u32 v, int j) { return v == 0 ? 0u : (v == 1 ? 1u << j : 1u << (16 + j)); }
+// bit j: step j adds into S1 (value 1); bit 16+j: step j adds into S2 (the other non-zero symbol).  Written with
+// 0/1 flags and immediate shifts so that no per-bit constant has to live in a VGPR (a select between two literal
+// masks would: 2 x 2K constants hoisted for the whole kernel).
+static __device__ __forceinline__ u32 step_bits(u32 v, int j) {
+  u32 is1 = v == 1u ? 1u : 0u, is2 = v > 1u ? 1u : 0u;
+  asm volatile("" : "+v"(is1), "+v"(is2));              // opaque: keeps the optimiser from folding this back into selects
+  return (is1 << j) | (is2 << (16 + j));
+}
 
 // Lane-conditional snapshot L1 <- S1, L2 <- S2 as an exec-masked block of in-place full-rate v_mov (hipcc would turn
 // plain assignments into v_cndmask, which is far slower on gfx950: profiles/r01_microbench_exec_rate.txt).
@@ -1001,8 +1011,10 @@ static __device__ __forceinline__ uint2 load_block_masks(F val, const Geom &g, i
     const int k = 2 * K * sub + 2 * t;
     const u32 v0 = k < g.N ? (val(k) & 0xFFFFu) : 0u, v1 = k + 1 < g.N ? (val(k + 1) & 0xFFFFu) : 0u;
     av[t] = v0 | (v1 << 16);
-    if (v0 == 1) mk.x |= 1u << (2 * t); else if (v0) mk.y |= 1u << (2 * t);
-    if (v1 == 1) mk.x |= 1u << (2 * t + 1); else if (v1) mk.y |= 1u << (2 * t + 1);
+    u32 a1 = v0 == 1u ? 1u : 0u, a2 = v0 > 1u ? 1u : 0u, b1 = v1 == 1u ? 1u : 0u, b2 = v1 > 1u ? 1u : 0u;
+    asm volatile("" : "+v"(a1), "+v"(a2), "+v"(b1), "+v"(b2));   // see step_bits
+    mk.x |= (a1 << (2 * t)) | (b1 << (2 * t + 1));
+    mk.y |= (a2 << (2 * t)) | (b2 << (2 * t + 1));
   }
   return mk;
 }
@@ -1212,6 +1224,122 @@ __global__ void k_add_mod(u32 mod, const u16 *__restrict__ a, const u16 *__restr
                           u16 *__restrict__ out) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
     out[idx] = (u16)(((u32)a[idx] + (u32)b[idx]) % mod);
+}
+
+
+// verifyKeysInputs on the add path: every product steps over a per-item ternary operand (f, f, g) with a per-item
+// window (fq, fp, 3*fq mod q), one item per wave.  Needs p == 3 (so that -1 = 2 mod p is the "other" symbol).
+template <int K, int ME>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys_t(
+    Geom g, u32 q, u32 p, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
+    const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
+    u16 *__restrict__ rem_fq, uint8_t *__restrict__ quot_fp, uint8_t *__restrict__ rem_fp, u16 *__restrict__ quot_h,
+    u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const LaneId L = lane_id(g);
+  const size_t raw_len = ((size_t)g.N + 1) & ~(size_t)1;
+  const size_t per_wave = (size_t)g.eo_len * 8 + (size_t)g.nl * 4 + raw_len * 2;
+  unsigned char *wbase = lds + (size_t)L.wave * per_wave;
+  uint2 *eo = (uint2 *)wbase;
+  u32 *codes = (u32 *)(wbase + (size_t)g.eo_len * 8);
+  u16 *raw = (u16 *)(wbase + (size_t)g.eo_len * 8 + (size_t)g.nl * 4);
+  for (long item = (long)blockIdx.x * WAVES_PER_BLOCK + L.wave; item < B; item += (long)gridDim.x * WAVES_PER_BLOCK) {
+    int sub = L.sub, N = g.N;
+    asm volatile("" : "+v"(sub), "+s"(N));
+    const long row = item * N;
+    u32 fl = 0;
+    // one product: window `win` (already mapped into [0, mod)), stepping operand `step` (ternary, -1 -> neg)
+    auto product = [&](auto win, const int8_t *step, u32 neg, auto split, auto emit) {
+      asm volatile("" : "+v"(sub));                      // fresh lane index: no load of this product is CSE'd with another's
+      stage_raw(raw, N, g.nl, win, sub, L.active);
+      {
+        u32 av[K];
+        const u32 word = load_block<K>(ValTernary{step + row, neg}, N, sub, av);
+        if (L.active) codes[sub] = word;
+      }
+      wave_lds_fence();
+      if (L.active) build_eo(eo, g, ValLds{raw}, sub, g.nl);
+      wave_lds_fence();
+      auto s_pair = [&](int t) -> u32 {                                   // reloaded behind the hot loop
+        int sub2 = sub;
+        asm volatile("" : "+v"(sub2));
+        const int8_t *sr = step + row;
+        const int k = 2 * K * sub2 + 2 * t;
+        const int k0 = k < N ? k : N - 1, k1 = k + 1 < N ? k + 1 : N - 1;
+        const int a0 = sr[k0], a1 = sr[k1];
+        const u32 v0 = k < N ? (a0 < 0 ? neg : (u32)a0) : 0u, v1 = k + 1 < N ? (a1 < 0 ? neg : (u32)a1) : 0u;
+        return v0 | (v1 << 16);
+      };
+      split(s_pair, emit);
+      wave_lds_fence();
+    };
+    // per-product bookkeeping shared by the two inverse checks (index.js:159,162): "length != 1 && [0] != 1"
+    bool nz_hi = false, first_not_one = false;
+    auto note_inverse = [&](int sub2, int t, u16x2 rv) {
+      const int k = 2 * K * sub2 + 2 * t;
+      nz_hi |= (k >= 1 && k < N && rv.x != 0) || (k + 1 < N && rv.y != 0);
+      if (t == 0) first_not_one = sub2 == 0 && rv.x != 1;
+    };
+    // ---- fq * f mod q
+    product(ValU16{fq + row}, f, q - 1,
+            [&](auto s_pair, auto emit) { tern_product_split<K, ME, true>(eo, codes, s_pair, g, sub, true, q, emit); },
+            [&](int t, u16x2 rv, u16x2 qv) {
+              int sub2 = sub; asm volatile("" : "+v"(sub2));
+              rv = rv & (u16)(q - 1);
+              const StorePlan sp = store_plan<K>(g, sub2, L.active);
+              const long lane0 = row + 2 * K * sub2;
+              store_pair(rem_fq + lane0, sp, t, rv);
+              store_pair(quot_fq + lane0, sp, t, qv);
+              note_inverse(sub2, t, rv);
+            });
+    if (item_any(nz_hi, g, L) && item_any(first_not_one, g, L)) fl |= NTRU_FLAG_INVALID_FQ;
+    // ---- fp * f mod p
+    nz_hi = false; first_not_one = false;
+    product(ValU8{fp + row}, f, p - 1,
+            [&](auto s_pair, auto emit) { tern_product_split<K, 0, false>(eo, codes, s_pair, g, sub, true, p, emit); },
+            [&](int t, u16x2 rv, u16x2 qv) {
+              int sub2 = sub; asm volatile("" : "+v"(sub2));
+              const StorePlan sp = store_plan<K>(g, sub2, L.active);
+              const long lane0 = row + 2 * K * sub2;
+              store_pair(rem_fp + lane0, sp, t, rv);
+              store_pair(quot_fp + lane0, sp, t, qv);
+              note_inverse(sub2, t, rv);
+            });
+    if (item_any(nz_hi, g, L) && item_any(first_not_one, g, L)) fl |= NTRU_FLAG_INVALID_FP;
+    // ---- (p*fq) * g mod q: the window is reduced mod q (same product; the unreduced p*fq of index.js:155 is host glue)
+    // 'invalid h' iff some index below h's trimmed length differs from the remainder (index.js:165): get that length first
+    int hl = 1;
+    {
+      int top = -1;
+#pragma unroll
+      for (int t = 0; t < K; t++) {
+        const int k = 2 * K * sub + 2 * t;
+        const int k0 = k < N ? k : N - 1, k1 = k + 1 < N ? k + 1 : N - 1;
+        if (k < N && h[row + k0]) top = k;
+        if (k + 1 < N && h[row + k1]) top = k + 1;
+      }
+      const unsigned long long bal = __ballot(top >= 0 && L.active);
+      const int src = bal ? 63 - __builtin_clzll(bal) : (int)L.lane;
+      const int top_src = __shfl(top, src);
+      if (bal) hl = top_src + 1;
+    }
+    bool bad = false;
+    product(ValU16x3m{fq + row, p, q - 1}, gg, q - 1,
+            [&](auto s_pair, auto emit) { tern_product_split<K, ME, true>(eo, codes, s_pair, g, sub, true, q, emit); },
+            [&](int t, u16x2 rv, u16x2 qv) {
+              int sub2 = sub; asm volatile("" : "+v"(sub2));
+              rv = rv & (u16)(q - 1);
+              const StorePlan sp = store_plan<K>(g, sub2, L.active);
+              const long lane0 = row + 2 * K * sub2;
+              store_pair(rem_h + lane0, sp, t, rv);
+              store_pair(quot_h + lane0, sp, t, qv);
+              const int k = 2 * K * sub2 + 2 * t;
+              const int k0 = k < N ? k : N - 1, k1 = k + 1 < N ? k + 1 : N - 1;
+              bad |= (k < hl && h[row + k0] != rv.x) || (k + 1 < hl && h[row + k1] != rv.y);
+            });
+    if (item_any(bad, g, L)) fl |= NTRU_FLAG_INVALID_H;
+    if (L.active && sub == 0) flags[item] = (uint8_t)fl;
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
@@ -1564,6 +1692,23 @@ extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int 
     return fail(NTRU_ERR_ARG, "ntru_verify_keys_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
+  if (const int me = p == 3 ? add_path_me(eng, N, q) : 0) {
+    L.K = pick_K(N);
+    L.g = make_geom(N, L.K);
+    const size_t raw_len = ((size_t)N + 1) & ~(size_t)1;
+    L.lds = WAVES_PER_BLOCK * ((size_t)L.g.eo_len * 8 + (size_t)L.g.nl * 4 + raw_len * 2);
+    L.grid = dim3((unsigned)((B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+    DISPATCH_K_ADD(L.K, me, {
+      if (int rc = allow_lds(k_verify_keys_t<KK, MM>, L.lds)) return rc;
+      if (int rc = resident_grid(eng, k_verify_keys_t<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+      note_kernel(eng, "k_verify_keys_t", KK, MM);
+      hipLaunchKernelGGL((k_verify_keys_t<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p,
+                         d_f, d_g, d_fq, d_fp, d_h, (long)B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h,
+                         d_flags);
+    });
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  }
   if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
   DISPATCH_K(L.K, {
     if (int rc = allow_lds(k_verify_keys<KK>, L.lds)) return rc;
