@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for rehearsing the launch path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="override the HIP device (default LOCAL_RANK)")
+    ap.add_argument("--sample-r", action="store_true",
+                    help="draw r with the engine's on-device sampler (generateCustomArray on a ChaCha20 stream) "
+                         "instead of torch; the timed region is unchanged")
     ap.add_argument("--gather", action="store_true", help="after timing, all_gather the decrypted values (RCCL)")
     return ap.parse_args()
 
@@ -156,6 +159,10 @@ def main():
     eng = pkg.Engine(dev_index)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
+    if args.sample_r:
+        key = np.arange(8, dtype=np.uint32) * 0x9E3779B1 + 20240
+        eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
+        torch.cuda.synchronize()
     eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2}[args.kernel_path])
 
     names = {}
@@ -232,7 +239,7 @@ def main():
             "config": {"workload": "N=%d q=%d p=%d d=%d, batch=2^%d round trips per GPU per step, shared golden key, "
                                    "%s outputs" % (N, q, p, d, args.batch_log2,
                                                    "full-witness" if witness else "value-only"),
-                       "mode": args.mode, "kernel_path": args.kernel_path, "seed": 20240,
+                       "mode": args.mode, "kernel_path": args.kernel_path, "seed": 20240, "r_source": "device sampler" if args.sample_r else "torch",
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "verified_bit_exact_rows": int(rows.numel()),
             "kernels_ms": {names.get("encrypt", "k_encrypt"): enc_ms, dname: dec_ms},

@@ -98,6 +98,17 @@ int ntru_add_batch(ntru_engine_t *eng, int N, int mod, const uint16_t *a, const 
 int ntru_add_batch_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B,
                        uint16_t *d_out);
 
+/* ---- on-device ternary sampler: generateCustomArray(N, n1, n2) (index.js:461-488) for B items, so that encryptBits'
+ *      randomness r never crosses PCIe.  Row b (item index first_item + b) gets n1 ones, n2 entries equal to `other`
+ *      (2 = p-1 for r after the index.js:89 map) and zeros, shuffled exactly like the reference: for i = N-1 .. 1:
+ *      j = u32 % (i+1), swap -- with the u32 of step t taken from word t of the ChaCha20 keystream (RFC 8439 block
+ *      function) under `key` (8 words) with nonce (item_lo, item_hi, 0x4e545255) and block counter 0,1,2,...
+ *      A host replays the stream with any ChaCha20 implementation.  key is a HOST pointer in both variants. */
+int ntru_sample_ternary(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key, uint64_t first_item,
+                        int64_t B, uint8_t *out);
+int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
+                            uint64_t first_item, int64_t B, uint8_t *d_out);
+
 /* ---- encryptBits (index.js:87-110) for B plaintexts under one public key.
  *      h[N] in [0,q); r[B][N] in {0,1,2} (the sampler output with -1 already mapped to p-1, index.js:89);
  *      m[B][N] plaintext coefficients (README: 0/1/2; any byte is accepted and added mod q).

@@ -1342,6 +1342,76 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys_t(
   }
 }
 
+
+// ---- on-device ternary sampler: generateCustomArray (index.js:461-488) for one item per LANE ---------------------
+// Same procedure as the reference: [1]*n1 ++ [other]*n2 ++ [0]*..., then for i = N-1 .. 1: j = u32 % (i+1), swap.
+// The u32 of step t of item b is word t of the ChaCha20 keystream (RFC 8439 block function) under the caller's key with
+// nonce (b_lo, b_hi, "NTRU"), so any host can replay it with a stock ChaCha20.  The Fisher-Yates chain
+// is inherently sequential per item, so items are spread over lanes; each lane's row lives in LDS (pitch = odd number
+// of dwords: the lock-step accesses row[i] of all lanes hit distinct banks).
+struct ChaChaKey { u32 k[8]; };
+
+#define CHACHA_QR(a, b, c, d)                                                          \
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 16); c += d; b ^= c; b = __builtin_rotateleft32(b, 12); \
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 8);  c += d; b ^= c; b = __builtin_rotateleft32(b, 7);
+
+__global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u32 other, ChaChaKey key,
+                                                       unsigned long long first_item, long B,
+                                                       uint8_t *__restrict__ out, int pitch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x;
+  const int pd = pitch >> 2;
+  for (long base = (long)blockIdx.x * 64; base < B; base += (long)gridDim.x * 64) {
+    // all 64 rows start identical: fill them cooperatively, one dword at a time
+    for (int idx = lane; idx < 64 * pd; idx += 64) {
+      const int c = (idx % pd) * 4;
+      u32 w = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int k = c + b;
+        const u32 v = k < n1 ? 1u : (k < n1 + n2 ? other : 0u);
+        w |= v << (8 * b);
+      }
+      ((u32 *)lds)[idx] = w;
+    }
+    wave_lds_fence();
+    unsigned char *row = lds + (size_t)lane * pitch;
+    const unsigned long long item = first_item + (unsigned long long)(base + lane);
+    const u32 n0 = (u32)item, nn1 = (u32)(item >> 32), nn2 = 0x4e545255u;
+    int i = N - 1;
+    for (u32 ctr = 0; i >= 1; ctr++) {                  // i is the same in every lane: uniform loop
+      u32 x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+      u32 x4 = key.k[0], x5 = key.k[1], x6 = key.k[2], x7 = key.k[3], x8 = key.k[4], x9 = key.k[5], x10 = key.k[6],
+          x11 = key.k[7], x12 = ctr, x13 = n0, x14 = nn1, x15 = nn2;
+      for (int r = 0; r < 10; r++) {
+        CHACHA_QR(x0, x4, x8, x12) CHACHA_QR(x1, x5, x9, x13) CHACHA_QR(x2, x6, x10, x14) CHACHA_QR(x3, x7, x11, x15)
+        CHACHA_QR(x0, x5, x10, x15) CHACHA_QR(x1, x6, x11, x12) CHACHA_QR(x2, x7, x8, x13) CHACHA_QR(x3, x4, x9, x14)
+      }
+      const u32 ks[16] = {x0 + 0x61707865u, x1 + 0x3320646eu, x2 + 0x79622d32u, x3 + 0x6b206574u,
+                          x4 + key.k[0], x5 + key.k[1], x6 + key.k[2], x7 + key.k[3], x8 + key.k[4], x9 + key.k[5],
+                          x10 + key.k[6], x11 + key.k[7], x12 + ctr, x13 + n0, x14 + nn1, x15 + nn2};
+#pragma unroll
+      for (int w = 0; w < 16; w++) {
+        if (i >= 1) {
+          const u32 j = ks[w] % (u32)(i + 1);
+          const unsigned char a = row[i], b = row[j];
+          row[i] = b; row[j] = a;
+          i--;
+        }
+      }
+    }
+    wave_lds_fence();
+    // rows -> row-major output, coalesced: the wave walks one row at a time
+    for (int rr = 0; rr < 64; rr++) {
+      if (base + rr >= B) break;
+      uint8_t *dst = out + (size_t)(base + rr) * N;
+      const unsigned char *src = lds + (size_t)rr * pitch;
+      for (int k = lane; k < N; k += 64) dst[k] = src[k];
+    }
+    wave_lds_fence();
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
@@ -1930,5 +2000,48 @@ extern "C" int ntru_add_batch(ntru_engine_t *eng, int N, int mod, const uint16_t
     D2H(out + o * N, dout, n * row);
     HIP_TRY(hipStreamSynchronize(eng->stream));
   }
+  return NTRU_OK;
+}
+
+static int sampler_pitch(int N) { int pd = (N + 3) / 4; if ((pd & 1) == 0) pd++; return pd * 4; }
+
+extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
+                                       uint64_t first_item, int64_t B, uint8_t *d_out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0 || N < 1 || n1 < 0 || n2 < 0) return fail(NTRU_ERR_ARG, "negative size");
+  if (n1 + n2 > N) return fail(NTRU_ERR_ARG, "The total of 1s and -1s cannot exceed the array length.");   // index.js:463
+  if (other < 0 || other > 255) return fail(NTRU_ERR_ARG, "`other` must fit a byte");
+  if (!key) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: key is NULL");
+  if (B == 0) return NTRU_OK;
+  if (!d_out) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: NULL buffer");
+  const int pitch = sampler_pitch(N);
+  const size_t lds = (size_t)64 * pitch;
+  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the sampler's LDS rows");
+  HIP_TRY(hipSetDevice(eng->device));
+  ChaChaKey ck;
+  memcpy(ck.k, key, 32);
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_sample_ternary, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_ternary, 64, lds));
+  long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
+  if (blocks > cap) blocks = cap;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_sample_ternary");
+  hipLaunchKernelGGL(k_sample_ternary, dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, n1, n2, (u32)other, ck,
+                     (unsigned long long)first_item, (long)B, d_out, pitch);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_sample_ternary(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
+                                   uint64_t first_item, int64_t B, uint8_t *out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B > 0 && !out) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: NULL buffer");
+  if (B <= 0) return ntru_sample_ternary_dev(eng, N, n1, n2, other, key, first_item, B, nullptr);
+  HIP_TRY(hipSetDevice(eng->device));
+  DevBuf d;
+  if (d.alloc((size_t)B * N)) return NTRU_ERR_HIP;
+  if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, other, key, first_item, B, (uint8_t *)d.p)) return rc;
+  D2H(out, d, (size_t)B * N);
+  HIP_TRY(hipStreamSynchronize(eng->stream));
   return NTRU_OK;
 }

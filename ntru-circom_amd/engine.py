@@ -33,6 +33,8 @@ _SIGS = {
     "ntru_last_error": (C.c_char_p, []),
     "ntru_engine_supports": (C.c_int, [_i, _i]),
 }
+_SIGS["ntru_sample_ternary"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
+_SIGS["ntru_sample_ternary_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 for _sfx in ("", "_dev"):
     _SIGS["ntru_polymul_split" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _i64, _vp, _vp])
     _SIGS["ntru_split_by_I" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i64, _vp, _vp])
@@ -149,6 +151,18 @@ class Engine:
         out = np.empty((B, N), np.uint16)
         self._chk(self._lib.ntru_add_batch(self._h, N, mod, _ptr(a), _ptr(b), B, _ptr(out)))
         return out
+
+    def sample_ternary(self, N, n1, n2, other, key, first_item, B):
+        """generateCustomArray on the device (ChaCha20 draw stream under `key`, 8 uint32)."""
+        key = _np(key, np.uint32, (8,))
+        out = np.empty((B, N), np.uint8)
+        self._chk(self._lib.ntru_sample_ternary(self._h, N, n1, n2, other, _ptr(key), int(first_item), B, _ptr(out)))
+        return out
+
+    def sample_ternary_dev(self, N, n1, n2, other, key, first_item, B, d_out):
+        key = _np(key, np.uint32, (8,))
+        self._chk(self._lib.ntru_sample_ternary_dev(self._h, N, n1, n2, other, _ptr(key), int(first_item), B,
+                                                    self._dp(d_out)))
 
     def encrypt_batch(self, N, q, h, r, m, want_quot=True):
         h = _np(h, np.uint16, (N,))

@@ -400,3 +400,49 @@ int orc_verify_keys_batch(int N, int q, int p, const int8_t *f, const int8_t *g,
   free(qo); work_free(&w);
   return rc;
 }
+
+/* ---- replayable draw stream for the on-device sampler ---------------------------------------
+ * The reference draws one u32 per Fisher-Yates step from crypto.getRandomValues (index.js:481-483).  The engine's
+ * sampler replaces that CSPRNG by the ChaCha20 keystream (RFC 8439 block function) of a caller-supplied 256-bit key:
+ * item b uses nonce = (b_lo, b_hi, 0x4e545255 "NTRU") and block counter 0,1,2,...; draw t of item b is keystream word
+ * t (little-endian).  Everything else is generateCustomArray verbatim (orc_generate_custom_array above). */
+static inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+#define QR(a, b, c, d) \
+  a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); \
+  a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7);
+
+void orc_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]) {
+  uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                    key[4], key[5], key[6], key[7], counter, nonce[0], nonce[1], nonce[2]};
+  uint32_t x[16];
+  for (int i = 0; i < 16; i++) x[i] = s[i];
+  for (int r = 0; r < 10; r++) {
+    QR(x[0], x[4], x[8], x[12]) QR(x[1], x[5], x[9], x[13]) QR(x[2], x[6], x[10], x[14]) QR(x[3], x[7], x[11], x[15])
+    QR(x[0], x[5], x[10], x[15]) QR(x[1], x[6], x[11], x[12]) QR(x[2], x[7], x[8], x[13]) QR(x[3], x[4], x[9], x[14])
+  }
+  for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+
+/* draws[t], t = 0..n-1, of item `item` */
+void orc_draw_stream(const uint32_t key[8], uint64_t item, int n, uint32_t *draws) {
+  uint32_t nonce[3] = {(uint32_t)item, (uint32_t)(item >> 32), 0x4e545255u}, blk[16];
+  for (int t = 0; t < n; t++) {
+    if ((t & 15) == 0) orc_chacha20_block(key, (uint32_t)(t >> 4), nonce, blk);
+    draws[t] = blk[t & 15];
+  }
+}
+
+/* r rows for items first_item .. first_item+B-1: n1 ones, n2 entries equal to `other`, zeros; stride N. */
+int orc_sample_ternary_batch(int N, int n1, int n2, int other, const uint32_t key[8], uint64_t first_item, int64_t B,
+                             uint8_t *out) {
+  if (n1 + n2 > N) return ORC_ERR_SAMPLER;
+  uint32_t *draws = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(N > 1 ? N - 1 : 1));
+  int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+  for (int64_t b = 0; b < B; b++) {
+    orc_draw_stream(key, first_item + (uint64_t)b, N - 1, draws);
+    orc_generate_custom_array(N, n1, n2, draws, tmp);
+    for (int k = 0; k < N; k++) out[b * N + k] = (uint8_t)(tmp[k] == -1 ? other : tmp[k]);
+  }
+  free(draws); free(tmp);
+  return ORC_OK;
+}

@@ -219,6 +219,28 @@ def verify_keys_batch(N, q, p, f, g, fq, fp, h, mode=EXACT):
     return out
 
 
+def chacha20_block(key, counter, nonce):
+    key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32)); nonce = np.ascontiguousarray(np.asarray(nonce, dtype=np.uint32))
+    out = np.zeros(16, np.uint32)
+    lib().orc_chacha20_block(_p(key), C.c_uint32(counter), _p(nonce), _p(out))
+    return out
+
+
+def draw_stream(key, item, n):
+    key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32))
+    out = np.zeros(max(n, 1), np.uint32)
+    lib().orc_draw_stream(_p(key), C.c_uint64(item), C.c_int(n), _p(out))
+    return out[:n]
+
+
+def sample_ternary_batch(N, n1, n2, other, key, first_item, B):
+    key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32))
+    out = np.zeros((B, N), np.uint8)
+    _check(lib().orc_sample_ternary_batch(C.c_int(N), C.c_int(n1), C.c_int(n2), C.c_int(other), _p(key),
+                                          C.c_uint64(first_item), C.c_int64(B), _p(out)))
+    return out
+
+
 # ---- scheme-level restatement ----------------------------------------------------------------
 
 class OracleNTRU:

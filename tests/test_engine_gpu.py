@@ -250,6 +250,36 @@ def test_split_and_add_kernels(eng):
         assert np.array_equal(eng.add_batch(N, mod, x, y), (x + y) % mod)
 
 
+@pytest.mark.parametrize("N,n1,n2", [(821, 273, 273), (701, 233, 233), (509, 169, 169), (167, 18, 18), (17, 2, 2),
+                                     (17, 17, 0), (5, 0, 0), (2, 1, 1), (1000, 1, 998)])
+def test_device_sampler_equals_oracle(eng, N, n1, n2):
+    """generateCustomArray on the device: same Fisher-Yates procedure on the same (ChaCha20) draw stream."""
+    key = (np.arange(8, dtype=np.uint64) * 0x9E3779B9 + 12345).astype(np.uint32)
+    for first, B in ((0, 1), (7, 64), (2 ** 33 + 5, 65), (123456, 200)):
+        got = eng.sample_ternary(N, n1, n2, 2, key, first, B)
+        want = orc.sample_ternary_batch(N, n1, n2, 2, key, first, B)
+        assert np.array_equal(got, want), (first, B)
+        assert ((got == 1).sum(axis=1) == n1).all() and ((got == 2).sum(axis=1) == n2).all()
+    with pytest.raises(pkg.EngineError, match="cannot exceed the array length"):
+        eng.sample_ternary(4, 3, 2, 2, key, 0, 1)
+
+
+def test_sampled_encrypt_matches_reference_semantics(eng, scheme_golden):
+    """sample r on the device, encrypt, and replay on the CPU: r from the oracle's sampler on the same stream, then the
+    oracle's encryptBits -- the witness must match bit for bit."""
+    opts = scheme_golden["options"]
+    N, q, d = opts["N"], opts["q"], opts["dr"]
+    key = np.array([1, 2, 3, 4, 5, 6, 7, 8], np.uint32) * 0x01000193
+    h = np.array(list(scheme_golden["keys"][0]["h"]) + [0] * (N - len(scheme_golden["keys"][0]["h"])))
+    B = 33
+    m = np.random.default_rng(N).integers(0, 2, (B, N))
+    r = eng.sample_ternary(N, d, d, 2, key, 1000, B)
+    e, quot = eng.encrypt_batch(N, q, h, r, m)
+    r_o = orc.sample_ternary_batch(N, d, d, 2, key, 1000, B)
+    e_o, quot_o = orc.encrypt_batch(N, q, h, r_o, m)
+    assert np.array_equal(r, r_o) and np.array_equal(e, e_o) and np.array_equal(quot, quot_o)
+
+
 # ---- error behaviour ------------------------------------------------------------------------------------------
 
 def test_error_behaviour(eng):

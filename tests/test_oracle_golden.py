@@ -152,3 +152,26 @@ def test_verify_flags_detect_bad_keys(scheme_golden):
     assert out["flags"][0] & 4                           # ... and a wrong fq also breaks h = p*fq*g
     assert int(out["flags"][1]) & 0xFD == 0
     assert out["flags"][2] == 4
+
+
+def test_chacha20_block_rfc8439_vector():
+    # RFC 8439 section 2.3.2: key 00..1f, counter 1, nonce 00:00:00:09 00:00:00:4a 00:00:00:00
+    key = np.frombuffer(bytes(range(32)), dtype="<u4")
+    nonce = np.array([0x09000000, 0x4a000000, 0x00000000], np.uint32)
+    out = orc.chacha20_block(key, 1, nonce)
+    want = [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+            0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    assert out.tolist() == want
+
+
+def test_sampler_stream_and_procedure(pure_golden):
+    key = np.arange(8, dtype=np.uint32) * 0x01010101
+    d = orc.draw_stream(key, 5, 40)
+    blk0 = orc.chacha20_block(key, 0, [5, 0, 0x4e545255]); blk2 = orc.chacha20_block(key, 2, [5, 0, 0x4e545255])
+    assert d[:16].tolist() == blk0.tolist() and d[32:40].tolist() == blk2[:8].tolist()
+    r = orc.sample_ternary_batch(167, 18, 18, 2, key, 3, 4)
+    for b in range(4):
+        ref = orc.generate_custom_array(167, 18, 18, orc.draw_stream(key, 3 + b, 166))
+        assert r[b].tolist() == [2 if x == -1 else x for x in ref]
+        assert (r[b] == 1).sum() == 18 and (r[b] == 2).sum() == 18
+    assert len({r[b].tobytes() for b in range(4)}) == 4

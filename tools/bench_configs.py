@@ -66,7 +66,18 @@ def verify_config(profile, logB):
             "kernel": eng.last_kernel(), "ms": ms, "keys_per_s": B / (ms * 1e-3), "hbm_GBps": 17 * N * B / (ms * 1e-3) / 1e9}
 
 
+def sampler_config(profile, logB):
+    o, _, _, _ = bench.load_key(profile)
+    N, d, p = o["N"], o["dr"], o["p"]
+    B = 1 << logB
+    r = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    key = np.arange(8, dtype=np.uint32) + 1
+    ms = timed(lambda: eng.sample_ternary_dev(N, d, d, p - 1, key, 0, B, r.data_ptr()))
+    return {"config": "N=%d d=%d batch=2^%d on-device generateCustomArray (ChaCha20 draws), 1 GPU" % (N, d, logB),
+            "kernel": eng.last_kernel(), "ms": ms, "samples_per_s": B / (ms * 1e-3), "hbm_GBps": N * B / (ms * 1e-3) / 1e9}
+
+
 if __name__ == "__main__":
     for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
-                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18)):
+                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), sampler_config("n821_q4096", 20)):
         print(json.dumps(res), flush=True)
