@@ -180,6 +180,20 @@ static napi_value VerifyKeysBatch(napi_env env, napi_callback_info info) {
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
+/* sampleTernary(N, n1, n2, other, key:Uint32Array[8], firstItem:Number, B, out:Uint8Array[B*N]) */
+static napi_value SampleTernary(napi_env env, napi_callback_info info) {
+  ARGS(8)
+  int32_t N, n1, n2, other, B; double first; void *key, *out;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &n1) || !get_i32(env, argv[2], &n2) ||
+      !get_i32(env, argv[3], &other) || napi_get_value_double(env, argv[5], &first) != napi_ok ||
+      !get_i32(env, argv[6], &B) || N < 1 || B < 0 || first < 0 || first > 9007199254740991.0) BAD_ARGS();
+  if (!get_buf(env, argv[4], napi_uint32_array, 8, 0, &key) ||
+      !get_buf(env, argv[7], napi_uint8_array, (size_t)N * (size_t)B, 0, &out)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_sample_ternary(g_engine, N, n1, n2, other, key, (uint64_t)first, B, out);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
     {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
@@ -192,6 +206,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"encryptBatch", NULL, EncryptBatch, NULL, NULL, NULL, napi_default, NULL},
     {"decryptBatch", NULL, DecryptBatch, NULL, NULL, NULL, napi_default, NULL},
     {"verifyKeysBatch", NULL, VerifyKeysBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"sampleTernary", NULL, SampleTernary, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof props / sizeof props[0], props) != napi_ok) return NULL;
   return exports;

@@ -233,6 +233,14 @@ export default class NTRU {
     return { e, quotientE: quot };
   }
 
+  // r for B encryptions drawn on the GPU: generateCustomArray(N, dr, dr) with -1 -> p-1 (index.js:89) on the ChaCha20
+  // stream of `key` (Uint32Array[8]) for item indices firstItem .. firstItem+B-1; replayable on any host.
+  sampleR(key, firstItem, B) {
+    const r = new Uint8Array(B * this.N);
+    engine().sampleTernary(this.N, this.dr, this.dr, this.p - 1, key, firstItem, B, r);
+    return r;
+  }
+
   // e: Uint16Array[B*N] -> { value, quotient1, remainder1, quotient2 }
   decryptBatch(e, B, wantWitness = true) {
     const { N, p, q } = this;

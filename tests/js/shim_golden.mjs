@@ -125,4 +125,23 @@ deepStrictEqual(lib.stringToBits('Hello World'), pure.misc.stringToBits[0].out);
   });
 }
 
+// on-device sampler: right weights, deterministic per (key, item), different per item; feeds the batch encrypt
+{
+  const g = golden('scheme_n167_q128.json'); const key = g.keys[0]; const N = g.options.N;
+  const ntru = new NTRU({ ...g.options, f: key.f, fp: key.fp, h: key.h });
+  const k = Uint32Array.from([1, 2, 3, 4, 5, 6, 7, 8]);
+  const r1 = ntru.sampleR(k, 10, 3), r2 = ntru.sampleR(k, 10, 3), r3 = ntru.sampleR(k, 11, 2);
+  deepStrictEqual(Array.from(r1), Array.from(r2));
+  deepStrictEqual(Array.from(r1.subarray(N, 3 * N)), Array.from(r3));
+  for (let b = 0; b < 3; b++) {
+    const row = Array.from(r1.subarray(b * N, (b + 1) * N));
+    strictEqual(row.filter(x => x === 1).length, g.options.dr);
+    strictEqual(row.filter(x => x === 2).length, g.options.dr);
+  }
+  const m = new Uint8Array(3 * N).fill(1);
+  const enc = ntru.encryptBatch(r1, m, 3);
+  const dec = ntru.decryptBatch(enc.e, 3);
+  deepStrictEqual(Array.from(dec.value), Array.from(m));       // q = 128 = 2 mod 3: round trip holds
+}
+
 console.log(`shim_golden: ${checks} scheme checks, ${nMul} multiply and ${nDiv} divide vectors OK`);
