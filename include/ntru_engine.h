@@ -142,6 +142,20 @@ int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int p, const in
                                uint16_t *d_quot_fq, uint16_t *d_rem_fq, uint8_t *d_quot_fp, uint8_t *d_rem_fp,
                                uint16_t *d_quot_h, uint16_t *d_rem_h, uint8_t *d_flags);
 
+/* ---- BN254 field-element packing: packOutput / unpackInput (index.js:572-620), the wire format of the circuits'
+ *      CombineArray / UnpackArray (circuits/ntru.circom:258-306).  bits = floor(log2(max_val)+1) per value,
+ *      per_output = floor(252/bits) values per field element, arr_len / output_size as index.js:575-580.
+ *      A field element is four little-endian uint64 limbs.  1 <= max_val <= 65535.
+ *      pack:   data [B][data_len] -> out [B][output_size][4];   out[b][o] = sum_j data[b][o*per+j] << (j*bits)
+ *      unpack: in [B][packed_size][4] -> out [B][packed_size*per], per = floor(packed_bits/bits) (trimming is host glue) */
+int ntru_pack_params(int max_val, int data_len, int *bits, int *per_output, int *arr_len, int *output_size);
+int ntru_pack_batch(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *data, int64_t B, uint64_t *out);
+int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *d_data, int64_t B, uint64_t *d_out);
+int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *in, int packed_size, int64_t B,
+                      uint16_t *out);
+int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *d_in, int packed_size,
+                          int64_t B, uint16_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

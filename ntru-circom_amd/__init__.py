@@ -13,4 +13,4 @@ raises `EngineError` when it (or a GPU) is missing.
 from .engine import Engine, EngineError, library_path, load_library  # noqa: F401
 from . import sharding  # noqa: F401
 from .ntru import (NTRU, addCiphertexts, addPolynomials, degree, dividePolynomials, expandArray, generateCustomArray,  # noqa: F401
-                   multiplyPolynomials, stringToBits, bitsToString, trimPolynomial)
+                   multiplyPolynomials, packOutput, unpackInput, stringToBits, bitsToString, trimPolynomial)

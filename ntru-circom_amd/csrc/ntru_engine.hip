@@ -1412,6 +1412,46 @@ __global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u3
   }
 }
 
+
+// ---- BN254 field-element packing (index.js:572-620): elementwise, HBM-bound ---------------------------------------
+// One thread per 64-bit limb of the output: out[b][o] = sum_j data[b][o*per + j] << (j*bits), four LE limbs per element.
+__global__ void k_pack(int bits, int per, int data_len, int out_size, const u16 *__restrict__ data, long B,
+                       unsigned long long *__restrict__ out) {
+  const long total = B * out_size * 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(idx & 3);
+    const long eo = idx >> 2;
+    const long b = eo / out_size;
+    const int o = (int)(eo - b * out_size);
+    const int lo_bit = 64 * l;
+    int j0 = lo_bit / bits, j1 = (lo_bit + 63) / bits;
+    if (j1 >= per) j1 = per - 1;
+    unsigned long long limb = 0;
+    for (int j = j0; j <= j1; j++) {
+      const int i = o * per + j;
+      const unsigned long long v = i < data_len ? data[b * data_len + i] : 0ull;
+      const int sh = j * bits - lo_bit;
+      limb |= sh >= 0 ? v << sh : v >> (-sh);
+    }
+    out[idx] = limb;
+  }
+}
+
+// unpackInput before trimming: out[b][i*per + j] = (in[b][i] >> (j*bits)) & mask.
+__global__ void k_unpack(int bits, int per, int packed_size, const unsigned long long *__restrict__ in, long B,
+                         u16 *__restrict__ out) {
+  const long total = B * packed_size * per;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long e = idx / per;
+    const int j = (int)(idx - e * per);
+    const unsigned long long *l = in + e * 4;
+    const int pos = j * bits, w = pos >> 6, sft = pos & 63;
+    unsigned long long v = l[w] >> sft;
+    if (sft + bits > 64 && w + 1 < 4) v |= l[w + 1] << (64 - sft);
+    out[idx] = (u16)(v & ((1u << bits) - 1u));
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
@@ -2042,6 +2082,91 @@ extern "C" int ntru_sample_ternary(ntru_engine_t *eng, int N, int n1, int n2, in
   if (d.alloc((size_t)B * N)) return NTRU_ERR_HIP;
   if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, other, key, first_item, B, (uint8_t *)d.p)) return rc;
   D2H(out, d, (size_t)B * N);
+  HIP_TRY(hipStreamSynchronize(eng->stream));
+  return NTRU_OK;
+}
+
+extern "C" int ntru_pack_params(int max_val, int data_len, int *bits, int *per_output, int *arr_len, int *output_size) {
+  if (max_val < 1 || max_val > 65535 || data_len < 0 || !bits || !per_output || !arr_len || !output_size)
+    return fail(NTRU_ERR_ARG, "ntru_pack_params: need 1 <= max_val <= 65535, data_len >= 0 and non-NULL outputs");
+  int b = 0;
+  while ((max_val >> b) != 0) b++;                    // floor(log2(maxVal) + 1), index.js:573
+  const int n = 252 / b;                              // index.js:574
+  int al = ((data_len + n - 1) / n) * n;              // index.js:575-578
+  if (al < 3 * n) al = 3 * n;
+  int os = (al + n - 1) / n;                          // index.js:580
+  if (os < 3) os = 3;
+  *bits = b; *per_output = n; *arr_len = al; *output_size = os;
+  return NTRU_OK;
+}
+
+extern "C" int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *d_data, int64_t B,
+                                   uint64_t *d_out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  int bits, per, al, os;
+  if (int rc = ntru_pack_params(max_val, data_len, &bits, &per, &al, &os)) return rc;
+  if (B == 0) return NTRU_OK;
+  if ((!d_data && data_len) || !d_out) return fail(NTRU_ERR_ARG, "ntru_pack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_pack, elementwise_grid(eng, B * os * 4), dim3(256), 0, eng->stream, bits, per, data_len, os, d_data,
+                     (long)B, (unsigned long long *)d_out);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *d_in,
+                                     int packed_size, int64_t B, uint16_t *d_out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0 || packed_size < 0) return fail(NTRU_ERR_ARG, "negative size");
+  if (max_val < 1 || max_val > 65535) return fail(NTRU_ERR_ARG, "need 1 <= max_val <= 65535");
+  int bits = 0;
+  while ((max_val >> bits) != 0) bits++;
+  const int per = packed_bits / bits;
+  if (per < 1 || per * bits > 256) return fail(NTRU_ERR_ARG, "packed_bits does not hold a whole number of values within 256 bits");
+  if (B == 0 || packed_size == 0) return NTRU_OK;
+  if (!d_in || !d_out) return fail(NTRU_ERR_ARG, "ntru_unpack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_unpack, elementwise_grid(eng, B * packed_size * per), dim3(256), 0, eng->stream, bits, per,
+                     packed_size, (const unsigned long long *)d_in, (long)B, d_out);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_pack_batch(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *data, int64_t B,
+                               uint64_t *out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  int bits, per, al, os;
+  if (int rc = ntru_pack_params(max_val, data_len, &bits, &per, &al, &os)) return rc;
+  if (B <= 0) return B == 0 ? NTRU_OK : fail(NTRU_ERR_ARG, "negative batch size");
+  if ((!data && data_len) || !out) return fail(NTRU_ERR_ARG, "ntru_pack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  DevBuf din, dout;
+  if (din.alloc((size_t)B * data_len * 2) || dout.alloc((size_t)B * os * 32)) return NTRU_ERR_HIP;
+  if (data_len) H2D(din, data, (size_t)B * data_len * 2);
+  if (int rc = ntru_pack_batch_dev(eng, max_val, data_len, (const uint16_t *)din.p, B, (uint64_t *)dout.p)) return rc;
+  D2H(out, dout, (size_t)B * os * 32);
+  HIP_TRY(hipStreamSynchronize(eng->stream));
+  return NTRU_OK;
+}
+
+extern "C" int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *in, int packed_size,
+                                 int64_t B, uint16_t *out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0 || packed_size < 0) return fail(NTRU_ERR_ARG, "negative size");
+  if (max_val < 1 || max_val > 65535) return fail(NTRU_ERR_ARG, "need 1 <= max_val <= 65535");
+  int bits = 0;
+  while ((max_val >> bits) != 0) bits++;
+  const int per = packed_bits / bits;
+  if (per < 1 || per * bits > 256) return fail(NTRU_ERR_ARG, "packed_bits does not hold a whole number of values within 256 bits");
+  if (B == 0 || packed_size == 0) return NTRU_OK;
+  if (!in || !out) return fail(NTRU_ERR_ARG, "ntru_unpack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  DevBuf din, dout;
+  if (din.alloc((size_t)B * packed_size * 32) || dout.alloc((size_t)B * packed_size * per * 2)) return NTRU_ERR_HIP;
+  H2D(din, in, (size_t)B * packed_size * 32);
+  if (int rc = ntru_unpack_batch_dev(eng, max_val, packed_bits, (const uint64_t *)din.p, packed_size, B, (uint16_t *)dout.p)) return rc;
+  D2H(out, dout, (size_t)B * packed_size * per * 2);
   HIP_TRY(hipStreamSynchronize(eng->stream));
   return NTRU_OK;
 }

@@ -35,6 +35,11 @@ _SIGS = {
 }
 _SIGS["ntru_sample_ternary"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _SIGS["ntru_sample_ternary_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
+_ip = C.POINTER(C.c_int)
+_SIGS["ntru_pack_params"] = (C.c_int, [_i, _i, _ip, _ip, _ip, _ip])
+for _sfx in ("", "_dev"):
+    _SIGS["ntru_pack_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i64, _vp])
+    _SIGS["ntru_unpack_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i, _i64, _vp])
 for _sfx in ("", "_dev"):
     _SIGS["ntru_polymul_split" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _i64, _vp, _vp])
     _SIGS["ntru_split_by_I" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i64, _vp, _vp])
@@ -150,6 +155,28 @@ class Engine:
         B = a.shape[0]
         out = np.empty((B, N), np.uint16)
         self._chk(self._lib.ntru_add_batch(self._h, N, mod, _ptr(a), _ptr(b), B, _ptr(out)))
+        return out
+
+    def pack_params(self, max_val, data_len):
+        v = [C.c_int(0) for _ in range(4)]
+        self._chk(self._lib.ntru_pack_params(int(max_val), int(data_len), *[C.byref(x) for x in v]))
+        return dict(zip(("maxInputBits", "numInputsPerOutput", "arrLen", "outputSize"), (x.value for x in v)))
+
+    def pack_batch(self, max_val, data_len, data):
+        """[B][data_len] values -> [B][outputSize][4] little-endian uint64 limbs (index.js:572-596)."""
+        data = _np(data, np.uint16).reshape(-1, data_len) if data_len else np.zeros((len(data), 0), np.uint16)
+        B = data.shape[0]
+        out = np.empty((B, self.pack_params(max_val, data_len)["outputSize"], 4), np.uint64)
+        self._chk(self._lib.ntru_pack_batch(self._h, max_val, data_len, _ptr(data), B, _ptr(out)))
+        return out
+
+    def unpack_batch(self, max_val, packed_bits, limbs):
+        """[B][packedSize][4] limbs -> [B][packedSize * per] values (index.js:598-620, untrimmed)."""
+        limbs = _np(limbs, np.uint64)
+        B, S = limbs.shape[0], limbs.shape[1]
+        per = packed_bits // self.pack_params(max_val, 0)["maxInputBits"]
+        out = np.empty((B, S * per), np.uint16)
+        self._chk(self._lib.ntru_unpack_batch(self._h, max_val, packed_bits, _ptr(limbs), S, B, _ptr(out)))
         return out
 
     def sample_ternary(self, N, n1, n2, other, key, first_item, B):

@@ -136,6 +136,27 @@ def addCiphertexts(e1, e2, q, engine=None):
     return trimPolynomial(out[0].tolist())
 
 
+def packOutput(maxVal, dataLen, data, engine=None):
+    """index.js:572-596: same dict as the reference; `expected` is a list of Python ints (the reference's BigInts)."""
+    eng = engine or default_engine()
+    pr = eng.pack_params(maxVal, dataLen)
+    limbs = eng.pack_batch(maxVal, dataLen, [expandArray(data, dataLen)])[0]
+    expected = [sum(int(w) << (64 * k) for k, w in enumerate(row)) for row in limbs]
+    return {"maxInputBits": pr["maxInputBits"], "maxOutputBits": pr["numInputsPerOutput"] * pr["maxInputBits"],
+            "outputSize": pr["outputSize"], "arrLen": pr["arrLen"], "expected": expected}
+
+
+def unpackInput(maxVal, packedBits, data, engine=None):
+    """index.js:598-620 (`data`: list of ints below 2^256)."""
+    eng = engine or default_engine()
+    bits = eng.pack_params(maxVal, 0)["maxInputBits"]
+    per = packedBits // bits
+    limbs = np.array([[(int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for v in data], dtype=np.uint64)
+    un = eng.unpack_batch(maxVal, packedBits, limbs[None])[0].tolist() if len(data) else []
+    return {"maxInputBits": bits, "packedBits": packedBits, "packedSize": len(data), "unpackedSize": per * len(data),
+            "unpacked": trimPolynomial(un)}
+
+
 # ---- the scheme class --------------------------------------------------------------------------------------
 
 class NTRU:

@@ -446,3 +446,56 @@ int orc_sample_ternary_batch(int N, int n1, int n2, int other, const uint32_t ke
   free(draws); free(tmp);
   return ORC_OK;
 }
+
+/* ---- BN254 field-element packing, index.js:572-620 -------------------------------------------
+ * A packed field element is stored as four little-endian uint64 limbs (values stay below 2^252). */
+int orc_pack_params(int max_val, int data_len, int *bits, int *per, int *arr_len, int *out_size) {
+  if (max_val < 1 || max_val > 65535 || data_len < 0) return ORC_ERR_ARG;
+  int b = 0;
+  while ((max_val >> b) != 0) b++;                   /* floor(log2(maxVal) + 1), index.js:573 */
+  int n = 252 / b;                                   /* :574 */
+  int al = ((data_len + n - 1) / n) * n;             /* :575-578 */
+  if (al < 3 * n) al = 3 * n;
+  int os = (al + n - 1) / n;                         /* :580 */
+  if (os < 3) os = 3;
+  *bits = b; *per = n; *arr_len = al; *out_size = os;
+  return ORC_OK;
+}
+
+static void limb_or(uint64_t *limbs, int bitpos, uint64_t v) {
+  int l = bitpos >> 6, s = bitpos & 63;
+  limbs[l] |= v << s;
+  if (s && l + 1 < 4) limbs[l + 1] |= v >> (64 - s);
+}
+
+/* index.js:581-587.  data: [B][data_len]; out: [B][out_size][4]. */
+int orc_pack_batch(int max_val, int data_len, const uint16_t *data, int64_t B, uint64_t *out) {
+  int bits, per, al, os;
+  int rc = orc_pack_params(max_val, data_len, &bits, &per, &al, &os);
+  if (rc) return rc;
+  memset(out, 0, sizeof(uint64_t) * 4 * (size_t)os * (size_t)B);
+  for (int64_t b = 0; b < B; b++)
+    for (int i = 0; i < data_len; i++)
+      limb_or(out + ((size_t)b * os + i / per) * 4, (i % per) * bits, data[b * data_len + i]);
+  return ORC_OK;
+}
+
+/* index.js:598-620 before trimming.  in: [B][packed_size][4]; out: [B][per * packed_size]. */
+int orc_unpack_batch(int max_val, int packed_bits, const uint64_t *in, int packed_size, int64_t B, uint16_t *out) {
+  if (max_val < 1 || max_val > 65535) return ORC_ERR_ARG;
+  int bits = 0;
+  while ((max_val >> bits) != 0) bits++;
+  int per = packed_bits / bits;
+  if (per < 1 || per * bits > 256) return ORC_ERR_ARG;
+  for (int64_t b = 0; b < B; b++)
+    for (int i = 0; i < packed_size; i++) {
+      const uint64_t *l = in + ((size_t)b * packed_size + i) * 4;
+      for (int j = 0; j < per; j++) {
+        int pos = j * bits, w = pos >> 6, s = pos & 63;
+        uint64_t v = l[w] >> s;
+        if (s + bits > 64 && w + 1 < 4) v |= l[w + 1] << (64 - s);
+        out[((size_t)b * packed_size + i) * per + j] = (uint16_t)(v & ((1u << bits) - 1));
+      }
+    }
+  return ORC_OK;
+}

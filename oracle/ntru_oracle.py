@@ -241,6 +241,45 @@ def sample_ternary_batch(N, n1, n2, other, key, first_item, B):
     return out
 
 
+def pack_params(max_val, data_len):
+    v = [C.c_int(0) for _ in range(4)]
+    _check(lib().orc_pack_params(C.c_int(max_val), C.c_int(data_len), *[C.byref(x) for x in v]))
+    return dict(zip(("maxInputBits", "numInputsPerOutput", "arrLen", "outputSize"), (x.value for x in v)))
+
+
+def limbs_to_ints(limbs):
+    """[..., 4] little-endian uint64 limbs -> Python ints."""
+    limbs = np.asarray(limbs, dtype=np.uint64).reshape(-1, 4)
+    return [sum(int(w) << (64 * k) for k, w in enumerate(row)) for row in limbs]
+
+
+def ints_to_limbs(vals):
+    out = np.zeros((len(vals), 4), np.uint64)
+    for i, v in enumerate(vals):
+        for k in range(4):
+            out[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def pack_batch(max_val, data_len, data):
+    data = _c(data, np.uint16).reshape(-1, data_len) if data_len else np.zeros((len(data), 0), np.uint16)
+    B = data.shape[0]
+    pr = pack_params(max_val, data_len)
+    out = np.zeros((B, pr["outputSize"], 4), np.uint64)
+    _check(lib().orc_pack_batch(C.c_int(max_val), C.c_int(data_len), _p(data), C.c_int64(B), _p(out)))
+    return out
+
+
+def unpack_batch(max_val, packed_bits, limbs):
+    limbs = np.ascontiguousarray(np.asarray(limbs, dtype=np.uint64))
+    B, S = limbs.shape[0], limbs.shape[1]
+    bits = pack_params(max_val, 0)["maxInputBits"]
+    per = packed_bits // bits
+    out = np.zeros((B, S * per), np.uint16)
+    _check(lib().orc_unpack_batch(C.c_int(max_val), C.c_int(packed_bits), _p(limbs), C.c_int(S), C.c_int64(B), _p(out)))
+    return out
+
+
 # ---- scheme-level restatement ----------------------------------------------------------------
 
 class OracleNTRU:

@@ -164,6 +164,25 @@ function main(ref) {
   });
   dump('pure_functions.json', pure);
 
+  // ---- field-element packing (index.js:572-620; circuits CombineArray/UnpackArray, test/circuits.test.js:20-58) ----
+  {
+    const hex = v => v.toString(16);
+    const pack = { packOutput: [], unpackInput: [] };
+    reseed(0xBACC);
+    for (const [maxVal, dataLen] of [[8192, 701], [8192, 17], [4096, 821], [2048, 509], [128, 167], [3, 821], [3, 17],
+      [2, 5], [8191, 40], [65535, 33], [1, 7], [4096, 1], [4095, 63]]) {
+      const data = randInts(dataLen, Math.min(maxVal + 1, 65536));
+      const out = ref.packOutput(maxVal, dataLen, data);
+      pack.packOutput.push({ maxVal, dataLen, data, maxInputBits: out.maxInputBits, maxOutputBits: out.maxOutputBits,
+        outputSize: out.outputSize, arrLen: out.arrLen, expected: out.expected.map(hex) });
+      const un = ref.unpackInput(maxVal, out.maxOutputBits, out.expected);
+      pack.unpackInput.push({ maxVal, packedBits: out.maxOutputBits, data: out.expected.map(hex),
+        maxInputBits: un.maxInputBits, packedSize: un.packedSize, unpackedSize: un.unpackedSize, unpacked: un.unpacked });
+    }
+    // the literal case of test/circuits.test.js:20-58: max 8192, N = 701
+    dump('pack_functions.json', pack);
+  }
+
   // ---- scheme-level vectors -------------------------------------------------
   const profiles = [
     { name: 'n17_q32', opt: { N: 17, q: 32, df: 3, dg: 2, dr: 2 }, keys: 3, seed: 0x1701 },

@@ -280,6 +280,28 @@ def test_sampled_encrypt_matches_reference_semantics(eng, scheme_golden):
     assert np.array_equal(r, r_o) and np.array_equal(e, e_o) and np.array_equal(quot, quot_o)
 
 
+def test_field_packing_equals_reference_and_oracle(eng):
+    from conftest import load_golden
+    g = load_golden("pack_functions.json")
+    for v in g["packOutput"]:
+        got = pkg.packOutput(v["maxVal"], v["dataLen"], v["data"], engine=eng)
+        want = {k: v[k] for k in ("maxInputBits", "maxOutputBits", "outputSize", "arrLen")}
+        want["expected"] = [int(x, 16) for x in v["expected"]]
+        assert got == want
+    for v in g["unpackInput"]:
+        got = pkg.unpackInput(v["maxVal"], v["packedBits"], [int(x, 16) for x in v["data"]], engine=eng)
+        assert got == {k: v[k] for k in ("maxInputBits", "packedBits", "packedSize", "unpackedSize", "unpacked")}
+    rng = np.random.default_rng(8)
+    for max_val, n in ((8192, 701), (4096, 821), (3, 821), (65535, 100), (1, 9)):
+        data = rng.integers(0, min(max_val + 1, 65536), (57, n))
+        limbs = eng.pack_batch(max_val, n, data)
+        assert np.array_equal(limbs, orc.pack_batch(max_val, n, data))
+        pr = eng.pack_params(max_val, n)
+        back = eng.unpack_batch(max_val, pr["numInputsPerOutput"] * pr["maxInputBits"], limbs)
+        assert np.array_equal(back[:, :n], data) and not back[:, n:].any()          # pack -> unpack round trip
+        assert np.array_equal(back, orc.unpack_batch(max_val, pr["numInputsPerOutput"] * pr["maxInputBits"], limbs))
+
+
 # ---- error behaviour ------------------------------------------------------------------------------------------
 
 def test_error_behaviour(eng):

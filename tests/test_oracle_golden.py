@@ -175,3 +175,18 @@ def test_sampler_stream_and_procedure(pure_golden):
         assert r[b].tolist() == [2 if x == -1 else x for x in ref]
         assert (r[b] == 1).sum() == 18 and (r[b] == 2).sum() == 18
     assert len({r[b].tobytes() for b in range(4)}) == 4
+
+
+def test_field_packing_matches_reference():
+    from conftest import load_golden
+    g = load_golden("pack_functions.json")
+    for v in g["packOutput"]:
+        pr = orc.pack_params(v["maxVal"], v["dataLen"])
+        assert pr == {k: v[k] for k in ("maxInputBits", "arrLen", "outputSize")} | {"numInputsPerOutput": v["maxOutputBits"] // v["maxInputBits"]}
+        limbs = orc.pack_batch(v["maxVal"], v["dataLen"], [v["data"]])
+        assert orc.limbs_to_ints(limbs[0]) == [int(x, 16) for x in v["expected"]]
+    for v in g["unpackInput"]:
+        limbs = orc.ints_to_limbs([int(x, 16) for x in v["data"]])[None]
+        un = orc.unpack_batch(v["maxVal"], v["packedBits"], limbs)
+        assert un.shape[1] == v["unpackedSize"]
+        assert orc.trim(un[0]) == v["unpacked"]
