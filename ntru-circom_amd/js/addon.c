@@ -5,6 +5,7 @@
  * (napi_get_typedarray_info), calls the engine, and throws a JS Error carrying ntru_last_error() on failure.
  * All reference-shaped behaviour (padding, trimming, {value, inputs, params} objects) lives in index.mjs.
  */
+#define NAPI_VERSION 6
 #include <node_api.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -194,6 +195,48 @@ static napi_value SampleTernary(napi_env env, napi_callback_info info) {
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
+/* packParams(maxVal, dataLen) -> [bits, perOutput, arrLen, outputSize] */
+static napi_value PackParams(napi_env env, napi_callback_info info) {
+  ARGS(2)
+  int32_t mv, dl; int v[4];
+  if (!get_i32(env, argv[0], &mv) || !get_i32(env, argv[1], &dl)) BAD_ARGS();
+  int rc = ntru_pack_params(mv, dl, &v[0], &v[1], &v[2], &v[3]);
+  if (rc) return throw_engine(env, rc);
+  napi_value arr; NAPI_OK(napi_create_array_with_length(env, 4, &arr));
+  for (int i = 0; i < 4; i++) { napi_value n; NAPI_OK(napi_create_int32(env, v[i], &n)); NAPI_OK(napi_set_element(env, arr, i, n)); }
+  return arr;
+}
+
+/* packBatch(maxVal, dataLen, data:Uint16Array[B*dataLen], B, out:BigUint64Array[B*outputSize*4]) */
+static napi_value PackBatch(napi_env env, napi_callback_info info) {
+  ARGS(5)
+  int32_t mv, dl, B; void *data, *out; int v[4];
+  if (!get_i32(env, argv[0], &mv) || !get_i32(env, argv[1], &dl) || !get_i32(env, argv[3], &B) || B < 0) BAD_ARGS();
+  int rc = ntru_pack_params(mv, dl, &v[0], &v[1], &v[2], &v[3]);
+  if (rc) return throw_engine(env, rc);
+  if (!get_buf(env, argv[2], napi_uint16_array, (size_t)dl * (size_t)B, 0, &data) ||
+      !get_buf(env, argv[4], napi_biguint64_array, (size_t)v[3] * 4 * (size_t)B, 0, &out)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  rc = ntru_pack_batch(g_engine, mv, dl, data, B, out);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* unpackBatch(maxVal, packedBits, in:BigUint64Array[B*packedSize*4], packedSize, B, out:Uint16Array[B*packedSize*per]) */
+static napi_value UnpackBatch(napi_env env, napi_callback_info info) {
+  ARGS(6)
+  int32_t mv, pb, ps, B; void *in, *out; int v[4];
+  if (!get_i32(env, argv[0], &mv) || !get_i32(env, argv[1], &pb) || !get_i32(env, argv[3], &ps) ||
+      !get_i32(env, argv[4], &B) || B < 0 || ps < 0) BAD_ARGS();
+  int rc = ntru_pack_params(mv, 0, &v[0], &v[1], &v[2], &v[3]);
+  if (rc) return throw_engine(env, rc);
+  const int per = pb / v[0];
+  if (!get_buf(env, argv[2], napi_biguint64_array, (size_t)ps * 4 * (size_t)B, 0, &in) ||
+      !get_buf(env, argv[5], napi_uint16_array, (size_t)ps * (size_t)(per > 0 ? per : 0) * (size_t)B, 0, &out)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  rc = ntru_unpack_batch(g_engine, mv, pb, in, ps, B, out);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
     {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
@@ -207,6 +250,9 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"decryptBatch", NULL, DecryptBatch, NULL, NULL, NULL, napi_default, NULL},
     {"verifyKeysBatch", NULL, VerifyKeysBatch, NULL, NULL, NULL, napi_default, NULL},
     {"sampleTernary", NULL, SampleTernary, NULL, NULL, NULL, napi_default, NULL},
+    {"packParams", NULL, PackParams, NULL, NULL, NULL, napi_default, NULL},
+    {"packBatch", NULL, PackBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"unpackBatch", NULL, UnpackBatch, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof props / sizeof props[0], props) != napi_ok) return NULL;
   return exports;

@@ -12,9 +12,8 @@
 // There is no JavaScript arithmetic fallback: without the addon or a GPU the first call throws.
 //
 // Out of scope (SURVEY.md 8f): key generation / inversion (loadPrivateKeyF, generatePrivateKeyF,
-// generateNewPublicKeyGH, generatePublicKeyH, polyInv, extendedEuclideanAlgorithm, generic long division) and the
-// BN254 field packing (packOutput / unpackInput).  Keys are supplied through the options object, as
-// README.md:81 of the reference already allows.
+// generateNewPublicKeyGH, generatePublicKeyH, polyInv, extendedEuclideanAlgorithm, generic long division).
+// Keys are supplied through the options object, as README.md:81 of the reference already allows.
 import { createRequire } from 'module';
 import { randomFillSync } from 'crypto';
 
@@ -143,6 +142,32 @@ export function addCiphertexts(e1, e2, q) {
   A.set(e1); Bv.set(e2);
   engine().addBatch(N, q, A, Bv, 1, out);
   return trimPolynomial(Array.from(out));
+}
+
+const limbsToBigInt = (l, at) => l[at] | (l[at + 1] << 64n) | (l[at + 2] << 128n) | (l[at + 3] << 192n);
+
+// index.js:572-596 on the GPU: same object as the reference (`expected` is an Array of BigInt).
+export function packOutput(maxVal, dataLen, data) {
+  const [maxInputBits, numInputsPerOutput, arrLen, outputSize] = engine().packParams(maxVal, dataLen);
+  const inArr = Uint16Array.from(expandArray(data, dataLen, 0));
+  const limbs = new BigUint64Array(outputSize * 4);
+  engine().packBatch(maxVal, dataLen, inArr, 1, limbs);
+  const expected = [];
+  for (let o = 0; o < outputSize; o++) expected.push(limbsToBigInt(limbs, 4 * o));
+  return { maxInputBits, maxOutputBits: numInputsPerOutput * maxInputBits, outputSize, arrLen, expected };
+}
+
+// index.js:598-620 on the GPU (`data`: Array of BigInt below 2^256).
+export function unpackInput(maxVal, packedBits, data) {
+  const [maxInputBits] = engine().packParams(maxVal, 0);
+  const per = Math.floor(packedBits / maxInputBits);
+  const limbs = new BigUint64Array(data.length * 4);
+  const M = (1n << 64n) - 1n;
+  data.forEach((v, i) => { for (let k = 0; k < 4; k++) limbs[4 * i + k] = (v >> BigInt(64 * k)) & M; });
+  const out = new Uint16Array(per * data.length);
+  if (data.length) engine().unpackBatch(maxVal, packedBits, limbs, data.length, 1, out);
+  return { maxInputBits, packedBits, packedSize: data.length, unpackedSize: per * data.length,
+    unpacked: trimPolynomial(Array.from(out)) };
 }
 
 const withZero = ta => { const a = Array.from(ta); a.push(0); return a; };

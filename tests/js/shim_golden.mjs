@@ -125,6 +125,22 @@ deepStrictEqual(lib.stringToBits('Hello World'), pure.misc.stringToBits[0].out);
   });
 }
 
+// field packing (index.js:572-620) against the captured reference outputs
+{
+  const g = golden('pack_functions.json');
+  for (const v of g.packOutput) {
+    const got = lib.packOutput(v.maxVal, v.dataLen, v.data);
+    deepStrictEqual({ ...got, expected: got.expected.map(x => x.toString(16)) },
+      { maxInputBits: v.maxInputBits, maxOutputBits: v.maxOutputBits, outputSize: v.outputSize, arrLen: v.arrLen, expected: v.expected });
+    strictEqual(typeof got.expected[0], 'bigint');
+  }
+  for (const v of g.unpackInput) {
+    const got = lib.unpackInput(v.maxVal, v.packedBits, v.data.map(x => BigInt('0x' + x)));
+    deepStrictEqual(got, { maxInputBits: v.maxInputBits, packedBits: v.packedBits, packedSize: v.packedSize,
+      unpackedSize: v.unpackedSize, unpacked: v.unpacked });
+  }
+}
+
 // on-device sampler: right weights, deterministic per (key, item), different per item; feeds the batch encrypt
 {
   const g = golden('scheme_n167_q128.json'); const key = g.keys[0]; const N = g.options.N;
