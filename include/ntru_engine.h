@@ -24,6 +24,10 @@
  *     synchronising; the same names without _dev take HOST pointers, copy in/out and return when
  *     the results are in the caller's buffers.
  *   - there is no CPU fallback: without a usable HIP device ntru_engine_create fails.
+ *   - symbol preconditions (what the reference itself always produces): r in {0,1,2}; f, g in {-1,0,1}; fp and the
+ *     plaintext-side values below p.  The fast kernels step over these ternary operands by symbol class (0 / 1 /
+ *     "the other symbol"); any other value is a caller error with unspecified results.  ntru_engine_set_kernel_path(1)
+ *     selects the multiply-accumulate kernels, which accept arbitrary operand values for r and h, e, fq.
  */
 #ifndef NTRU_ENGINE_H
 #define NTRU_ENGINE_H

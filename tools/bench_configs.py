@@ -77,7 +77,20 @@ def sampler_config(profile, logB):
             "kernel": eng.last_kernel(), "ms": ms, "samples_per_s": B / (ms * 1e-3), "hbm_GBps": N * B / (ms * 1e-3) / 1e9}
 
 
+def add_config(N, q, logB):
+    B = 1 << logB
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    a = torch.randint(0, q, (B, N), device=dev, generator=gen).to(torch.int16)
+    b = torch.randint(0, q, (B, N), device=dev, generator=gen).to(torch.int16)
+    out = torch.empty_like(a)
+    ms = timed(lambda: eng.add_batch_dev(N, q, a.data_ptr(), b.data_ptr(), B, out.data_ptr()), steps=10)
+    ok = bool(torch.equal(out.to(torch.int32) & 0xFFFF, ((a.to(torch.int32) & 0xFFFF) + (b.to(torch.int32) & 0xFFFF)) % q))
+    return {"config": "N=%d q=%d batch=2^%d addPolynomials on ciphertexts (elementwise), 1 GPU" % (N, q, logB), "ms": ms,
+            "adds_per_s": B / (ms * 1e-3), "hbm_GBps": 6 * N * B / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBps": 6 * N * B / (ms * 1e-3) / 8e12,
+            "correct": ok}
+
+
 if __name__ == "__main__":
     for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
-                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), sampler_config("n821_q4096", 20)):
+                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20)):
         print(json.dumps(res), flush=True)
