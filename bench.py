@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PK_MAC_PEAK_T = 75.6           # measured v_pk_mad_u16 roof, profiles/r01_microbench_valu_lds.txt (T MAC/s)
+DOT8_PEAK_T = 302.0            # measured v_dot8_u32_u4 roof: 37.9 T lane-instr/s x 8 nibble MACs
 ADD_PEAK_T = 134.0             # measured v_add_u32 roof 67 T lane-adds/s x 2 packed 16-bit coefficients per add
 
 
@@ -217,7 +218,16 @@ def main():
         dec_s = dec_ms * 1e-3
         dname = names.get("decrypt", "k_decrypt")
         add_path = dname.startswith(("k_decrypt_s", "k_decrypt_t"))
-        if add_path:
+        if "+dot8" in dname:
+            # product 1 steps over f (adds), product 2 is all N^2 nibble MACs on v_dot8_u32_u4
+            w1, w2 = float(np.count_nonzero(f_np)) * N * B, float(N) * N * B
+            ideal_s = w1 / (ADD_PEAK_T * 1e12) + w2 / (DOT8_PEAK_T * 1e12)
+            valu = {"kernel": dname, "achieved": (w1 + w2) / dec_s / 1e12, "peak": (w1 + w2) / ideal_s / 1e12,
+                    "unit": "T ops/s (coefficient-adds of product 1 + nibble-MACs of product 2)",
+                    "note": "peak = this mix at the measured issue roofs: v_add_u32 67 T/s x 2 coefficients for the "
+                            "stepping product, v_dot8_u32_u4 302 T nibble-MAC/s for the dot8 product "
+                            "(profiles/r01_microbench_valu_lds.txt); frac = ideal issue time / measured time"}
+        elif add_path:
             # work actually issued by the ternary add path: one packed coefficient-add per (non-zero step, output)
             nz_f = float(np.count_nonzero(f_np)) / N
             nz_b = 2.0 / 3.0                                  # the lifted message is ~uniform over {0,1,2}

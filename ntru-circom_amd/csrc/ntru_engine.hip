@@ -214,7 +214,8 @@ struct LaneId {
 };
 static __device__ __forceinline__ LaneId lane_id(const Geom &g) {
   LaneId L;
-  L.wave = threadIdx.x >> 6; L.lane = threadIdx.x & 63;
+  L.wave = threadIdx.x >> 6;     // (readfirstlane here saves 5 VGPRs in k_encrypt_t but measured 11% slower)
+  L.lane = threadIdx.x & 63;
   L.active = L.lane < g.G * g.nl;
   L.grp = L.active ? L.lane / g.nl : 0;
   L.sub = L.active ? L.lane - L.grp * g.nl : 0;
@@ -1002,6 +1003,119 @@ static __device__ __forceinline__ void shared_product_split(const u32 *E, const 
   }
 }
 
+
+// ---- ternary x ternary product on v_dot8_u32_u4 (decrypt's c = fp * b mod 3) ---------------------------------------
+// Both operands are in {0,1,2}: 8 multiply-accumulates per instruction, no branches, exact sums (<= 4N).  Layout for
+// this phase: lane l owns the 32 outputs k = 32 l + t.  A8r[I] (shared, built once per workgroup) packs fp[8I+7-i] in
+// nibble i; the per-item operand b is a nibble stream in LDS (coefficient j at nibble j + 8*nblk, extended cyclically
+// below 0), and FB(t, I) = the forward window b[k-8I-7 .. k-8I] is cut out of two stream dwords with v_alignbit; going
+// to the next block shifts all windows by 8 slots, so only 8 of the 32 are recomputed.  The low half for the quotient
+// is the accumulator snapshot before block 4 l plus a 4-block correction against the zero-extended stream.
+// tools/dot8_model.py is the executable specification (checked against a direct convolution).
+static __device__ __forceinline__ u32 funnel(u32 hi, u32 lo, int sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+// nibble stream of b from the K pairs per lane of the 32-lane product-1 layout (P[t] = (b[2v], b[2v+1]), v = K sub + t)
+template <int K>
+static __device__ __forceinline__ void build_nibble_stream(u32 *dwp, int N, int nblk, int sub, bool active,
+                                                           const u32 (&P)[K]) {
+  if (active) {
+    unsigned char *by = (unsigned char *)dwp + 4 * nblk + K * sub;       // coefficient 0 sits at dword nblk
+#pragma unroll
+    for (int t = 0; t < K; t++) by[t] = (unsigned char)((P[t] & 0xFu) | (((P[t] >> 16) & 0xFu) << 4));
+  }
+  wave_lds_fence();
+  const int a = N >> 3, r4 = 4 * (N & 7);                                 // N nibbles = a dwords + r nibbles
+  for (int w = sub; w < nblk; w += 32) {                                 // coefficient j < 0 is b[j + N]
+    const u32 lo = dwp[w + a], hi = dwp[w + a + 1];
+    if (active) dwp[w] = r4 ? funnel(hi, lo, r4) : lo;
+  }
+  wave_lds_fence();
+}
+
+template <bool WL>
+static __device__ __forceinline__ void dot8_core(const u32 *__restrict__ dwp, const u32 *__restrict__ a8, int nblk, int l,
+                                                 u32 (&acc)[32], u32 (&snap)[32]) {
+  u32 S[32];
+  const u32 *base = dwp + 4 * l + nblk - 1;
+  u32 Y;
+  {
+    u32 D[5];
+#pragma unroll
+    for (int g = 0; g < 5; g++) D[g] = base[g];
+#pragma unroll
+    for (int t = 0; t < 32; t++) {
+      const int g = (t + 1) >> 3, ph = (t + 1) & 7;
+      S[t] = ph ? funnel(D[g + 1 < 5 ? g + 1 : 4], D[g], 4 * ph) : D[g];
+    }
+    Y = D[0];
+  }
+#pragma unroll
+  for (int t = 0; t < 32; t++) { acc[t] = 0; snap[t] = 0; }
+  const u32 *xp = base - 1;                                               // block I reads xp[-I]
+  for (int u = 0; u < (nblk >> 2); u++) {
+    if constexpr (WL) {
+      if (u == l) {
+#pragma unroll
+        for (int t = 0; t < 32; t++) asm volatile("v_mov_b32 %0, %1" : "+v"(snap[t]) : "v"(acc[t]));
+      }
+    }
+    const uint4 av = *(const uint4 *)(a8 + 4 * u);
+    const u32 A[4] = {av.x, av.y, av.z, av.w};
+    u32 X[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) X[v] = xp[-(4 * u + v)];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+#pragma unroll
+      for (int t = 0; t < 32; t++) acc[t] = __builtin_amdgcn_udot8(A[v], S[(t - 8 * v) & 31], acc[t], false);
+#pragma unroll
+      for (int tp = 0; tp < 7; tp++) S[(tp - 8 * (v + 1)) & 31] = funnel(Y, X[v], 4 * (tp + 1));
+      S[(7 - 8 * (v + 1)) & 31] = Y;
+      Y = X[v];
+    }
+  }
+}
+
+// c = fp * b mod 3 for one item per 32-lane half: value / quotient2 rows stored directly.
+template <bool WQ>
+static __device__ __forceinline__ void dot8_product_mod3(const u32 *dwp, const u32 *a8, int N, int nblk, int l, bool valid,
+                                                         int lanes, uint8_t *__restrict__ value_row,
+                                                         uint8_t *__restrict__ quot_row) {
+  u32 acc[32], low[32];
+  dot8_core<WQ>(dwp, a8, nblk, l, acc, low);
+  if (WQ) {                                             // low += in-block part, against the zero-extended stream
+    u32 ZD[9];
+#pragma unroll
+    for (int g = 0; g < 4; g++) ZD[g] = 0;
+#pragma unroll
+    for (int g = 0; g < 5; g++) ZD[4 + g] = dwp[nblk + g];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const u32 a = a8[4 * l + d];
+#pragma unroll
+      for (int t = 0; t < 32; t++) {
+        const int g = ((t + 1) >> 3) + 3 - d, ph = (t + 1) & 7;
+        const u32 w = ph ? funnel(ZD[g + 1], ZD[g], 4 * ph) : ZD[g];
+        low[t] = __builtin_amdgcn_udot8(a, w, low[t], false);
+      }
+    }
+  }
+  const int nv = N - 32 * (lanes - 1);                  // valid outputs of the last lane (wave-uniform)
+  const bool full = valid && l < lanes - 1, tail = valid && l == lanes - 1;
+  uint8_t *vr = value_row + 32 * l, *qr = quot_row + 32 * l;
+#pragma unroll
+  for (int t = 0; t < 32; t++) {
+    const u32 T = acc[t];
+    const u32 rv = T % 3u;
+    u32 qv = 0;
+    if (WQ) { const u32 h = (T - low[t]) % 3u; qv = h ? 3u - h : 0u; }
+    if (full || (tail && t < nv)) {
+      vr[t] = (uint8_t)rv;
+      if (WQ) qr[t] = (uint8_t)qv;
+    }
+  }
+}
+
 // The lane's block of a shared stepping operand: numeric pairs + the block's two step masks.
 template <int K, class F>
 static __device__ __forceinline__ uint2 load_block_masks(F val, const Geom &g, int sub, u32 (&av)[K]) {
@@ -1020,7 +1134,7 @@ static __device__ __forceinline__ uint2 load_block_masks(F val, const Geom &g, i
 }
 
 // decryptBits with both products stepping over the shared key (f, then fp); two items per wave.  p must be 3.
-template <int K, int ME>
+template <int K, int ME, bool D8>
 __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u32 p, const int8_t *__restrict__ f,
                                                              const uint8_t *__restrict__ fp,
                                                              const u16 *__restrict__ e, long B,
@@ -1032,8 +1146,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u
   u32 *blk_f = (u32 *)(masks_fp + g.nl);                                // [nl][K] numeric pairs of f (for the triangles)
   u32 *blk_fp = blk_f + (size_t)g.nl * K;
   const LaneId L = lane_id(g);
+  const int nblk = ((g.N + 31) >> 5) << 2;                              // dot8 phase: 8-step blocks, multiple of 4
+  u32 *a8fp = blk_fp + (size_t)g.nl * K;                                // [nblk] reversed-nibble words of fp (16-byte aligned)
   const int e_alloc = g.eo_len + 2;                                     // dwords per item incl. spare front entry + dummy slot
-  u32 *E = blk_fp + (size_t)g.nl * K + ((size_t)L.wave * g.G + L.grp) * e_alloc + 1;
+  const int e_off0 = nblk + (L.wave * g.G + L.grp) * e_alloc + 1;
   if (L.wave == 0 && L.active && L.grp == 0) {                          // key-dependent tables, once per workgroup
     u32 av[K];
     masks_f[L.sub] = load_block_masks<K>(ValTernary{f, q - 1}, g, L.sub, av);
@@ -1043,6 +1159,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u
 #pragma unroll
     for (int t = 0; t < K; t++) blk_fp[K * L.sub + t] = av[t];
   }
+  if (D8 && L.wave == 1) {                                              // A8r[I]: nibble i = fp[8I + 7 - i]
+    for (int I = L.lane; I < nblk; I += 64) {
+      u32 w = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { const int j = 8 * I + 7 - i; w |= (j < g.N ? (u32)fp[j] & 0xFu : 0u) << (4 * i); }
+      a8fp[I] = w;
+    }
+  }
   const u32 *av_f = blk_f + K * L.sub, *av_fp = blk_fp + K * L.sub;
   __syncthreads();
   const long ngroups = (B + g.G - 1) / g.G;
@@ -1051,8 +1175,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u
     // Re-materialise the lane index and N every iteration: otherwise the compiler hoists all per-lane address /
     // predicate arithmetic of the glue below out of this loop and keeps ~100 registers live (and spilled) across
     // both hot loops.
-    int sub = L.sub, N = g.N;
-    asm volatile("" : "+v"(sub), "+s"(N));
+    int sub = L.sub, N = g.N, e_off = e_off0;
+    asm volatile("" : "+v"(sub), "+s"(N), "+v"(e_off));
+    u32 *E = a8fp + e_off;
     const long item = grp * g.G + L.grp;
     const bool valid = L.active && item < B;
     const long row = (valid ? item : 0) * N;
@@ -1083,12 +1208,25 @@ __global__ __launch_bounds__(BLOCK_THREADS, 4) void k_decrypt_s(Geom g, u32 q, u
       P[t] = b0 | (b1 << 16);
     });
     wave_lds_fence();                                                   // everyone is done reading E(e)
-    build_cyclic_pairs<K>(E, g, sub, L.active, P, true, P[0] & 0xFFFFu);
-    // ---- product 2: c = fp * b mod p (exact small sums, no masking)
-    shared_product_split<K, 0, false>(E, masks_fp, av_fp, g, sub, want_q2, p, [&](int t, u16x2 rv, u16x2 qv) {
-      store_pair(value + lane0, sp, t, rv);
-      if (want_q2) store_pair(quot2 + lane0, sp, t, qv);
-    });
+    if constexpr (D8) {
+      // ---- product 2 on v_dot8: the item's buffer now holds the nibble stream of the lifted message
+      int d_off = e_off - 1, l8 = L.lane & 31;                          // 16-byte aligned start of the item's buffer
+      asm volatile("" : "+v"(d_off), "+v"(l8));                         // keep this phase's addresses out of product 1
+      u32 *dwp = a8fp + d_off;
+      build_nibble_stream<K>(dwp, N, nblk, sub, L.active, P);
+      const int lanes8 = (N + 31) >> 5;
+      const bool act8 = l8 < lanes8 && L.active;
+      l8 = act8 ? l8 : 0;
+      if (want_q2) dot8_product_mod3<true>(dwp, a8fp, N, nblk, l8, valid && act8, lanes8, value + row, quot2 + row);
+      else dot8_product_mod3<false>(dwp, a8fp, N, nblk, l8, valid && act8, lanes8, value + row, value + row);
+    } else {
+      build_cyclic_pairs<K>(E, g, sub, L.active, P, true, P[0] & 0xFFFFu);
+      // ---- product 2: c = fp * b mod p (exact small sums, no masking)
+      shared_product_split<K, 0, false>(E, masks_fp, av_fp, g, sub, want_q2, p, [&](int t, u16x2 rv, u16x2 qv) {
+        store_pair(value + lane0, sp, t, rv);
+        if (want_q2) store_pair(quot2 + lane0, sp, t, qv);
+      });
+    }
     wave_lds_fence();
   }
 }
@@ -1554,7 +1692,7 @@ extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
 
 extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (path < 0 || path > 2) return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC) or 2 (add)");
+  if (path < 0 || path > 3) return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add) or 3 (add without dot8)");
   eng->path = path;
   return NTRU_OK;
 }
@@ -1630,13 +1768,16 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
   return K;
 }
 
-#define DISPATCH_K_SHARED(Kv, MEv, ...)                                                             \
-  switch ((Kv) * 100 + (MEv)) {                                                                     \
-    case 1313: { constexpr int KK = 13, MM = 13; __VA_ARGS__; } break;                              \
-    case 1111: { constexpr int KK = 11, MM = 11; __VA_ARGS__; } break;                              \
-    case 1107: { constexpr int KK = 11, MM = 7; __VA_ARGS__; } break;                               \
-    case 909: { constexpr int KK = 9, MM = 9; __VA_ARGS__; } break;                                 \
-    case 907: { constexpr int KK = 9, MM = 7; __VA_ARGS__; } break;                                 \
+#define DISPATCH_K_SHARED(Kv, MEv, D8v, ...)                                                        \
+  switch ((Kv) * 1000 + (MEv) * 10 + (D8v)) {                                                       \
+    case 13131: { constexpr int KK = 13, MM = 13; constexpr bool DD = true; __VA_ARGS__; } break;   \
+    case 13130: { constexpr int KK = 13, MM = 13; constexpr bool DD = false; __VA_ARGS__; } break;  \
+    case 11111: { constexpr int KK = 11, MM = 11; constexpr bool DD = true; __VA_ARGS__; } break;   \
+    case 11110: { constexpr int KK = 11, MM = 11; constexpr bool DD = false; __VA_ARGS__; } break;  \
+    case 11071: { constexpr int KK = 11, MM = 7; constexpr bool DD = true; __VA_ARGS__; } break;    \
+    case 11070: { constexpr int KK = 11, MM = 7; constexpr bool DD = false; __VA_ARGS__; } break;   \
+    case 9090: { constexpr int KK = 9, MM = 9; constexpr bool DD = false; __VA_ARGS__; } break;     \
+    case 9070: { constexpr int KK = 9, MM = 7; constexpr bool DD = false; __VA_ARGS__; } break;     \
     default: return fail(NTRU_ERR_UNSUPPORTED, "no shared-step kernel for this (K, mask interval)"); \
   }
 
@@ -1741,15 +1882,18 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
       L.K = KS;
       L.g = make_geom(N, KS);
       const size_t per_wave = (size_t)L.g.G * (L.g.eo_len + 2) * 4;
-      L.lds = (size_t)L.g.nl * 16 + (size_t)L.g.nl * KS * 8 + WAVES_PER_BLOCK * per_wave;
+      const int nblk8 = ((N + 31) >> 5) << 2;
+      L.lds = (size_t)L.g.nl * 16 + (size_t)L.g.nl * KS * 8 + (size_t)nblk8 * 4 + WAVES_PER_BLOCK * per_wave;
+      // product 2 on v_dot8 needs the 32-lane item layout (and is skipped when the MAC/add families are forced apart)
+      const int d8 = (L.g.nl == 32 && eng->path != 3) ? 1 : 0;
       const long ngroups = (B + L.g.G - 1) / L.g.G;
       long blocks = (ngroups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
       L.grid = dim3((unsigned)(blocks < 1 ? 1 : blocks));
-      DISPATCH_K_SHARED(KS, me, {
-        if (int rc = allow_lds(k_decrypt_s<KK, MM>, L.lds)) return rc;
-    if (int rc = resident_grid(eng, k_decrypt_s<KK, MM>, L.lds, (long)L.grid.x, &L.grid)) return rc;
-        note_kernel(eng, "k_decrypt_s", KK, MM);
-        hipLaunchKernelGGL((k_decrypt_s<KK, MM>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p,
+      DISPATCH_K_SHARED(KS, me, d8, {
+        if (int rc = allow_lds(k_decrypt_s<KK, MM, DD>, L.lds)) return rc;
+        if (int rc = resident_grid(eng, k_decrypt_s<KK, MM, DD>, L.lds, (long)L.grid.x, &L.grid)) return rc;
+        note_kernel(eng, DD ? "k_decrypt_s+dot8" : "k_decrypt_s", KK, MM);
+        hipLaunchKernelGGL((k_decrypt_s<KK, MM, DD>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, (u32)p,
                            d_f, d_fp, d_e, (long)B, d_value, d_quot1, d_rem1, d_quot2);
       });
       HIP_TRY(hipGetLastError());

@@ -18,7 +18,8 @@ class EngineError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libntru_engine.so")
+    """The in-tree build; NTRU_ENGINE_LIB selects another build of the same C ABI (A/B measurements)."""
+    return os.environ.get("NTRU_ENGINE_LIB") or os.path.join(_HERE, "lib", "libntru_engine.so")
 
 
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64

@@ -3,6 +3,8 @@
 
   python tools/pmc_summary.py <tag> [--mode witness|value] [--N 821] [--logB 20]
 
+(rocprofv3 writes CSV with --output-format csv; its default rocpd database is converted first with
+ `rocpd2csv -i <results.db> -d gpurun_out/prof_<x>/csv`.)
 Reads  gpurun_out/prof_stats/**/**_kernel_stats.csv            (rocprofv3 --kernel-trace --stats)
        gpurun_out/prof_fetch/**/**_counter_collection.csv      (rocprofv3 --pmc FETCH_SIZE --kernel-trace)
        gpurun_out/prof_write/**/**_counter_collection.csv      (rocprofv3 --pmc WRITE_SIZE --kernel-trace)
@@ -21,8 +23,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.match(r"(?:void )?(k_[a-z_]+<[0-9, ]+>)", name)
-    return m.group(1).replace(" ", "") if m else None
+    """rocprof's demangled template name -> the name ntru_engine_last_kernel / bench.py report."""
+    m = re.match(r"(?:void )?(k_[a-z_]+)<([0-9a-z, ]+)>", name)
+    if not m:
+        return None
+    fam, args = m.group(1), [x.strip() for x in m.group(2).split(",")]
+    if args[-1] in ("true", "false"):                      # k_decrypt_s<K, ME, D8>
+        fam += "+dot8" if args.pop() == "true" else ""
+    return "%s<%s>" % (fam, ",".join(args))
 
 
 def main():
@@ -33,16 +41,31 @@ def main():
     ap.add_argument("--logB", type=int, default=20)
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    sdir = os.path.join(ROOT, "gpurun_out", "prof_stats")
+    stats = glob.glob(os.path.join(sdir, "**", "*_kernel_stats.csv"), recursive=True)
+    trace = glob.glob(os.path.join(sdir, "**", "*kernel_trace.csv"), recursive=True)
     if stats:
         rows = list(csv.reader(open(sorted(stats)[-1])))
+    elif trace:      # rocpd output converted with rocpd2csv: rebuild the --stats table from the kernel trace
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(sorted(trace)[-1])):
+            dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        total = float(sum(sum(v) for v in dur.values()))
+        rows = [["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]]
+        for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            mean = sum(v) / len(v)
+            sd = (sum((x - mean) ** 2 for x in v) / (len(v) - 1)) ** 0.5 if len(v) > 1 else 0.0
+            rows.append([k, len(v), sum(v), "%.6f" % mean, "%.2f" % (100 * sum(v) / total), min(v), max(v), "%.6f" % sd])
+    else:
+        rows = None
+    if rows:
         with open(os.path.join(out, a.tag + "_kernel_stats.csv"), "w", newline="") as fh:
             w = csv.writer(fh)
             for r in rows:
                 w.writerow([r[0][:110]] + r[1:])
     kern = {}
     for cname, sub in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
-        files = glob.glob(os.path.join(ROOT, "gpurun_out", sub, "**", "*_counter_collection.csv"), recursive=True)
+        files = glob.glob(os.path.join(ROOT, "gpurun_out", sub, "**", "*counter_collection*.csv"), recursive=True)
         if not files:
             continue
         acc = collections.defaultdict(list)
