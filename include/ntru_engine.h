@@ -65,7 +65,8 @@ void ntru_engine_destroy(ntru_engine_t *eng);
  * The engine never owns the stream. */
 int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
 /* Tuning / test knob: 0 = pick the fastest applicable kernel family (default), 1 = always the packed-u16 MAC
- * kernels, 2 = the ternary add path wherever it applies.  Results are identical. */
+ * kernels, 2 = the ternary add path wherever it applies, 3 = the add path without its dot8 product, 4 = the int8
+ * matrix-core path wherever it applies (shared key, q <= 8192), even for small N.  Results are identical. */
 int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
 /* Name of the kernel the last *_dev call on this engine launched, e.g. "k_decrypt_s<13,13>" (for reports). */
 const char *ntru_engine_last_kernel(ntru_engine_t *eng);

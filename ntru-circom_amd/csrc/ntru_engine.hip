@@ -1607,6 +1607,364 @@ __global__ void k_unpack(int bits, int per, int packed_size, const unsigned long
   }
 }
 
+// ---- family 4: shared-key products on the int8 matrix cores ---------------------------------------------------------
+// A product of a batch operand X[b][i] with a SHARED key operand s is a matrix product with the Toeplitz matrix of s,
+// which is what v_mfma_i32_32x32x32_i8 is for (exact: int8 x int8 -> int32).  Rows = 32 items of a row block, columns
+// = output coefficients k = 32 kb + k', contraction i = 32 ib + i'; the key tile depends only on d = kb - ib:
+//     G_d[i'][k'] = sc[32 d + k' - i'],  sc = s with period N
+// d > 0 accumulates into `low` (coefficients 0..N-1 of the linear product), d < 0 into `high` (N..2N-1), d = 0 is split
+// by k' >= i'; remainder = low + high, quotient = -high (closed form of the division by 1 - x^N).
+// Operands wider than int8 use two digit planes on the contraction axis, value = lo + 128 hi computed as
+// [A | alpha A] x [lo ; beta hi], alpha beta = 128.  LDS images: operand stages [32 rows][pitchA] (ds_read_b128, pitch an
+// odd multiple of 16 bytes), key arrays reversed and cyclic, rev[y] = digit(sc[(32 NT - 1 - y) mod N]), in 4 byte-shifted
+// copies so that a lane's 16-byte Toeplitz fragment (which starts at an arbitrary byte) is 4 aligned dwords; each of the
+// 4 waves owns strips of <= 4 column tiles, its fragment window slides by one tile per contraction step (one new
+// fragment per step).  tools/mfma_model.py is the executable specification; profiles/r01_microbench_mfma_lds.txt holds
+// the measurements behind the layout choices.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct MGeom {
+  int N;        // ring size
+  int NT;       // 32-wide tiles per row: ceil(N / 32)
+  int pitchA;   // bytes per row of an operand stage: 32 NT + 16
+  int tpitch;   // dwords per byte-shifted copy of a reversed key array (= 8 mod 32: the 4 copies use disjoint banks)
+};
+
+enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
+
+template <class D>
+static __device__ __forceinline__ void build_toeplitz_array(u32 *T, const MGeom &g, D digit, int tid, int nthr) {
+  const int Y0 = 32 * g.NT - 1;
+  for (int x = tid; x < 4 * g.tpitch; x += nthr) {
+    const int c = x / g.tpitch, w = x - c * g.tpitch;
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int idx = (Y0 - (4 * w + c + j)) % g.N;       // remainder takes the dividend's sign
+      idx += idx < 0 ? g.N : 0;
+      v |= ((u32)digit(idx) & 0xFFu) << (8 * j);
+    }
+    T[x] = v;
+  }
+}
+
+// Per-lane pointer to the fragment of tile offset d = 0 (the fragment of offset d starts 8 d dwords below it).
+static __device__ __forceinline__ const u32 *frag_lane_base(const u32 *T, const MGeom &g, int lane) {
+  const int y0 = 32 * g.NT - 1 - (lane & 31) + 16 * (lane >> 5);
+  return T + (y0 & 3) * g.tpitch + (y0 >> 2);
+}
+
+static __device__ __forceinline__ v4i and4(v4i a, const u32 (&m)[4]) {
+  return (v4i){(int)((u32)a[0] & m[0]), (int)((u32)a[1] & m[1]), (int)((u32)a[2] & m[2]), (int)((u32)a[3] & m[3])};
+}
+
+// One strip of NT_S column tiles starting at tile kb0, all 32 rows of the staged row block.  st0 / st1: this lane's
+// row of the operand stage(s) (+ 16 bytes for the upper half-wave); tb0 / tb1: this lane's fragment bases.
+template <int MODE, int NT_S, class Epi>
+static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__restrict__ st0,
+                                                      const unsigned char *__restrict__ st1,
+                                                      const u32 *__restrict__ tb0, const u32 *__restrict__ tb1,
+                                                      const MGeom &g, int kb0, const u32 (&mlow)[4], Epi epi) {
+  constexpr bool TWO = MODE != M_DEC2;
+  v16i accL[NT_S], accH[NT_S];
+  v4i W0[NT_S], W1[NT_S];
+#pragma unroll
+  for (int t = 0; t < NT_S; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { accL[t][i] = 0; accH[t][i] = 0; }
+  auto load_w = [&](int d, v4i &w0, v4i &w1) {
+    const u32 *p = tb0 - 8 * d;
+    w0 = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+    if (MODE == M_ENC) {
+      const u32 *p1 = tb1 - 8 * d;
+      w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+    } else if (MODE == M_DEC1) {                       // 64 f from f in {-1,0,1}: bit 0 -> bit 6, sign bit kept
+#pragma unroll
+      for (int c = 0; c < 4; c++) w1[c] = (int)((((u32)w0[c] & 0x01010101u) << 6) | ((u32)w0[c] & 0x80808080u));
+    } else {
+      w1 = w0;
+    }
+  };
+  auto load_a = [&](int ib, v4i &a0, v4i &a1) {
+    a0 = *(const v4i *)(st0 + 32 * ib);
+    if (MODE == M_ENC) {                               // 32 r: r <= 3, no carry between bytes
+#pragma unroll
+      for (int c = 0; c < 4; c++) a1[c] = (int)((u32)a0[c] << 5);
+    } else if (MODE == M_DEC1) {
+      a1 = *(const v4i *)(st1 + 32 * ib);
+    } else {
+      a1 = a0;
+    }
+  };
+  auto mm = [&](v16i &acc, v4i a0, v4i a1, v4i w0, v4i w1) {
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w0, acc, 0, 0, 0);
+    if (TWO) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w1, acc, 0, 0, 0);
+  };
+  auto slide = [&](int ib_next) {
+#pragma unroll
+    for (int t = NT_S - 1; t > 0; t--) { W0[t] = W0[t - 1]; W1[t] = W1[t - 1]; }
+    load_w(kb0 - ib_next, W0[0], W1[0]);
+  };
+#pragma unroll
+  for (int t = 0; t < NT_S; t++) load_w(kb0 + t, W0[t], W1[t]);
+  int ib = 0;
+  for (; ib < kb0; ib++) {                             // every tile of the strip is above the diagonal: low
+    v4i a0, a1;
+    load_a(ib, a0, a1);
+#pragma unroll
+    for (int t = 0; t < NT_S; t++) mm(accL[t], a0, a1, W0[t], W1[t]);
+    slide(ib + 1);
+  }
+  u32 mhigh[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
+#pragma unroll
+  for (int s = 0; s < NT_S; s++) {                     // the strip's own contraction tiles: ib = kb0 + s
+    v4i a0, a1;
+    load_a(kb0 + s, a0, a1);
+#pragma unroll
+    for (int t = 0; t < NT_S; t++) {
+      if (t > s) mm(accL[t], a0, a1, W0[t], W1[t]);
+      else if (t < s) mm(accH[t], a0, a1, W0[t], W1[t]);
+      else {
+        mm(accL[t], a0, a1, and4(W0[t], mlow), and4(W1[t], mlow));
+        mm(accH[t], a0, a1, and4(W0[t], mhigh), and4(W1[t], mhigh));
+      }
+    }
+    slide(kb0 + s + 1);
+  }
+  for (ib = kb0 + NT_S; ib < g.NT; ib++) {             // below the diagonal: high
+    v4i a0, a1;
+    load_a(ib, a0, a1);
+#pragma unroll
+    for (int t = 0; t < NT_S; t++) mm(accH[t], a0, a1, W0[t], W1[t]);
+    slide(ib + 1);
+  }
+#pragma unroll
+  for (int t = 0; t < NT_S; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) epi(t, i, accL[t][i], accH[t][i]);
+}
+
+// This wave's share of the NT column tiles, cut into strips of at most 4 tiles; body(kb0, nt) per strip.
+template <class Body>
+static __device__ __forceinline__ void for_each_strip(int NT, int wave, Body body) {
+  const int base = NT / WAVES_PER_BLOCK, extra = NT % WAVES_PER_BLOCK;
+  const int share = base + (wave < extra ? 1 : 0);
+  int kb = wave * base + (wave < extra ? wave : extra);
+  if (share == 0) return;
+  const int n_str = (share + 3) >> 2;
+  for (int s = 0; s < n_str; s++) {
+    const int nt = share / n_str + (s < share % n_str ? 1 : 0);
+    body(kb, nt);
+    kb += nt;
+  }
+}
+
+static __device__ __forceinline__ uint4 load16_unaligned(const void *p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
+static __device__ __forceinline__ void diag_low_mask(int lane, u32 (&mlow)[4]) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    u32 mk = 0;
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) mk |= (r >= 16 * hh + 4 * c + jj) ? (0xFFu << (8 * jj)) : 0u;
+    mlow[c] = mk;
+  }
+}
+
+// Row of result register i of a 32x32 accumulator tile held by this lane (column = lane & 31).
+static __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// encryptBits on the matrix cores: e = (r * h + m) split by 1 - x^N; r in {0..3} bytes, h < q <= 8192.
+// h is taken in the representative hs = d0 + 128 d1, d0 in [-64,63], 4 d1 in [-128,124]; planes [r | 32 r] x [d0 ; 4 d1].
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, const u16 *__restrict__ h,
+                                                             const uint8_t *__restrict__ r,
+                                                             const uint8_t *__restrict__ m, long B,
+                                                             u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;
+  unsigned char *stA = (unsigned char *)(T1 + 4 * g.tpitch);
+  unsigned char *mimg = stA + 32 * g.pitchA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hthr = (int)(q >> 1) - 65;
+  auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
+  build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, tid, BLOCK_THREADS);
+  build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid, BLOCK_THREADS);
+  const bool want_q = quotE != nullptr;
+  const long nrb = (B + 31) >> 5;
+  const int nch = 2 * g.NT;                              // 16-byte chunks per staged row
+  const int lane0 = lane, tid0 = tid;
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    // Re-materialise the lane index and N per row block: otherwise every per-lane address / predicate of the staging
+    // and of the 64-element epilogues is hoisted out of this loop and spilled around the matrix loops.
+    int lane = lane0, N = g.N, tid = tid0;
+    asm volatile("" : "+v"(lane), "+s"(N), "+v"(tid));
+    const u32 *tb0 = frag_lane_base(T0, g, lane), *tb1 = frag_lane_base(T1, g, lane);
+    const unsigned char *st0 = stA + (lane & 31) * g.pitchA + 16 * (lane >> 5);
+    u32 mlow[4];
+    diag_low_mask(lane, mlow);
+    const long b0 = rb << 5;
+    const int rows = (int)(B - b0 < 32 ? B - b0 : 32);
+    __syncthreads();                                    // the previous row block's readers are done (first pass: key arrays built)
+    for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
+      for (int c = lane; c < nch; c += 64) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < rows) {
+          const uint8_t *src = r + (b0 + row) * N + 16 * c;
+          if (16 * c + 16 <= N) v = load16_unaligned(src);
+          else {
+            u32 w[4] = {0u, 0u, 0u, 0u};
+            for (int j = 0; j < 16; j++) if (16 * c + j < N) w[j >> 2] |= (u32)src[j] << (8 * (j & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
+        *(uint4 *)(stA + row * g.pitchA + 16 * c) = v;
+      }
+    }
+    {
+      const long total = (long)rows * N;
+      const uint8_t *msrc = m + b0 * N;
+      for (long i = (long)tid * 16; i + 16 <= total; i += BLOCK_THREADS * 16) *(uint4 *)(mimg + i) = load16_unaligned(msrc + i);
+      for (long i = (total & ~15L) + tid; i < total; i += BLOCK_THREADS) mimg[i] = msrc[i];
+    }
+    __syncthreads();
+    for_each_strip(g.NT, wave, [&](int kb0, int nt) {
+      auto epi = [&](int t, int i, int lo, int hi) {
+        const int row = acc_row(i, lane), k = 32 * (kb0 + t) + (lane & 31);
+        if (k < N && row < rows) {
+          const long o = (b0 + row) * N + k;
+          e[o] = (u16)((u32)(lo + hi + (int)mimg[row * N + k]) & (q - 1));
+          if (want_q) quotE[o] = (u16)((u32)(0 - hi) & (q - 1));
+        }
+      };
+      switch (nt) {
+        case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+        case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+        case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+        default: toeplitz_strip<M_ENC, 4>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+      }
+    });
+  }
+}
+
+// decryptBits on the matrix cores.  Product 1: a = f * e, e = lo7 + 128 hi (both digits non-negative, q <= 8192), planes
+// [e_lo | 2 e_hi] x [f ; 64 f]; centred lift (index.js:117 verbatim); product 2: c = fp * lifted, one plane.  The lifted
+// message goes from the accumulator layout (column per lane) to the operand stage (row per lane) through a 2-bit packed
+// LDS image [column][8 bytes] and one expansion pass.
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                             const uint8_t *__restrict__ fp,
+                                                             const u16 *__restrict__ e, long B,
+                                                             uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                             u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  u32 *TF = (u32 *)lds, *TP = TF + 4 * g.tpitch;
+  unsigned char *stLo = (unsigned char *)(TP + 4 * g.tpitch);
+  unsigned char *stHi = stLo + 32 * g.pitchA;
+  unsigned char *blp = stHi + 32 * g.pitchA;             // [32 NT columns][8]: 2 bits per row
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid, BLOCK_THREADS);
+  build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid, BLOCK_THREADS);
+  const bool want_q1 = quot1 != nullptr, want_r1 = rem1 != nullptr, want_q2 = quot2 != nullptr;
+  const long nrb = (B + 31) >> 5;
+  const int nch = 2 * g.NT;
+  const u32 qm2 = (q - 1) * 0x00010001u;
+  const int lane0 = lane;
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    int lane = lane0, N = g.N;                           // see k_encrypt_m
+    asm volatile("" : "+v"(lane), "+s"(N));
+    const u32 *tbf = frag_lane_base(TF, g, lane), *tbp = frag_lane_base(TP, g, lane);
+    const unsigned char *st0 = stLo + (lane & 31) * g.pitchA + 16 * (lane >> 5);
+    const unsigned char *st1 = stHi + (lane & 31) * g.pitchA + 16 * (lane >> 5);
+    u32 mlow[4];
+    diag_low_mask(lane, mlow);
+    const long b0 = rb << 5;
+    const int rows = (int)(B - b0 < 32 ? B - b0 : 32);
+    __syncthreads();
+    for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
+      for (int c16 = lane; c16 < nch; c16 += 64) {
+        u32 x[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};    // 16 coefficients as u16 pairs
+        if (row < rows) {
+          const u16 *src = e + (b0 + row) * N + 16 * c16;
+          if (16 * c16 + 16 <= N) {
+            const uint4 v0 = load16_unaligned(src), v1 = load16_unaligned(src + 8);
+            x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+          } else {
+            for (int j = 0; j < 16; j++) if (16 * c16 + j < N) x[j >> 1] |= (u32)src[j] << (16 * (j & 1));
+          }
+        }
+        u32 lo[4], hi[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const u32 xa = x[2 * c] & qm2, xb = x[2 * c + 1] & qm2;
+          lo[c] = __builtin_amdgcn_perm(xb & 0x007F007Fu, xa & 0x007F007Fu, 0x06040200u);
+          hi[c] = __builtin_amdgcn_perm((xb >> 6) & 0x00FE00FEu, (xa >> 6) & 0x00FE00FEu, 0x06040200u);
+        }
+        *(uint4 *)(stLo + row * g.pitchA + 16 * c16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *(uint4 *)(stHi + row * g.pitchA + 16 * c16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      }
+    }
+    __syncthreads();
+    // ---- product 1: a = f * e mod q; witness stores; lifted message -> packed image
+    for_each_strip(g.NT, wave, [&](int kb0, int nt) {
+      u32 pk = 0;
+      auto epi = [&](int t, int i, int lo, int hi) {
+        const int row = acc_row(i, lane), k = 32 * (kb0 + t) + (lane & 31);
+        const u32 x = (u32)(lo + hi) & (q - 1);
+        u32 bl = mod_small(2 * x > q ? x + 1 : x, p);
+        bl = k < N ? bl : 0u;
+        if (k < N && row < rows) {
+          const long o = (b0 + row) * N + k;
+          if (want_r1) rem1[o] = (u16)x;
+          if (want_q1) quot1[o] = (u16)((u32)(0 - hi) & (q - 1));
+        }
+        pk = (i & 3) ? (pk | (bl << (2 * (i & 3)))) : bl;
+        if ((i & 3) == 3) blp[(32 * (kb0 + t) + (lane & 31)) * 8 + 2 * (i >> 2) + (lane >> 5)] = (unsigned char)pk;
+      };
+      switch (nt) {
+        case 1: toeplitz_strip<M_DEC1, 1>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
+        case 2: toeplitz_strip<M_DEC1, 2>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
+        case 3: toeplitz_strip<M_DEC1, 3>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
+        default: toeplitz_strip<M_DEC1, 4>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
+      }
+    });
+    __syncthreads();                                    // every wave is done with the e stages; packed image complete
+    for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
+      const int rgb = 2 * (row >> 3) + ((row >> 2) & 1), sh = 2 * (row & 3);
+      for (int c4 = lane; c4 < 8 * g.NT; c4 += 64) {
+        u32 v = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) v |= (((u32)blp[(4 * c4 + jj) * 8 + rgb] >> sh) & 3u) << (8 * jj);
+        *(u32 *)(stLo + row * g.pitchA + 4 * c4) = v;
+      }
+    }
+    __syncthreads();
+    // ---- product 2: c = fp * lifted mod p
+    for_each_strip(g.NT, wave, [&](int kb0, int nt) {
+      auto epi = [&](int t, int i, int lo, int hi) {
+        const int row = acc_row(i, lane), k = 32 * (kb0 + t) + (lane & 31);
+        if (k < N && row < rows) {
+          const long o = (b0 + row) * N + k;
+          value[o] = (uint8_t)mod_small((u32)(lo + hi), p);
+          if (want_q2) { const u32 hm = mod_small((u32)hi, p); quot2[o] = (uint8_t)(hm ? p - hm : 0u); }
+        }
+      };
+      switch (nt) {
+        case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
+        case 2: toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
+        case 3: toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
+        default: toeplitz_strip<M_DEC2, 4>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
+      }
+    });
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
@@ -1616,7 +1974,7 @@ struct ntru_engine {
   int device;
   hipStream_t stream;
   int cus;
-  int path;     // 0 auto, 1 force the MAC kernels, 2 force the add path where it is applicable
+  int path;     // 0 auto, 1 MAC kernels, 2 add path, 3 add path without dot8, 4 matrix-core path (where applicable)
   char last_kernel[64];   // name of the kernel the last *_dev call launched (reporting only)
 };
 
@@ -1692,7 +2050,8 @@ extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
 
 extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (path < 0 || path > 3) return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add) or 3 (add without dot8)");
+  if (path < 0 || path > 4)
+    return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8) or 4 (matrix cores)");
   eng->path = path;
   return NTRU_OK;
 }
@@ -1768,6 +2127,17 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
   return K;
 }
 
+// Matrix-core path (family 4): shared key, q a power of two <= 8192 (two int8 digit planes), LDS for a 32-row block.
+static bool make_mgeom(const ntru_engine *eng, int N, int q, MGeom *g) {
+  if (eng->path != 0 && eng->path != 4) return false;
+  if (q > 8192 || N < (eng->path == 4 ? 2 : 64)) return false;
+  g->N = N;
+  g->NT = (N + 31) / 32;
+  g->pitchA = 32 * g->NT + 16;
+  g->tpitch = ((16 * g->NT + 31) / 32) * 32 + 8;
+  return true;
+}
+
 #define DISPATCH_K_SHARED(Kv, MEv, D8v, ...)                                                        \
   switch ((Kv) * 1000 + (MEv) * 10 + (D8v)) {                                                       \
     case 13131: { constexpr int KK = 13, MM = 13; constexpr bool DD = true; __VA_ARGS__; } break;   \
@@ -1841,6 +2211,20 @@ extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const ui
   if (!d_h || !d_r || !d_m || !d_e) return fail(NTRU_ERR_ARG, "ntru_encrypt_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
+  {
+    MGeom mg;
+    const size_t lds = make_mgeom(eng, N, q, &mg)
+                           ? (size_t)32 * mg.tpitch + (size_t)32 * mg.pitchA + (((size_t)32 * N + 15) & ~(size_t)15) + 16 : 0;
+    if (lds && lds <= 160 * 1024) {
+      if (int rc = allow_lds(k_encrypt_m, lds)) return rc;
+      if (int rc = resident_grid(eng, k_encrypt_m, lds, (long)((B + 31) / 32), &L.grid)) return rc;
+      snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_encrypt_m");
+      hipLaunchKernelGGL(k_encrypt_m, L.grid, dim3(BLOCK_THREADS), lds, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B,
+                         d_e, d_quotE);
+      HIP_TRY(hipGetLastError());
+      return NTRU_OK;
+    }
+  }
   if (const int me = add_path_me(eng, N, q)) {
     Geom g0 = make_geom(N, pick_K(N));
     if (int rc = plan_add(eng, N, B, (size_t)g0.eo_len * 8, (size_t)g0.nl * 4, &L)) return rc;
@@ -1876,6 +2260,20 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
   if (!d_f || !d_fp || !d_e || !d_value) return fail(NTRU_ERR_ARG, "ntru_decrypt_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
+  {
+    MGeom mg;
+    const size_t lds = (p == 3 && make_mgeom(eng, N, q, &mg))
+                           ? (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT : 0;
+    if (lds && lds <= 160 * 1024) {
+      if (int rc = allow_lds(k_decrypt_m, lds)) return rc;
+      if (int rc = resident_grid(eng, k_decrypt_m, lds, (long)((B + 31) / 32), &L.grid)) return rc;
+      snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_decrypt_m");
+      hipLaunchKernelGGL(k_decrypt_m, L.grid, dim3(BLOCK_THREADS), lds, eng->stream, mg, (u32)q, (u32)p, d_f, d_fp, d_e,
+                         (long)B, d_value, d_quot1, d_rem1, d_quot2);
+      HIP_TRY(hipGetLastError());
+      return NTRU_OK;
+    }
+  }
   {
     int me = 0;
     if (const int KS = shared_path_K(eng, N, q, p, &me)) {

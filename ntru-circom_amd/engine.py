@@ -124,7 +124,8 @@ class Engine:
         self._chk(self._lib.ntru_engine_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
 
     def set_kernel_path(self, path):
-        """0 auto, 1 packed-u16 MAC kernels, 2 ternary add path where applicable (same results)."""
+        """0 auto, 1 packed-u16 MAC kernels, 2 ternary add path, 3 add path without dot8, 4 int8 matrix-core path
+        (each where applicable; same results)."""
         self._chk(self._lib.ntru_engine_set_kernel_path(self._h, int(path)))
 
     def last_kernel(self):

@@ -129,7 +129,7 @@ def test_field_overflow_extremes(eng, N, q):
     hmax = np.full(N, q - 1)
     r = np.stack([np.ones(N), np.full(N, 2), np.arange(N) % 3, (np.arange(N) + 1) % 2 * 2]).astype(np.int64)
     m = np.full((4, N), 2)
-    for path in (0, 1, 2):
+    for path in (0, 1, 2, 3, 4):
         eng.set_kernel_path(path)
         try:
             e, quot = eng.encrypt_batch(N, q, hmax, r, m)
@@ -153,7 +153,7 @@ def test_kernel_families_agree(eng):
         f = ternary_rows(rng, 1, N, d, d - 1, two=-1)[0]
         r = ternary_rows(rng, 9, N, d, d); m = rng.integers(0, 2, (9, N))
         outs, names = [], []
-        for path in (1, 2, 0):
+        for path in (1, 2, 3, 4, 0):
             eng.set_kernel_path(path)
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             names.append(eng.last_kernel() if False else None)
@@ -163,6 +163,41 @@ def test_kernel_families_agree(eng):
         for o in outs[1:]:
             for a, b in zip(outs[0], o):
                 assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N,q,d", [(17, 32, 2), (31, 64, 5), (32, 128, 6), (33, 32, 7), (64, 8192, 20), (65, 4096, 21),
+                                   (167, 128, 18), (509, 2048, 169), (701, 8192, 233), (821, 4096, 273),
+                                   (1024, 8192, 300)])
+def test_matrix_core_path_equals_oracle(eng, N, q, d):
+    """Family 4 forced (ntru_engine_set_kernel_path 4), including sizes the automatic choice leaves to other
+    families, batches that do not fill a 32-row block, and h at the corners of the digit-plane range."""
+    rng = np.random.default_rng(N * 31 + q)
+    p = 3
+    eng.set_kernel_path(4)
+    try:
+        for B in (1, 31, 33, 70):
+            h = rng.integers(0, q, N)
+            h[:6] = np.array([q // 2 - 65, q // 2 - 64, q // 2 - 1, q // 2, q - 1, 0]) % q
+            f = ternary_rows(rng, 1, N, min(d + 1, N), min(d, N - min(d + 1, N)), two=-1)[0]
+            fp = rng.integers(0, p, N)
+            r = ternary_rows(rng, B, N, d, d)
+            m = rng.integers(0, 256, (B, N))
+            e, quot = eng.encrypt_batch(N, q, h, r, m)
+            assert eng.last_kernel() == "k_encrypt_m"
+            e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
+            assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
+            ein = e_o.copy()
+            ein[-1] = rng.integers(0, q, N)
+            ein[0, :4] = (q - 1, 0, q // 2, q // 2 + 1)
+            got = eng.decrypt_batch(N, q, p, f, fp, ein)
+            assert eng.last_kernel() == "k_decrypt_m"
+            want = orc.decrypt_batch(N, q, p, f, fp, ein)
+            for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
+                assert np.array_equal(g_, w_), (B, name)
+            v_only = eng.decrypt_batch(N, q, p, f, fp, ein, want_witness=False)
+            assert np.array_equal(v_only[0], want[0])
+    finally:
+        eng.set_kernel_path(0)
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 6, 7, 8, 13, 29, 257])
