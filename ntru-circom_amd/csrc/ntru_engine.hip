@@ -24,8 +24,10 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include "ntru_engine.h"
 
@@ -1633,6 +1635,13 @@ struct MGeom {
 
 enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
 
+// -DNTRU_ABLATE=1|2|3 builds timing-only variants (1: no result stores, 2: no matrix loops); never shipped.
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 1)
+#define ABL_STORE(x) && (x) == 0x7fffffff
+#else
+#define ABL_STORE(x)
+#endif
+
 template <class D>
 static __device__ __forceinline__ void build_toeplitz_array(u32 *T, const MGeom &g, D digit, int tid, int nthr) {
   const int Y0 = 32 * g.NT - 1;
@@ -1666,6 +1675,9 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
                                                       const unsigned char *__restrict__ st1,
                                                       const u32 *__restrict__ tb0, const u32 *__restrict__ tb1,
                                                       const MGeom &g, int kb0, const u32 (&mlow)[4], Epi epi) {
+#ifndef NTRU_ABLATE
+#define NTRU_ABLATE 0
+#endif
   constexpr bool TWO = MODE != M_DEC2;
   v16i accL[NT_S], accH[NT_S];
   v4i W0[NT_S], W1[NT_S];
@@ -1709,6 +1721,11 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
 #pragma unroll
   for (int t = 0; t < NT_S; t++) load_w(kb0 + t, W0[t], W1[t]);
   int ib = 0;
+#if NTRU_ABLATE & 2
+  const int kb0_ = kb0; kb0 = 0; const int NT_ = 0;
+#else
+  const int NT_ = g.NT;
+#endif
   for (; ib < kb0; ib++) {                             // every tile of the strip is above the diagonal: low
     v4i a0, a1;
     load_a(ib, a0, a1);
@@ -1734,7 +1751,7 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     }
     slide(kb0 + s + 1);
   }
-  for (ib = kb0 + NT_S; ib < g.NT; ib++) {             // below the diagonal: high
+  for (ib = kb0 + NT_S; ib < NT_; ib++) {              // below the diagonal: high
     v4i a0, a1;
     load_a(ib, a0, a1);
 #pragma unroll
@@ -1742,9 +1759,10 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     slide(ib + 1);
   }
 #pragma unroll
-  for (int t = 0; t < NT_S; t++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) epi(t, i, accL[t][i], accH[t][i]);
+  for (int t = 0; t < NT_S; t++) epi(t, accL[t], accH[t]);
+#if NTRU_ABLATE & 2
+  (void)kb0_;
+#endif
 }
 
 // This wave's share of the NT column tiles, cut into strips of at most 4 tiles; body(kb0, nt) per strip.
@@ -1782,6 +1800,95 @@ static __device__ __forceinline__ void diag_low_mask(int lane, u32 (&mlow)[4]) {
 // Row of result register i of a 32x32 accumulator tile held by this lane (column = lane & 31).
 static __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
+// Buffer descriptor of `bytes` bytes at p: loads beyond the end return 0 and stores beyond it are dropped, which is how
+// the rows of a partial last row block are handled (the row block is rebased so that in-block offsets are small).
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes < 0x7FFFF000L ? bytes : 0x7FFFF000L), 0x00020000);
+}
+
+// Reading rows whose pitch (N or 2N bytes, N odd) is not a multiple of 16: a per-lane 16-byte load at an unaligned
+// address runs at a fraction of the aligned rate (profiles/r01_ablation_mfma.txt: 0.8 of 2.5 ms), so rows are read as
+// ALIGNED 16-byte chunks and shifted in registers; the shift is wave-uniform because a wave stages one row at a time.
+// AlignedSrc: descriptor based at the 16-byte aligned address at or below p, a0 = p's offset in it; out-of-range
+// dwords read as zero (the range check is per dword, so the size is rounded up to whole dwords).
+struct AlignedSrc { __amdgpu_buffer_rsrc_t rs; int a0; };
+static __device__ __forceinline__ AlignedSrc aligned_src(const void *p, long bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  AlignedSrc s;
+  s.a0 = (int)(a & 15);
+  s.rs = rows_rsrc((const void *)(a & ~15ULL), (bytes + s.a0 + 3) & ~3L);
+  return s;
+}
+
+// NCH consecutive 16-byte chunks starting at byte `pos` (any alignment) of src, in two steps so that a caller can put
+// many loads in flight before the first shift: raw (NCH + 1 aligned chunks), then shift by sh = pos & 15 (wave-uniform:
+// the dword part of the shift is two rounds of selects on a scalar condition, the byte part one v_alignbyte each).
+template <int NCH>
+struct RawChunks { v4i c[NCH + 1]; };
+template <int NCH>
+static __device__ __forceinline__ RawChunks<NCH> load_raw(const AlignedSrc &src, int pos, int sh) {
+  RawChunks<NCH> r;
+#pragma unroll
+  for (int c = 0; c <= NCH; c++) r.c[c] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, pos - sh + 16 * c, 0, 0);
+  return r;
+}
+template <int NCH>
+static __device__ __forceinline__ void shift_raw(const RawChunks<NCH> &r, int sh, v4i (&out)[NCH]) {
+  u32 d[4 * NCH + 4];
+#pragma unroll
+  for (int c = 0; c <= NCH; c++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[4 * c + k] = (u32)r.c[c][k];
+  u32 m1 = (sh & 4) ? ~0u : 0u, m2 = (sh & 8) ? ~0u : 0u;   // bit selects (v_bfi): a select of neighbouring array
+  asm volatile("" : "+s"(m1), "+s"(m2));                      // elements would be turned into a dynamically indexed
+#pragma unroll                                                // (scratch) array
+  for (int k = 0; k < 4 * NCH + 3; k++) d[k] = (d[k + 1] & m1) | (d[k] & ~m1);
+#pragma unroll
+  for (int k = 0; k < 4 * NCH + 1; k++) d[k] = (d[k + 2] & m2) | (d[k] & ~m2);
+#pragma unroll
+  for (int k = 0; k < 4 * NCH; k++) out[k >> 2][k & 3] = (int)__builtin_amdgcn_alignbyte(d[k + 1], d[k], (u32)(sh & 3));
+}
+
+// Byte mask of the columns < N inside the 16-byte chunk starting at column c16 (all ones / partial / zero).
+static __device__ __forceinline__ v4i col_mask16(int c16, int N) {
+  v4i mk;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int left = N - (c16 + 4 * k);                  // valid bytes of this dword
+    mk[k] = left >= 4 ? -1 : (left <= 0 ? 0 : (int)((1u << (8 * left)) - 1u));
+  }
+  return mk;
+}
+
+// Copy rows [b0, b0+32) x [0, N) of a u8 batch array into a stage with 16-byte aligned rows, zero padded.  A wave
+// takes rows wave, wave+4, ...: all their loads are issued before the first shift.
+static __device__ __forceinline__ void stage_rows_u8(unsigned char *st, const MGeom &g, int N, const AlignedSrc &src,
+                                                     int wave, int lane) {
+  constexpr int RPW = 32 / WAVES_PER_BLOCK;
+  const int nch = 2 * g.NT;
+  for (int c = lane; c < nch; c += 64) {
+    RawChunks<1> raw[RPW];
+    int sh[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int pos0 = src.a0 + (wave + WAVES_PER_BLOCK * j) * N;
+      sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
+      raw[j].c[0] = raw[j].c[1] = (v4i){pos0, c, 2, 1};
+#else
+      raw[j] = load_raw<1>(src, pos0 + 16 * c, sh[j]);
+#endif
+    }
+    const v4i mk = col_mask16(16 * c, N);
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      v4i v[1];
+      shift_raw<1>(raw[j], sh[j], v);
+      *(v4i *)(st + (wave + WAVES_PER_BLOCK * j) * g.pitchA + 16 * c) = v[0] & mk;
+    }
+  }
+}
+
 // encryptBits on the matrix cores: e = (r * h + m) split by 1 - x^N; r in {0..3} bytes, h < q <= 8192.
 // h is taken in the representative hs = d0 + 128 d1, d0 in [-64,63], 4 d1 in [-128,124]; planes [r | 32 r] x [d0 ; 4 d1].
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, const u16 *__restrict__ h,
@@ -1791,57 +1898,74 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;
   unsigned char *stA = (unsigned char *)(T1 + 4 * g.tpitch);
-  unsigned char *mimg = stA + 32 * g.pitchA;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char *mimg = stA + 32 * g.pitchA;             // rows b0..b0+31 of m exactly as in memory (pitch N)
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int hthr = (int)(q >> 1) - 65;
   auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
-  build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, tid, BLOCK_THREADS);
-  build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid, BLOCK_THREADS);
+  build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, tid0, BLOCK_THREADS);
+  build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid0, BLOCK_THREADS);
   const bool want_q = quotE != nullptr;
   const long nrb = (B + 31) >> 5;
-  const int nch = 2 * g.NT;                              // 16-byte chunks per staged row
-  const int lane0 = lane, tid0 = tid;
   for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     // Re-materialise the lane index and N per row block: otherwise every per-lane address / predicate of the staging
-    // and of the 64-element epilogues is hoisted out of this loop and spilled around the matrix loops.
+    // and of the epilogues is hoisted out of this loop and spilled around the matrix loops.
     int lane = lane0, N = g.N, tid = tid0;
     asm volatile("" : "+v"(lane), "+s"(N), "+v"(tid));
     const u32 *tb0 = frag_lane_base(T0, g, lane), *tb1 = frag_lane_base(T1, g, lane);
     const unsigned char *st0 = stA + (lane & 31) * g.pitchA + 16 * (lane >> 5);
     u32 mlow[4];
     diag_low_mask(lane, mlow);
-    const long b0 = rb << 5;
-    const int rows = (int)(B - b0 < 32 ? B - b0 : 32);
+    const long b0 = rb << 5, left = (B - b0) * N;        // elements from this row block to the end of the batch
+    const AlignedSrc src_r = aligned_src(r + b0 * N, left), src_m = aligned_src(m + b0 * N, left);
+    const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + b0 * N, 2 * left);
+    const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quotE + b0 * N : e + b0 * N, 2 * left);
     __syncthreads();                                    // the previous row block's readers are done (first pass: key arrays built)
-    for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
-      for (int c = lane; c < nch; c += 64) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < rows) {
-          const uint8_t *src = r + (b0 + row) * N + 16 * c;
-          if (16 * c + 16 <= N) v = load16_unaligned(src);
-          else {
-            u32 w[4] = {0u, 0u, 0u, 0u};
-            for (int j = 0; j < 16; j++) if (16 * c + j < N) w[j >> 2] |= (u32)src[j] << (8 * (j & 3));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-          }
-        }
-        *(uint4 *)(stA + row * g.pitchA + 16 * c) = v;
-      }
-    }
+    stage_rows_u8(stA, g, N, src_r, wave, lane);
     {
-      const long total = (long)rows * N;
-      const uint8_t *msrc = m + b0 * N;
-      for (long i = (long)tid * 16; i + 16 <= total; i += BLOCK_THREADS * 16) *(uint4 *)(mimg + i) = load16_unaligned(msrc + i);
-      for (long i = (total & ~15L) + tid; i < total; i += BLOCK_THREADS) mimg[i] = msrc[i];
+      const int shm = __builtin_amdgcn_readfirstlane(src_m.a0);
+      for (int i0 = tid * 16; i0 < 32 * N; i0 += 8 * BLOCK_THREADS * 16) {
+        RawChunks<1> raw[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int i = i0 + j * BLOCK_THREADS * 16;
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 8)
+          raw[j].c[0] = raw[j].c[1] = (v4i){i, 1, 0, 1};
+#else
+          if (i < 32 * N) raw[j] = load_raw<1>(src_m, src_m.a0 + i, shm);
+#endif
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int i = i0 + j * BLOCK_THREADS * 16;
+          v4i v[1];
+          shift_raw<1>(raw[j], shm, v);
+          if (i < 32 * N) *(v4i *)(mimg + i) = v[0];
+        }
+      }
     }
     __syncthreads();
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
-      auto epi = [&](int t, int i, int lo, int hi) {
-        const int row = acc_row(i, lane), k = 32 * (kb0 + t) + (lane & 31);
-        if (k < N && row < rows) {
-          const long o = (b0 + row) * N + k;
-          e[o] = (u16)((u32)(lo + hi + (int)mimg[row * N + k]) & (q - 1));
-          if (want_q) quotE[o] = (u16)((u32)(0 - hi) & (q - 1));
+      // Result register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31: a per-lane offset
+      // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
+      const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
+      auto epi = [&](int t, const v16i &lo, const v16i &hi) {
+        const int kb = kb0 + t;
+        if (32 * kb + (lane & 31) < N) {
+          const unsigned char *m_l = mimg + 32 * kb + lane_off;
+          u32 mv[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) mv[i] = m_l[((i & 3) + 8 * (i >> 2)) * N];
+          auto out = [&](auto wq) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const int so = 2 * (((i & 3) + 8 * (i >> 2)) * N + 32 * kb);
+              if (true ABL_STORE(lo[i])) {
+                __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo[i] + hi[i] + (int)mv[i]) & (q - 1)), rs_e, 2 * lane_off, so, 0);
+                if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[i]) & (q - 1)), rs_q, 2 * lane_off, so, 0);
+              }
+            }
+          };
+          if (want_q) out(std::true_type{}); else out(std::false_type{});
         }
       };
       switch (nt) {
@@ -1868,14 +1992,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
   unsigned char *stLo = (unsigned char *)(TP + 4 * g.tpitch);
   unsigned char *stHi = stLo + 32 * g.pitchA;
   unsigned char *blp = stHi + 32 * g.pitchA;             // [32 NT columns][8]: 2 bits per row
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid, BLOCK_THREADS);
-  build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid, BLOCK_THREADS);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid0, BLOCK_THREADS);
+  build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid0, BLOCK_THREADS);
   const bool want_q1 = quot1 != nullptr, want_r1 = rem1 != nullptr, want_q2 = quot2 != nullptr;
   const long nrb = (B + 31) >> 5;
   const int nch = 2 * g.NT;
   const u32 qm2 = (q - 1) * 0x00010001u;
-  const int lane0 = lane;
   for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     int lane = lane0, N = g.N;                           // see k_encrypt_m
     asm volatile("" : "+v"(lane), "+s"(N));
@@ -1884,19 +2007,36 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     const unsigned char *st1 = stHi + (lane & 31) * g.pitchA + 16 * (lane >> 5);
     u32 mlow[4];
     diag_low_mask(lane, mlow);
-    const long b0 = rb << 5;
-    const int rows = (int)(B - b0 < 32 ? B - b0 : 32);
+    const long b0 = rb << 5, left = (B - b0) * N;
+    const AlignedSrc src_e = aligned_src(e + b0 * N, 2 * left);
+    const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value + b0 * N, left);
+    const __amdgpu_buffer_rsrc_t rs_r1 = rows_rsrc(want_r1 ? rem1 + b0 * N : nullptr, want_r1 ? 2 * left : 0);
+    const __amdgpu_buffer_rsrc_t rs_q1 = rows_rsrc(want_q1 ? quot1 + b0 * N : nullptr, want_q1 ? 2 * left : 0);
+    const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + b0 * N : nullptr, want_q2 ? left : 0);
     __syncthreads();
-    for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
-      for (int c16 = lane; c16 < nch; c16 += 64) {
-        u32 x[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};    // 16 coefficients as u16 pairs
-        if (row < rows) {
-          const u16 *src = e + (b0 + row) * N + 16 * c16;
-          if (16 * c16 + 16 <= N) {
-            const uint4 v0 = load16_unaligned(src), v1 = load16_unaligned(src + 8);
-            x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-          } else {
-            for (int j = 0; j < 16; j++) if (16 * c16 + j < N) x[j >> 1] |= (u32)src[j] << (16 * (j & 1));
+    for (int c16 = lane; c16 < nch; c16 += 64) {
+      constexpr int RPW = 32 / WAVES_PER_BLOCK;
+      RawChunks<2> raw[RPW];
+      int sh[RPW];
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * N;
+        sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
+        raw[j] = load_raw<2>(src_e, pos0 + 32 * c16, sh[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const int row = wave + WAVES_PER_BLOCK * j;
+        v4i v[2];                                        // 16 coefficients as u16 pairs
+        shift_raw<2>(raw[j], sh[j], v);
+        u32 x[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
+        if (16 * c16 + 16 > N) {                         // columns >= N of the last chunk(s) are zero
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const int left2 = N - (16 * c16 + 2 * c);
+            x[c] &= left2 >= 2 ? 0xFFFFFFFFu : (left2 == 1 ? 0x0000FFFFu : 0u);
           }
         }
         u32 lo[4], hi[4];
@@ -1911,21 +2051,40 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       }
     }
     __syncthreads();
+    const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
     // ---- product 1: a = f * e mod q; witness stores; lifted message -> packed image
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
-      u32 pk = 0;
-      auto epi = [&](int t, int i, int lo, int hi) {
-        const int row = acc_row(i, lane), k = 32 * (kb0 + t) + (lane & 31);
-        const u32 x = (u32)(lo + hi) & (q - 1);
-        u32 bl = mod_small(2 * x > q ? x + 1 : x, p);
-        bl = k < N ? bl : 0u;
-        if (k < N && row < rows) {
-          const long o = (b0 + row) * N + k;
-          if (want_r1) rem1[o] = (u16)x;
-          if (want_q1) quot1[o] = (u16)((u32)(0 - hi) & (q - 1));
+      auto epi = [&](int t, const v16i &lo, const v16i &hi) {
+        const int kb = kb0 + t;
+        const bool colv = 32 * kb + (lane & 31) < N;
+        unsigned char *pk_t = blp + (32 * kb + (lane & 31)) * 8 + (lane >> 5);
+        u32 xs[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          u32 pk = 0;
+#pragma unroll
+          for (int ii = 0; ii < 4; ii++) {
+            const u32 x = (u32)(lo[4 * j + ii] + hi[4 * j + ii]) & (q - 1);
+            xs[4 * j + ii] = x;
+            pk |= mod_small(2 * x > q ? x + 1 : x, p) << (2 * ii);
+          }
+          pk_t[2 * j] = (unsigned char)(colv ? pk : 0u);
         }
-        pk = (i & 3) ? (pk | (bl << (2 * (i & 3)))) : bl;
-        if ((i & 3) == 3) blp[(32 * (kb0 + t) + (lane & 31)) * 8 + 2 * (i >> 2) + (lane >> 5)] = (unsigned char)pk;
+        if (colv) {
+          auto out = [&](auto wr, auto wq) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const int so = 2 * (((i & 3) + 8 * (i >> 2)) * N + 32 * kb);
+              if (true ABL_STORE(lo[i])) {
+                if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)xs[i], rs_r1, 2 * lane_off, so, 0);
+                if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[i]) & (q - 1)), rs_q1, 2 * lane_off, so, 0);
+              }
+            }
+          };
+          if (want_r1 && want_q1) out(std::true_type{}, std::true_type{});
+          else if (want_r1) out(std::true_type{}, std::false_type{});
+          else if (want_q1) out(std::false_type{}, std::true_type{});
+        }
       };
       switch (nt) {
         case 1: toeplitz_strip<M_DEC1, 1>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
@@ -1947,12 +2106,23 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     __syncthreads();
     // ---- product 2: c = fp * lifted mod p
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
-      auto epi = [&](int t, int i, int lo, int hi) {
-        const int row = acc_row(i, lane), k = 32 * (kb0 + t) + (lane & 31);
-        if (k < N && row < rows) {
-          const long o = (b0 + row) * N + k;
-          value[o] = (uint8_t)mod_small((u32)(lo + hi), p);
-          if (want_q2) { const u32 hm = mod_small((u32)hi, p); quot2[o] = (uint8_t)(hm ? p - hm : 0u); }
+      auto epi = [&](int t, const v16i &lo, const v16i &hi) {
+        const int kb = kb0 + t;
+        if (32 * kb + (lane & 31) < N) {
+          auto out = [&](auto wq) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const int so = ((i & 3) + 8 * (i >> 2)) * N + 32 * kb;
+              if (true ABL_STORE(lo[i])) {
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod_small((u32)(lo[i] + hi[i]), p), rs_v, lane_off, so, 0);
+                if (decltype(wq)::value) {
+                  const u32 hm = mod_small((u32)hi[i], p);
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(hm ? p - hm : 0u), rs_q2, lane_off, so, 0);
+                }
+              }
+            }
+          };
+          if (want_q2) out(std::true_type{}); else out(std::false_type{});
         }
       };
       switch (nt) {
@@ -2171,6 +2341,10 @@ static int resident_grid(const ntru_engine *eng, Kern kern, size_t lds, long wor
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK_THREADS, lds));
   if (per_cu < 1) per_cu = 1;
+  if (const char *cap = getenv("NTRU_MAX_BLOCKS_PER_CU")) {      // tuning experiments only
+    const int c = atoi(cap);
+    if (c >= 1 && c < per_cu) per_cu = c;
+  }
   long blocks = (long)eng->cus * per_cu;
   if (blocks > work_blocks) blocks = work_blocks;
   *grid = dim3((unsigned)(blocks < 1 ? 1 : blocks));

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Timing-only ablations of the matrix-core kernels (never shipped, results unchecked):
+#   bit 1 = result stores disabled, 2 = matrix loops disabled, 4 = encrypt: r not loaded, 8 = encrypt: m not loaded;
+#   ABL_SET="3 7 11 15" selects the combinations (default 1 2 3).
+# Build here:   tools/ablate.sh build      -> ntru-circom_amd/lib/ab/libntru_abl{1,2,3}.so
+# Run on a GPU: tools/ablate.sh run [bench.py args]
+set -e
+cd "$(dirname "$0")/.."
+if [ "$1" = build ]; then
+  mkdir -p ntru-circom_amd/lib/ab
+  for a in ${ABL_SET:-1 2 3}; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -DNTRU_ABLATE=$a -shared \
+      -o ntru-circom_amd/lib/ab/libntru_abl$a.so ntru-circom_amd/csrc/ntru_engine.hip
+  done
+else
+  shift || true
+  python bench.py --no-cpu-baseline "$@" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("full      ", d["kernels_ms"])'
+  for a in ${ABL_SET:-1 2 3}; do
+    NTRU_BENCH_ABLATION=1 NTRU_ENGINE_LIB=$PWD/ntru-circom_amd/lib/ab/libntru_abl$a.so python bench.py --no-cpu-baseline "$@" \
+      | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("ablation '$a'", d["kernels_ms"], d["results_match_oracle"])'
+  done
+fi
