@@ -52,6 +52,11 @@ static __device__ __forceinline__ u32 as_u32(u16x2 v) { return __builtin_bit_cas
 
 // x mod a small runtime modulus; p = 3 (every NTRU parameter set) gets the constant-divisor sequence.
 static __device__ __forceinline__ u32 mod_small(u32 x, u32 m) { return m == 3u ? x % 3u : x % m; }
+// x mod 3 for x < 2^15 with 24-bit multiplies (the generic sequence uses the quarter-rate 32-bit multiply-high).
+static __device__ __forceinline__ u32 mod3_15(u32 x) {
+  const u32 qt = ((x & 0x7FFFu) * 0xAAABu) >> 17;       // operands provably below 2^24: v_mul_u32_u24
+  return x - 3u * qt;
+}
 
 // Order this wave's LDS writes before its later LDS reads (regions touched here are private to one wave).
 static __device__ __forceinline__ void wave_lds_fence() {
@@ -1631,7 +1636,16 @@ struct MGeom {
   int NT;       // 32-wide tiles per row: ceil(N / 32)
   int pitchA;   // bytes per row of an operand stage: 32 NT + 16
   int tpitch;   // dwords per byte-shifted copy of a reversed key array (= 8 mod 32: the 4 copies use disjoint banks)
+  int stagger;  // start delay (units of 64 x 127 cycles) of the second half of the grid, see stagger_start()
 };
+
+// Co-resident workgroups that start together run in lockstep (both stage, both multiply, both store) and never overlap
+// one's memory phases with the other's matrix phase; delaying the workgroups of the second dispatch round once, by
+// about half a row-block period, keeps them out of phase.
+static __device__ __forceinline__ void stagger_start(const MGeom &g) {
+  if (2 * blockIdx.x >= gridDim.x)
+    for (int i = 0; i < g.stagger; i++) __builtin_amdgcn_s_sleep(127);
+}
 
 enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
 
@@ -1713,51 +1727,59 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w0, acc, 0, 0, 0);
     if (TWO) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w1, acc, 0, 0, 0);
   };
-  auto slide = [&](int ib_next) {
-#pragma unroll
-    for (int t = NT_S - 1; t > 0; t--) { W0[t] = W0[t - 1]; W1[t] = W1[t - 1]; }
-    load_w(kb0 - ib_next, W0[0], W1[0]);
-  };
+  // Fragment window: at a step boundary slot t holds the fragment of tile t ("canonical").  A block of NT_S steps
+  // rotates through the slots with compile-time indices (no register moves) and ends canonical again: at sub-step u tile t
+  // uses slot (t - u) mod NT_S, and the fragment needed next replaces the one tile NT_S-1 just used.  Left-over steps
+  // slide the window physically.  The next operand fragment is requested before the current step's products.
 #pragma unroll
   for (int t = 0; t < NT_S; t++) load_w(kb0 + t, W0[t], W1[t]);
-  int ib = 0;
 #if NTRU_ABLATE & 2
   const int kb0_ = kb0; kb0 = 0; const int NT_ = 0;
 #else
   const int NT_ = g.NT;
 #endif
-  for (; ib < kb0; ib++) {                             // every tile of the strip is above the diagonal: low
-    v4i a0, a1;
-    load_a(ib, a0, a1);
-#pragma unroll
-    for (int t = 0; t < NT_S; t++) mm(accL[t], a0, a1, W0[t], W1[t]);
-    slide(ib + 1);
-  }
   u32 mhigh[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
+  v4i a0, a1;
+  load_a(0, a0, a1);
+  // kind: 0 = all tiles low, 1 = all high, 2 = the strip's own (diagonal) steps
+  auto block = [&](int ib, auto kind) {
 #pragma unroll
-  for (int s = 0; s < NT_S; s++) {                     // the strip's own contraction tiles: ib = kb0 + s
-    v4i a0, a1;
-    load_a(kb0 + s, a0, a1);
+    for (int u = 0; u < NT_S; u++) {
+      v4i n0, n1;
+      load_a(ib + u + 1, n0, n1);
 #pragma unroll
-    for (int t = 0; t < NT_S; t++) {
-      if (t > s) mm(accL[t], a0, a1, W0[t], W1[t]);
-      else if (t < s) mm(accH[t], a0, a1, W0[t], W1[t]);
-      else {
-        mm(accL[t], a0, a1, and4(W0[t], mlow), and4(W1[t], mlow));
-        mm(accH[t], a0, a1, and4(W0[t], mhigh), and4(W1[t], mhigh));
+      for (int t = 0; t < NT_S; t++) {
+        constexpr int K = decltype(kind)::value;
+        const int sl = (t - u + NT_S) % NT_S;
+        if (K == 0 || (K == 2 && t > u)) mm(accL[t], a0, a1, W0[sl], W1[sl]);
+        else if (K == 1 || (K == 2 && t < u)) mm(accH[t], a0, a1, W0[sl], W1[sl]);
+        else {
+          mm(accL[t], a0, a1, and4(W0[sl], mlow), and4(W1[sl], mlow));
+          mm(accH[t], a0, a1, and4(W0[sl], mhigh), and4(W1[sl], mhigh));
+        }
       }
+      load_w(kb0 - (ib + u + 1), W0[(NT_S - 1 - u) % NT_S], W1[(NT_S - 1 - u) % NT_S]);
+      a0 = n0; a1 = n1;
     }
-    slide(kb0 + s + 1);
-  }
-  for (ib = kb0 + NT_S; ib < NT_; ib++) {              // below the diagonal: high
-    v4i a0, a1;
-    load_a(ib, a0, a1);
+  };
+  auto single = [&](int ib, v16i (&acc)[NT_S]) {
+    v4i n0, n1;
+    load_a(ib + 1, n0, n1);
 #pragma unroll
-    for (int t = 0; t < NT_S; t++) mm(accH[t], a0, a1, W0[t], W1[t]);
-    slide(ib + 1);
-  }
+    for (int t = 0; t < NT_S; t++) mm(acc[t], a0, a1, W0[t], W1[t]);
+#pragma unroll
+    for (int t = NT_S - 1; t > 0; t--) { W0[t] = W0[t - 1]; W1[t] = W1[t - 1]; }
+    load_w(kb0 - (ib + 1), W0[0], W1[0]);
+    a0 = n0; a1 = n1;
+  };
+  int ib = 0;
+  for (; ib + NT_S <= kb0; ib += NT_S) block(ib, std::integral_constant<int, 0>{});   // above the diagonal: low
+  for (; ib < kb0; ib++) single(ib, accL);
+  block(kb0, std::integral_constant<int, 2>{});                                        // ib = kb0 .. kb0 + NT_S - 1
+  for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) block(ib, std::integral_constant<int, 1>{});   // below: high
+  for (; ib < NT_; ib++) single(ib, accH);
 #pragma unroll
   for (int t = 0; t < NT_S; t++) epi(t, accL[t], accH[t]);
 #if NTRU_ABLATE & 2
@@ -1902,6 +1924,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int hthr = (int)(q >> 1) - 65;
   auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
+  stagger_start(g);
   build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, tid0, BLOCK_THREADS);
   build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid0, BLOCK_THREADS);
   const bool want_q = quotE != nullptr;
@@ -1931,7 +1954,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 8)
           raw[j].c[0] = raw[j].c[1] = (v4i){i, 1, 0, 1};
 #else
-          if (i < 32 * N) raw[j] = load_raw<1>(src_m, src_m.a0 + i, shm);
+          raw[j] = load_raw<1>(src_m, src_m.a0 + i, shm);    // past the row block: next rows or zeros, not written
 #endif
         }
 #pragma unroll
@@ -1991,8 +2014,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
   u32 *TF = (u32 *)lds, *TP = TF + 4 * g.tpitch;
   unsigned char *stLo = (unsigned char *)(TP + 4 * g.tpitch);
   unsigned char *stHi = stLo + 32 * g.pitchA;
-  unsigned char *blp = stHi + 32 * g.pitchA;             // [32 NT columns][8]: 2 bits per row
+  unsigned char *blp = stHi + 32 * g.pitchA;             // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  stagger_start(g);
   build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid0, BLOCK_THREADS);
   build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid0, BLOCK_THREADS);
   const bool want_q1 = quot1 != nullptr, want_r1 = rem1 != nullptr, want_q2 = quot2 != nullptr;
@@ -2022,7 +2046,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       for (int j = 0; j < RPW; j++) {
         const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * N;
         sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
+        raw[j].c[0] = raw[j].c[1] = raw[j].c[2] = (v4i){pos0, c16, 2, 1};
+#else
         raw[j] = load_raw<2>(src_e, pos0 + 32 * c16, sh[j]);
+#endif
       }
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
@@ -2057,7 +2085,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       auto epi = [&](int t, const v16i &lo, const v16i &hi) {
         const int kb = kb0 + t;
         const bool colv = 32 * kb + (lane & 31) < N;
-        unsigned char *pk_t = blp + (32 * kb + (lane & 31)) * 8 + (lane >> 5);
+        unsigned char *pk_t = blp + (lane >> 5) * 32 * g.NT + 32 * kb + (lane & 31);   // [row group 2j+hh][column]
         u32 xs[16];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -2066,9 +2094,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
           for (int ii = 0; ii < 4; ii++) {
             const u32 x = (u32)(lo[4 * j + ii] + hi[4 * j + ii]) & (q - 1);
             xs[4 * j + ii] = x;
-            pk |= mod_small(2 * x > q ? x + 1 : x, p) << (2 * ii);
+            pk |= mod3_15(2 * x > q ? x + 1 : x) << (2 * ii);
           }
-          pk_t[2 * j] = (unsigned char)(colv ? pk : 0u);
+          pk_t[2 * j * 32 * g.NT] = (unsigned char)(colv ? pk : 0u);
         }
         if (colv) {
           auto out = [&](auto wr, auto wq) {
@@ -2096,12 +2124,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     __syncthreads();                                    // every wave is done with the e stages; packed image complete
     for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
       const int rgb = 2 * (row >> 3) + ((row >> 2) & 1), sh = 2 * (row & 3);
-      for (int c4 = lane; c4 < 8 * g.NT; c4 += 64) {
-        u32 v = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) v |= (((u32)blp[(4 * c4 + jj) * 8 + rgb] >> sh) & 3u) << (8 * jj);
-        *(u32 *)(stLo + row * g.pitchA + 4 * c4) = v;
-      }
+      const u32 *src = (const u32 *)(blp + rgb * 32 * g.NT);
+      for (int c4 = lane; c4 < 8 * g.NT; c4 += 64) *(u32 *)(stLo + row * g.pitchA + 4 * c4) = (src[c4] >> sh) & 0x03030303u;
     }
     __syncthreads();
     // ---- product 2: c = fp * lifted mod p
@@ -2114,11 +2138,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
             for (int i = 0; i < 16; i++) {
               const int so = ((i & 3) + 8 * (i >> 2)) * N + 32 * kb;
               if (true ABL_STORE(lo[i])) {
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod_small((u32)(lo[i] + hi[i]), p), rs_v, lane_off, so, 0);
-                if (decltype(wq)::value) {
-                  const u32 hm = mod_small((u32)hi[i], p);
-                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(hm ? p - hm : 0u), rs_q2, lane_off, so, 0);
-                }
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15((u32)(lo[i] + hi[i])), rs_v, lane_off, so, 0);
+                if (decltype(wq)::value)                 // -hi = 2 hi (mod 3)
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15(2u * (u32)hi[i]), rs_q2, lane_off, so, 0);
               }
             }
           };
@@ -2305,6 +2327,8 @@ static bool make_mgeom(const ntru_engine *eng, int N, int q, MGeom *g) {
   g->NT = (N + 31) / 32;
   g->pitchA = 32 * g->NT + 16;
   g->tpitch = ((16 * g->NT + 31) / 32) * 32 + 8;
+  g->stagger = 0;
+  if (const char *st = getenv("NTRU_STAGGER")) g->stagger = atoi(st);
   return true;
 }
 
