@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PK_MAC_PEAK_T = 75.6           # measured v_pk_mad_u16 roof, profiles/r01_microbench_valu_lds.txt (T MAC/s)
+MFMA_I8_PEAK_T = 5000.0        # dense int8 MFMA = 2 x bf16 (~2.5 PFLOP/s), MI355X_MICROARCH.md "Matrix cores"
 DOT8_PEAK_T = 302.0            # measured v_dot8_u32_u4 roof: 37.9 T lane-instr/s x 8 nibble MACs
 ADD_PEAK_T = 134.0             # measured v_add_u32 roof 67 T lane-adds/s x 2 packed 16-bit coefficients per add
 
@@ -39,7 +40,7 @@ def parse_args():
                     help="witness: every array the reference returns; value: ciphertext / plaintext only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-path", choices=["auto", "mac", "add"], default="auto",
+    ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix"], default="auto",
                     help="kernel family: packed-u16 MAC, ternary add path, or the engine's choice (same results)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for rehearsing the launch path on one GPU")
@@ -164,7 +165,7 @@ def main():
         key = np.arange(8, dtype=np.uint32) * 0x9E3779B1 + 20240
         eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
         torch.cuda.synchronize()
-    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2}[args.kernel_path])
+    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4}[args.kernel_path])
 
     names = {}
 
@@ -219,7 +220,21 @@ def main():
         dec_s = dec_ms * 1e-3
         dname = names.get("decrypt", "k_decrypt")
         add_path = dname.startswith(("k_decrypt_s", "k_decrypt_t"))
-        if "+dot8" in dname:
+        mfma = None
+        if dname == "k_decrypt_m":
+            # int8 matrix path: decrypt = 3 plane-products (e_lo, e_hi against f; lifted against fp), each 27 tile
+            # products per 32x32 output tile on a 32-padded grid (26 x 26 tiles at N = 821)
+            NT = (N + 31) // 32
+            n_mfma = 3.0 * NT * (NT + 1) * ((B + 31) // 32)
+            ops = 2.0 * 32768 * n_mfma
+            mfma = {"kernel": dname, "achieved": ops / dec_s / 1e12, "peak": MFMA_I8_PEAK_T, "unit": "TOP/s (int8, executed)",
+                    "frac": ops / dec_s / 1e12 / MFMA_I8_PEAK_T, "instructions_per_launch": n_mfma,
+                    "algorithmic_TOPs_per_s": 2.0 * 2.0 * N * N * B / dec_s / 1e12,
+                    "note": "v_mfma_i32_32x32x32_i8; peak = dense int8 (2x bf16, MI355X_MICROARCH.md); measured issue roof "
+                            "4400 TOP/s (profiles/r01_microbench_mfma_i8.txt); algorithmic = 2 N^2 MACs per decrypt"}
+            valu = {"kernel": dname, "achieved": mfma["achieved"], "peak": MFMA_I8_PEAK_T, "unit": mfma["unit"],
+                    "note": "see `mfma`"}
+        elif "+dot8" in dname:
             # product 1 steps over f (adds), product 2 is all N^2 nibble MACs on v_dot8_u32_u4
             w1, w2 = float(np.count_nonzero(f_np)) * N * B, float(N) * N * B
             ideal_s = w1 / (ADD_PEAK_T * 1e12) + w2 / (DOT8_PEAK_T * 1e12)
@@ -257,8 +272,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dname, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dname, args.mode, args.batch_log2),
                          "algorithmic_bytes_per_item": dec_bytes, "algorithmic_bytes_per_launch": dec_bytes * B,
-                         "note": "the path is VALU/scalar-issue bound (O(N^2) integer work on O(N) bytes); see `valu`"},
+                         "note": ("matrix-core path: HBM traffic and int8 MFMA issue are within a factor of two of each "
+                                  "other; the MFMA side is reported in `mfma`") if mfma else
+                                 "the path is VALU/scalar-issue bound (O(N^2) integer work on O(N) bytes); see `valu`"},
             "valu": valu,
+            "mfma": mfma,
             "hbm_gbs_round_trip": (dec_bytes + enc_bytes) * B / ((dec_ms + enc_ms) * 1e-3) / 1e9,
         }
         if ablation:       # timing-only build of the engine (tools/ablate.sh): results are NOT checked, not a benchmark line

@@ -1780,25 +1780,23 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   block(kb0, std::integral_constant<int, 2>{});                                        // ib = kb0 .. kb0 + NT_S - 1
   for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) block(ib, std::integral_constant<int, 1>{});   // below: high
   for (; ib < NT_; ib++) single(ib, accH);
-#pragma unroll
-  for (int t = 0; t < NT_S; t++) epi(t, accL[t], accH[t]);
+  epi(accL, accH);
 #if NTRU_ABLATE & 2
   (void)kb0_;
 #endif
 }
 
-// This wave's share of the NT column tiles, cut into strips of at most 4 tiles; body(kb0, nt) per strip.
+// The NT column tiles are cut into 4 R strips of at most 4 tiles (sizes as even as possible, in column order); in round
+// rho the four waves take the adjacent strips 4 rho .. 4 rho + 3, so neighbouring strips are stored at about the same
+// time and the cache lines they share are completed in L2 instead of being written to HBM twice.  body(kb0, nt).
 template <class Body>
 static __device__ __forceinline__ void for_each_strip(int NT, int wave, Body body) {
-  const int base = NT / WAVES_PER_BLOCK, extra = NT % WAVES_PER_BLOCK;
-  const int share = base + (wave < extra ? 1 : 0);
-  int kb = wave * base + (wave < extra ? wave : extra);
-  if (share == 0) return;
-  const int n_str = (share + 3) >> 2;
-  for (int s = 0; s < n_str; s++) {
-    const int nt = share / n_str + (s < share % n_str ? 1 : 0);
-    body(kb, nt);
-    kb += nt;
+  const int rounds = (((NT + 3) >> 2) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int n_str = rounds * WAVES_PER_BLOCK, base = NT / n_str, rem = NT % n_str;
+  for (int rho = 0; rho < rounds; rho++) {
+    const int j = rho * WAVES_PER_BLOCK + wave;
+    const int nt = base + (j < rem ? 1 : 0);
+    if (nt > 0) body(j * base + (j < rem ? j : rem), nt);
   }
 }
 
@@ -1971,25 +1969,27 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
       // Result register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31: a per-lane offset
       // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
       const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
-      auto epi = [&](int t, const v16i &lo, const v16i &hi) {
-        const int kb = kb0 + t;
-        if (32 * kb + (lane & 31) < N) {
-          const unsigned char *m_l = mimg + 32 * kb + lane_off;
-          u32 mv[16];
+      auto epi = [&](auto &lo, auto &hi) {               // arrays of the strip's tiles
+        constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        const unsigned char *m_l = mimg + 32 * kb0 + lane_off;
+        auto out = [&](auto wq) {
 #pragma unroll
-          for (int i = 0; i < 16; i++) mv[i] = m_l[((i & 3) + 8 * (i >> 2)) * N];
-          auto out = [&](auto wq) {
+          for (int i = 0; i < 16; i++) {                 // one row (per half-wave) at a time, across the strip's tiles
+            const int ro = (i & 3) + 8 * (i >> 2);
+            u32 mv[NTS];
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-              const int so = 2 * (((i & 3) + 8 * (i >> 2)) * N + 32 * kb);
-              if (true ABL_STORE(lo[i])) {
-                __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo[i] + hi[i] + (int)mv[i]) & (q - 1)), rs_e, 2 * lane_off, so, 0);
-                if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[i]) & (q - 1)), rs_q, 2 * lane_off, so, 0);
+            for (int t = 0; t < NTS; t++) mv[t] = m_l[ro * N + 32 * t];
+#pragma unroll
+            for (int t = 0; t < NTS; t++) {
+              const int so = 2 * (ro * N + 32 * (kb0 + t));
+              if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
+                __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo[t][i] + hi[t][i] + (int)mv[t]) & (q - 1)), rs_e, 2 * lane_off, so, 0);
+                if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q, 2 * lane_off, so, 0);
               }
             }
-          };
-          if (want_q) out(std::true_type{}); else out(std::false_type{});
-        }
+          }
+        };
+        if (want_q) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
         case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
@@ -2082,37 +2082,39 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
     // ---- product 1: a = f * e mod q; witness stores; lifted message -> packed image
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
-      auto epi = [&](int t, const v16i &lo, const v16i &hi) {
-        const int kb = kb0 + t;
-        const bool colv = 32 * kb + (lane & 31) < N;
-        unsigned char *pk_t = blp + (lane >> 5) * 32 * g.NT + 32 * kb + (lane & 31);   // [row group 2j+hh][column]
-        u32 xs[16];
+      auto epi = [&](auto &lo, auto &hi) {
+        constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        auto out = [&](auto wr, auto wq) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          u32 pk = 0;
+          for (int j = 0; j < 4; j++) {
+            u32 pk[NTS];
 #pragma unroll
-          for (int ii = 0; ii < 4; ii++) {
-            const u32 x = (u32)(lo[4 * j + ii] + hi[4 * j + ii]) & (q - 1);
-            xs[4 * j + ii] = x;
-            pk |= mod3_15(2 * x > q ? x + 1 : x) << (2 * ii);
-          }
-          pk_t[2 * j * 32 * g.NT] = (unsigned char)(colv ? pk : 0u);
-        }
-        if (colv) {
-          auto out = [&](auto wr, auto wq) {
+            for (int t = 0; t < NTS; t++) pk[t] = 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-              const int so = 2 * (((i & 3) + 8 * (i >> 2)) * N + 32 * kb);
-              if (true ABL_STORE(lo[i])) {
-                if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)xs[i], rs_r1, 2 * lane_off, so, 0);
-                if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[i]) & (q - 1)), rs_q1, 2 * lane_off, so, 0);
+            for (int ii = 0; ii < 4; ii++) {
+              const int i = 4 * j + ii, ro = ii + 8 * j;
+#pragma unroll
+              for (int t = 0; t < NTS; t++) {
+                const u32 x = (u32)(lo[t][i] + hi[t][i]) & (q - 1);
+                pk[t] |= mod3_15(2 * x > q ? x + 1 : x) << (2 * ii);
+                const int so = 2 * (ro * N + 32 * (kb0 + t));
+                if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
+                  if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, 2 * lane_off, so, 0);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, 2 * lane_off, so, 0);
+                }
               }
             }
-          };
-          if (want_r1 && want_q1) out(std::true_type{}, std::true_type{});
-          else if (want_r1) out(std::true_type{}, std::false_type{});
-          else if (want_q1) out(std::false_type{}, std::true_type{});
-        }
+#pragma unroll
+            for (int t = 0; t < NTS; t++) {
+              const int col = 32 * (kb0 + t) + (lane & 31);
+              blp[((lane >> 5) + 2 * j) * 32 * g.NT + col] = (unsigned char)(col < N ? pk[t] : 0u);   // [row group 2j+hh][column]
+            }
+          }
+        };
+        if (want_r1 && want_q1) out(std::true_type{}, std::true_type{});
+        else if (want_r1) out(std::true_type{}, std::false_type{});
+        else if (want_q1) out(std::false_type{}, std::true_type{});
+        else out(std::false_type{}, std::false_type{});
       };
       switch (nt) {
         case 1: toeplitz_strip<M_DEC1, 1>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
@@ -2130,22 +2132,23 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     __syncthreads();
     // ---- product 2: c = fp * lifted mod p
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
-      auto epi = [&](int t, const v16i &lo, const v16i &hi) {
-        const int kb = kb0 + t;
-        if (32 * kb + (lane & 31) < N) {
-          auto out = [&](auto wq) {
+      auto epi = [&](auto &lo, auto &hi) {
+        constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        auto out = [&](auto wq) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-              const int so = ((i & 3) + 8 * (i >> 2)) * N + 32 * kb;
-              if (true ABL_STORE(lo[i])) {
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15((u32)(lo[i] + hi[i])), rs_v, lane_off, so, 0);
+          for (int i = 0; i < 16; i++) {
+#pragma unroll
+            for (int t = 0; t < NTS; t++) {
+              const int so = ((i & 3) + 8 * (i >> 2)) * N + 32 * (kb0 + t);
+              if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15((u32)(lo[t][i] + hi[t][i])), rs_v, lane_off, so, 0);
                 if (decltype(wq)::value)                 // -hi = 2 hi (mod 3)
-                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15(2u * (u32)hi[i]), rs_q2, lane_off, so, 0);
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15(2u * (u32)hi[t][i]), rs_q2, lane_off, so, 0);
               }
             }
-          };
-          if (want_q2) out(std::true_type{}); else out(std::false_type{});
-        }
+          }
+        };
+        if (want_q2) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
         case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;

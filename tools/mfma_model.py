@@ -78,18 +78,18 @@ def mfma(a, b, acc):
     return acc + A @ Bm
 
 
-def strips(NT, waves=4, max_nt=4):
-    """Tile ranges per wave: shares as even as possible, each share cut into strips of at most max_nt tiles."""
-    out, kb = [], 0
-    for w in range(waves):
-        share = NT // waves + (1 if w < NT % waves else 0)
-        ws = []
-        n_str = -(-share // max_nt) if share else 0
-        for s in range(n_str):
-            nt = share // n_str + (1 if s < share % n_str else 0)
-            ws.append((kb, nt)); kb += nt
-        out.append(ws)
-    assert kb == NT
+def strips(NT, waves=4):
+    """4 R strips of <= 4 tiles in column order; in round rho wave w takes strip 4 rho + w (adjacent strips are produced
+    at the same time).  Returns per wave the list of (kb0, nt)."""
+    rounds = -(-(-(-NT // 4)) // waves)
+    n_str = rounds * waves
+    base, rem = NT // n_str, NT % n_str
+    out = [[] for _ in range(waves)]
+    for j in range(n_str):
+        nt = base + (1 if j < rem else 0)
+        if nt:
+            out[j % waves].append((j * base + min(j, rem), nt))
+    assert sum(nt for w in out for _, nt in w) == NT and max(nt for w in out for _, nt in w) <= 4
     return out
 
 

@@ -23,11 +23,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    """rocprof's demangled template name -> the name ntru_engine_last_kernel / bench.py report."""
-    m = re.match(r"(?:void )?(k_[a-z_]+)<([0-9a-z, ]+)>", name)
+    """rocprof's demangled kernel name -> the name ntru_engine_last_kernel / bench.py report."""
+    m = re.match(r"(?:void )?(k_[a-z_0-9]+)(?:<([0-9a-z, ]+)>)?\(", name)
     if not m:
         return None
-    fam, args = m.group(1), [x.strip() for x in m.group(2).split(",")]
+    fam = m.group(1)
+    if m.group(2) is None:
+        return fam
+    args = [x.strip() for x in m.group(2).split(",")]
     if args[-1] in ("true", "false"):                      # k_decrypt_s<K, ME, D8>
         fam += "+dot8" if args.pop() == "true" else ""
     return "%s<%s>" % (fam, ",".join(args))
