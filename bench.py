@@ -279,6 +279,25 @@ def main():
             "mfma": mfma,
             "hbm_gbs_round_trip": (dec_bytes + enc_bytes) * B / ((dec_ms + enc_ms) * 1e-3) / 1e9,
         }
+        if world == 1 and args.kernel_path == "auto" and names.get("decrypt", "").endswith("_m"):
+            # The wavefront-per-ciphertext VALU families (BASELINE north_star's design), same buffers, outside the timed
+            # region: a few steps, and their outputs must equal the ones just verified.
+            ref_out = [t.clone() for t in (e, value)]
+            eng.set_kernel_path(2)
+            step(); torch.cuda.synchronize()
+            same = all(bool(torch.equal(a, b)) for a, b in zip(ref_out, (e, value)))
+            alt_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(3)]
+            for ev in alt_ev:
+                step(ev)
+            torch.cuda.synchronize()
+            a_enc = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in alt_ev]))
+            a_dec = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in alt_ev]))
+            out["valu_families"] = {"value": B / ((a_enc + a_dec) * 1e-3), "unit": "round_trips/s",
+                                    "kernels_ms": {names["encrypt"]: a_enc, names["decrypt"]: a_dec},
+                                    "outputs_equal_matrix_path": same,
+                                    "note": "ntru_engine_set_kernel_path(2): one ciphertext per wavefront, no MFMA; kernel "
+                                            "times only, 3 steps"}
+            eng.set_kernel_path(0)
         if ablation:       # timing-only build of the engine (tools/ablate.sh): results are NOT checked, not a benchmark line
             out = {"ABLATION_NOT_A_RESULT": os.environ["NTRU_ENGINE_LIB"], "results_match_oracle": bool(ok),
                    "kernels_ms": out["kernels_ms"], "ms_per_step": out["ms_per_step"]}
