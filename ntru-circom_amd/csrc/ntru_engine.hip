@@ -1630,22 +1630,16 @@ __global__ void k_unpack(int bits, int per, int packed_size, const unsigned long
 // the measurements behind the layout choices.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+#ifndef ST_AUX
+#define ST_AUX 0     // cache policy bits of the result stores (0 measured best; 2 = non-temporal is 1.6x slower)
+#endif
 
 struct MGeom {
   int N;        // ring size
   int NT;       // 32-wide tiles per row: ceil(N / 32)
   int pitchA;   // bytes per row of an operand stage: 32 NT + 16
   int tpitch;   // dwords per byte-shifted copy of a reversed key array (= 8 mod 32: the 4 copies use disjoint banks)
-  int stagger;  // start delay (units of 64 x 127 cycles) of the second half of the grid, see stagger_start()
 };
-
-// Co-resident workgroups that start together run in lockstep (both stage, both multiply, both store) and never overlap
-// one's memory phases with the other's matrix phase; delaying the workgroups of the second dispatch round once, by
-// about half a row-block period, keeps them out of phase.
-static __device__ __forceinline__ void stagger_start(const MGeom &g) {
-  if (2 * blockIdx.x >= gridDim.x)
-    for (int i = 0; i < g.stagger; i++) __builtin_amdgcn_s_sleep(127);
-}
 
 enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
 
@@ -1823,7 +1817,12 @@ static __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) 
 // Buffer descriptor of `bytes` bytes at p: loads beyond the end return 0 and stores beyond it are dropped, which is how
 // the rows of a partial last row block are handled (the row block is rebased so that in-block offsets are small).
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *p, long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes < 0x7FFFF000L ? bytes : 0x7FFFF000L), 0x00020000);
+  // the operands are wave-uniform; saying so keeps the descriptor in scalar registers (a descriptor the compiler takes
+  // for divergent turns every access into a waterfall loop)
+  const unsigned long long a = (unsigned long long)p;
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)a), hi = __builtin_amdgcn_readfirstlane((u32)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFF000L ? bytes : 0x7FFFF000L));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
 }
 
 // Reading rows whose pitch (N or 2N bytes, N odd) is not a multiple of 16: a per-lane 16-byte load at an unaligned
@@ -1922,7 +1921,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int hthr = (int)(q >> 1) - 65;
   auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
-  stagger_start(g);
   build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, tid0, BLOCK_THREADS);
   build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid0, BLOCK_THREADS);
   const bool want_q = quotE != nullptr;
@@ -1938,8 +1936,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
     diag_low_mask(lane, mlow);
     const long b0 = rb << 5, left = (B - b0) * N;        // elements from this row block to the end of the batch
     const AlignedSrc src_r = aligned_src(r + b0 * N, left), src_m = aligned_src(m + b0 * N, left);
-    const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + b0 * N, 2 * left);
-    const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quotE + b0 * N : e + b0 * N, 2 * left);
     __syncthreads();                                    // the previous row block's readers are done (first pass: key arrays built)
     stage_rows_u8(stA, g, N, src_r, wave, lane);
     {
@@ -1968,23 +1964,40 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
       // Result register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31: a per-lane offset
       // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
+      // (Packing 4 columns per lane with in-quad transposes and 64-bit stores was measured 8 % slower: the rows are only
+      // 2-byte aligned.)
       const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
       auto epi = [&](auto &lo, auto &hi) {               // arrays of the strip's tiles
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        long bb = b0;                                    // descriptors made where they are used: see k_decrypt_m
+        asm volatile("" : "+s"(bb));
+        const long lf = (B - bb) * N;
+        const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + bb * N, 2 * lf);
+        const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quotE + bb * N : e + bb * N, 2 * lf);
         const unsigned char *m_l = mimg + 32 * kb0 + lane_off;
         auto out = [&](auto wq) {
 #pragma unroll
-          for (int i = 0; i < 16; i++) {                 // one row (per half-wave) at a time, across the strip's tiles
-            const int ro = (i & 3) + 8 * (i >> 2);
-            u32 mv[NTS];
+          for (int j = 0; j < 4; j++) {                  // 4 rows per half-wave at a time, across the strip's tiles
+            u32 mv[NTS][4];
 #pragma unroll
-            for (int t = 0; t < NTS; t++) mv[t] = m_l[ro * N + 32 * t];
+            for (int t = 0; t < NTS; t++)
+#pragma unroll
+              for (int ii = 0; ii < 4; ii++) mv[t][ii] = m_l[(8 * j + ii) * N + 32 * t];
 #pragma unroll
             for (int t = 0; t < NTS; t++) {
-              const int so = 2 * (ro * N + 32 * (kb0 + t));
-              if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
-                __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo[t][i] + hi[t][i] + (int)mv[t]) & (q - 1)), rs_e, 2 * lane_off, so, 0);
-                if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q, 2 * lane_off, so, 0);
+              const int so = 2 * (8 * j * N + 32 * (kb0 + t));
+              u32 ev[4], qv[4];
+#pragma unroll
+              for (int ii = 0; ii < 4; ii++) {
+                ev[ii] = (u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + (int)mv[t][ii]) & (q - 1);
+                qv[ii] = (u32)(0 - hi[t][4 * j + ii]) & (q - 1);
+              }
+              if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][4 * j])) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ii++) {
+                  __builtin_amdgcn_raw_buffer_store_b16((u16)ev[ii], rs_e, 2 * lane_off, so + 2 * ii * N, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)qv[ii], rs_q, 2 * lane_off, so + 2 * ii * N, ST_AUX);
+                }
               }
             }
           }
@@ -2015,10 +2028,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
   unsigned char *stLo = (unsigned char *)(TP + 4 * g.tpitch);
   unsigned char *stHi = stLo + 32 * g.pitchA;
   unsigned char *blp = stHi + 32 * g.pitchA;             // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
+  unsigned char *lift_lut = blp + 256 * g.NT;            // [q]: centred lift followed by mod p, index.js:117 verbatim
+  unsigned char *m3_lut = stHi;                          // [(p-1)^2 N + 1], rebuilt per row block once the e stages are dead:
+                                                         // x mod p in bits 0-1, (-x) mod p in bits 2-3
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  stagger_start(g);
   build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid0, BLOCK_THREADS);
   build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid0, BLOCK_THREADS);
+  for (u32 x = tid0; x < q; x += BLOCK_THREADS) lift_lut[x] = (unsigned char)mod_small(2 * x > q ? x + 1 : x, p);
   const bool want_q1 = quot1 != nullptr, want_r1 = rem1 != nullptr, want_q2 = quot2 != nullptr;
   const long nrb = (B + 31) >> 5;
   const int nch = 2 * g.NT;
@@ -2033,10 +2049,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     diag_low_mask(lane, mlow);
     const long b0 = rb << 5, left = (B - b0) * N;
     const AlignedSrc src_e = aligned_src(e + b0 * N, 2 * left);
-    const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value + b0 * N, left);
-    const __amdgpu_buffer_rsrc_t rs_r1 = rows_rsrc(want_r1 ? rem1 + b0 * N : nullptr, want_r1 ? 2 * left : 0);
-    const __amdgpu_buffer_rsrc_t rs_q1 = rows_rsrc(want_q1 ? quot1 + b0 * N : nullptr, want_q1 ? 2 * left : 0);
-    const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + b0 * N : nullptr, want_q2 ? left : 0);
     __syncthreads();
     for (int c16 = lane; c16 < nch; c16 += 64) {
       constexpr int RPW = 32 / WAVES_PER_BLOCK;
@@ -2084,6 +2096,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
       auto epi = [&](auto &lo, auto &hi) {
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        // descriptors are made here, from a re-materialised row-block base, so that they live in scalar registers only
+        // while they are used (held across the matrix loops they are spilled to VGPRs and every store becomes a
+        // waterfall loop)
+        long bb = b0;
+        asm volatile("" : "+s"(bb));
+        const long lf = (B - bb) * N;
+        const __amdgpu_buffer_rsrc_t rs_r1 = rows_rsrc(want_r1 ? rem1 + bb * N : nullptr, want_r1 ? 2 * lf : 0);
+        const __amdgpu_buffer_rsrc_t rs_q1 = rows_rsrc(want_q1 ? quot1 + bb * N : nullptr, want_q1 ? 2 * lf : 0);
         auto out = [&](auto wr, auto wq) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -2096,11 +2116,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
 #pragma unroll
               for (int t = 0; t < NTS; t++) {
                 const u32 x = (u32)(lo[t][i] + hi[t][i]) & (q - 1);
-                pk[t] |= mod3_15(2 * x > q ? x + 1 : x) << (2 * ii);
+                pk[t] |= (u32)lift_lut[x] << (2 * ii);
                 const int so = 2 * (ro * N + 32 * (kb0 + t));
                 if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
-                  if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, 2 * lane_off, so, 0);
-                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, 2 * lane_off, so, 0);
+                  if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, 2 * lane_off, so, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, 2 * lane_off, so, ST_AUX);
                 }
               }
             }
@@ -2124,6 +2144,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       }
     });
     __syncthreads();                                    // every wave is done with the e stages; packed image complete
+    for (int x = tid0; x <= (int)((p - 1) * (p - 1)) * N; x += BLOCK_THREADS) {
+      const u32 rm = mod_small((u32)x, p);
+      m3_lut[x] = (unsigned char)(rm | ((rm ? p - rm : 0u) << 2));
+    }
     for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
       const int rgb = 2 * (row >> 3) + ((row >> 2) & 1), sh = 2 * (row & 3);
       const u32 *src = (const u32 *)(blp + rgb * 32 * g.NT);
@@ -2134,6 +2158,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
       auto epi = [&](auto &lo, auto &hi) {
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        long bb = b0;                                    // see product 1
+        asm volatile("" : "+s"(bb));
+        const long lf = (B - bb) * N;
+        const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value + bb * N, lf);
+        const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + bb * N : nullptr, want_q2 ? lf : 0);
         auto out = [&](auto wq) {
 #pragma unroll
           for (int i = 0; i < 16; i++) {
@@ -2141,9 +2170,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
             for (int t = 0; t < NTS; t++) {
               const int so = ((i & 3) + 8 * (i >> 2)) * N + 32 * (kb0 + t);
               if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15((u32)(lo[t][i] + hi[t][i])), rs_v, lane_off, so, 0);
-                if (decltype(wq)::value)                 // -hi = 2 hi (mod 3)
-                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)mod3_15(2u * (u32)hi[t][i]), rs_q2, lane_off, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(m3_lut[lo[t][i] + hi[t][i]] & 3), rs_v, lane_off, so, ST_AUX);
+                if (decltype(wq)::value)
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(m3_lut[hi[t][i]] >> 2), rs_q2, lane_off, so, ST_AUX);
               }
             }
           }
@@ -2330,8 +2359,6 @@ static bool make_mgeom(const ntru_engine *eng, int N, int q, MGeom *g) {
   g->NT = (N + 31) / 32;
   g->pitchA = 32 * g->NT + 16;
   g->tpitch = ((16 * g->NT + 31) / 32) * 32 + 8;
-  g->stagger = 0;
-  if (const char *st = getenv("NTRU_STAGGER")) g->stagger = atoi(st);
   return true;
 }
 
@@ -2464,7 +2491,7 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
   {
     MGeom mg;
     const size_t lds = (p == 3 && make_mgeom(eng, N, q, &mg))
-                           ? (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT : 0;
+                           ? (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT + (((size_t)q + 15) & ~(size_t)15) : 0;
     if (lds && lds <= 160 * 1024) {
       if (int rc = allow_lds(k_decrypt_m, lds)) return rc;
       if (int rc = resident_grid(eng, k_decrypt_m, lds, (long)((B + 31) / 32), &L.grid)) return rc;
