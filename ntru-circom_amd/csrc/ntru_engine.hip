@@ -1769,11 +1769,13 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     a0 = n0; a1 = n1;
   };
   int ib = 0;
+  __builtin_amdgcn_s_setprio(3);       // the partner wave on this SIMD is usually in a VALU phase: decrypt -3 %
   for (; ib + NT_S <= kb0; ib += NT_S) block(ib, std::integral_constant<int, 0>{});   // above the diagonal: low
   for (; ib < kb0; ib++) single(ib, accL);
   block(kb0, std::integral_constant<int, 2>{});                                        // ib = kb0 .. kb0 + NT_S - 1
   for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) block(ib, std::integral_constant<int, 1>{});   // below: high
   for (; ib < NT_; ib++) single(ib, accH);
+  __builtin_amdgcn_s_setprio(0);
   epi(accL, accH);
 #if NTRU_ABLATE & 2
   (void)kb0_;
@@ -1840,30 +1842,35 @@ static __device__ __forceinline__ AlignedSrc aligned_src(const void *p, long byt
 }
 
 // NCH consecutive 16-byte chunks starting at byte `pos` (any alignment) of src, in two steps so that a caller can put
-// many loads in flight before the first shift: raw (NCH + 1 aligned chunks), then shift by sh = pos & 15 (wave-uniform:
-// the dword part of the shift is two rounds of selects on a scalar condition, the byte part one v_alignbyte each).
+// many loads in flight before the first shift: raw (dword-aligned loads: a 4-byte aligned 16-byte load runs at the full
+// rate, only sub-dword misalignment is slow), then one v_alignbyte per dword by pos & 3.
 template <int NCH>
-struct RawChunks { v4i c[NCH + 1]; };
+struct RawChunks { v4i c[NCH]; u32 tail; };
 template <int NCH>
-static __device__ __forceinline__ RawChunks<NCH> load_raw(const AlignedSrc &src, int pos, int sh) {
+static __device__ __forceinline__ RawChunks<NCH> load_raw(const AlignedSrc &src, int pos, int) {
+  RawChunks<NCH> r;
+  const int al = pos & ~3;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) r.c[c] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, al + 16 * c, 0, 0);
+  r.tail = __builtin_amdgcn_raw_buffer_load_b32(src.rs, al + 16 * NCH, 0, 0);
+  return r;
+}
+template <int NCH>
+static __device__ __forceinline__ RawChunks<NCH> fake_raw(int v) {        // timing-only builds (NTRU_ABLATE)
   RawChunks<NCH> r;
 #pragma unroll
-  for (int c = 0; c <= NCH; c++) r.c[c] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, pos - sh + 16 * c, 0, 0);
+  for (int c = 0; c < NCH; c++) r.c[c] = (v4i){v, 1, 2, 1};
+  r.tail = 0;
   return r;
 }
 template <int NCH>
 static __device__ __forceinline__ void shift_raw(const RawChunks<NCH> &r, int sh, v4i (&out)[NCH]) {
-  u32 d[4 * NCH + 4];
+  u32 d[4 * NCH + 1];
 #pragma unroll
-  for (int c = 0; c <= NCH; c++)
+  for (int c = 0; c < NCH; c++)
 #pragma unroll
     for (int k = 0; k < 4; k++) d[4 * c + k] = (u32)r.c[c][k];
-  u32 m1 = (sh & 4) ? ~0u : 0u, m2 = (sh & 8) ? ~0u : 0u;   // bit selects (v_bfi): a select of neighbouring array
-  asm volatile("" : "+s"(m1), "+s"(m2));                      // elements would be turned into a dynamically indexed
-#pragma unroll                                                // (scratch) array
-  for (int k = 0; k < 4 * NCH + 3; k++) d[k] = (d[k + 1] & m1) | (d[k] & ~m1);
-#pragma unroll
-  for (int k = 0; k < 4 * NCH + 1; k++) d[k] = (d[k + 2] & m2) | (d[k] & ~m2);
+  d[4 * NCH] = r.tail;
 #pragma unroll
   for (int k = 0; k < 4 * NCH; k++) out[k >> 2][k & 3] = (int)__builtin_amdgcn_alignbyte(d[k + 1], d[k], (u32)(sh & 3));
 }
@@ -1893,7 +1900,7 @@ static __device__ __forceinline__ void stage_rows_u8(unsigned char *st, const MG
       const int pos0 = src.a0 + (wave + WAVES_PER_BLOCK * j) * N;
       sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
-      raw[j].c[0] = raw[j].c[1] = (v4i){pos0, c, 2, 1};
+      raw[j] = fake_raw<1>(pos0 + c);
 #else
       raw[j] = load_raw<1>(src, pos0 + 16 * c, sh[j]);
 #endif
@@ -1946,7 +1953,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
         for (int j = 0; j < 8; j++) {
           const int i = i0 + j * BLOCK_THREADS * 16;
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 8)
-          raw[j].c[0] = raw[j].c[1] = (v4i){i, 1, 0, 1};
+          raw[j] = fake_raw<1>(i);
 #else
           raw[j] = load_raw<1>(src_m, src_m.a0 + i, shm);    // past the row block: next rows or zeros, not written
 #endif
@@ -2059,7 +2066,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * N;
         sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
-        raw[j].c[0] = raw[j].c[1] = raw[j].c[2] = (v4i){pos0, c16, 2, 1};
+        raw[j] = fake_raw<2>(pos0 + c16);
 #else
         raw[j] = load_raw<2>(src_e, pos0 + 32 * c16, sh[j]);
 #endif
