@@ -200,6 +200,52 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d):
         eng.set_kernel_path(0)
 
 
+@pytest.mark.parametrize("N,q", [(821, 4096), (167, 128), (701, 8192)])
+def test_device_pointers_at_any_alignment(eng, N, q):
+    """The *_dev entry points take any pointer: the matrix-core kernels read rows through aligned chunks + shifts and
+    write through byte/short stores, so buffers that start at odd byte offsets must give the same results."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N + q)
+    p, B, d = 3, 45, N // 3
+    h = rng.integers(0, q, N); f = ternary_rows(rng, 1, N, d, d - 1, two=-1)[0]; fp = rng.integers(0, p, N)
+    r = ternary_rows(rng, B, N, d, d); m = rng.integers(0, 256, (B, N))
+    e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
+    want = orc.decrypt_batch(N, q, p, f, fp, e_o)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for off in (1, 2, 3, 5, 14, 15):
+            def place(a, dtype, elt):                    # copy `a` into a byte buffer at byte offset off * elt' (u16 stays 2-aligned)
+                raw = np.ascontiguousarray(a.astype(dtype)).view(np.uint8).ravel()
+                o = off * elt
+                buf = torch.zeros(raw.size + 64, dtype=torch.uint8, device=dev)
+                buf[o:o + raw.size] = torch.from_numpy(raw).to(dev)
+                return buf, buf.data_ptr() + o
+            def out(nbytes, elt):
+                buf = torch.full((nbytes + 64,), 0xAB, dtype=torch.uint8, device=dev)
+                return buf, buf.data_ptr() + off * elt
+            hb, hp = place(h, np.uint16, 2); rb, rp = place(r, np.uint8, 1); mb, mp = place(m, np.uint8, 1)
+            fb, fpp = place(f, np.int8, 1); fpb, fppp = place(fp, np.uint8, 1)
+            eb, ep = out(2 * B * N, 2); qb, qp = out(2 * B * N, 2)
+            eng.encrypt_batch_dev(N, q, hp, rp, mp, B, ep, qp)
+            vb, vp = out(B * N, 1); q1b, q1p = out(2 * B * N, 2); r1b, r1p = out(2 * B * N, 2); q2b, q2p = out(B * N, 1)
+            eng.decrypt_batch_dev(N, q, p, fpp, fppp, ep, B, vp, q1p, r1p, q2p)
+            torch.cuda.synchronize()
+            def back(buf, elt, dtype, n):
+                o = off * elt
+                a = buf.cpu().numpy()
+                assert (a[:o] == 0xAB).all() and (a[o + n * np.dtype(dtype).itemsize:] == 0xAB).all()   # nothing outside
+                return a[o:o + n * np.dtype(dtype).itemsize].view(dtype).reshape(B, N)
+            assert np.array_equal(back(eb, 2, np.uint16, B * N), e_o), off
+            assert np.array_equal(back(qb, 2, np.uint16, B * N), quot_o), off
+            got = (back(vb, 1, np.uint8, B * N), back(q1b, 2, np.uint16, B * N), back(r1b, 2, np.uint16, B * N),
+                   back(q2b, 1, np.uint8, B * N))
+            for g_, w_ in zip(got, want):
+                assert np.array_equal(g_, w_), off
+    finally:
+        eng.set_stream(None)
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 6, 7, 8, 13, 29, 257])
 def test_ragged_batch_sizes(eng, B):
     # N=17 packs 7 items per wavefront, N=167 two: batches that do not fill a wave / a workgroup
