@@ -1776,6 +1776,12 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) block(ib, std::integral_constant<int, 1>{});   // below: high
   for (; ib < NT_; ib++) single(ib, accH);
   __builtin_amdgcn_s_setprio(0);
+#if NTRU_ABLATE & 128
+  if (MODE == M_DEC1) { if (accL[0][0] == 0x7fffffff) epi(accL, accH); return; }
+#endif
+#if NTRU_ABLATE & 256
+  if (MODE == M_DEC2) { if (accL[0][0] == 0x7fffffff) epi(accL, accH); return; }
+#endif
   epi(accL, accH);
 #if NTRU_ABLATE & 2
   (void)kb0_;
@@ -2113,17 +2119,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         const __amdgpu_buffer_rsrc_t rs_q1 = rows_rsrc(want_q1 ? quot1 + bb * N : nullptr, want_q1 ? 2 * lf : 0);
         auto out = [&](auto wr, auto wq) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            u32 pk[NTS];
-#pragma unroll
-            for (int t = 0; t < NTS; t++) pk[t] = 0;
+          for (int j = 0; j < 4; j++) {                  // 4 rows x the strip's tiles at a time: remainders (and their
+            u32 xs[NTS][4], lv[NTS][4];                  // stores), then their table lookups in flight together, then packing
 #pragma unroll
             for (int ii = 0; ii < 4; ii++) {
               const int i = 4 * j + ii, ro = ii + 8 * j;
 #pragma unroll
               for (int t = 0; t < NTS; t++) {
                 const u32 x = (u32)(lo[t][i] + hi[t][i]) & (q - 1);
-                pk[t] |= (u32)lift_lut[x] << (2 * ii);
+                xs[t][ii] = x;
                 const int so = 2 * (ro * N + 32 * (kb0 + t));
                 if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
                   if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, 2 * lane_off, so, ST_AUX);
@@ -2132,9 +2136,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
               }
             }
 #pragma unroll
+            for (int t = 0; t < NTS; t++)
+#pragma unroll
+              for (int ii = 0; ii < 4; ii++) lv[t][ii] = lift_lut[xs[t][ii]];
+#pragma unroll
             for (int t = 0; t < NTS; t++) {
               const int col = 32 * (kb0 + t) + (lane & 31);
-              blp[((lane >> 5) + 2 * j) * 32 * g.NT + col] = (unsigned char)(col < N ? pk[t] : 0u);   // [row group 2j+hh][column]
+              const u32 pk = lv[t][0] | (lv[t][1] << 2) | (lv[t][2] << 4) | (lv[t][3] << 6);
+              blp[((lane >> 5) + 2 * j) * 32 * g.NT + col] = (unsigned char)(col < N ? pk : 0u);   // [row group 2j+hh][column]
             }
           }
         };
@@ -2151,15 +2160,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       }
     });
     __syncthreads();                                    // every wave is done with the e stages; packed image complete
+#if !(NTRU_ABLATE & 64)
     for (int x = tid0; x <= (int)((p - 1) * (p - 1)) * N; x += BLOCK_THREADS) {
       const u32 rm = mod_small((u32)x, p);
       m3_lut[x] = (unsigned char)(rm | ((rm ? p - rm : 0u) << 2));
     }
+#endif
+#if !(NTRU_ABLATE & 32)
     for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
       const int rgb = 2 * (row >> 3) + ((row >> 2) & 1), sh = 2 * (row & 3);
       const u32 *src = (const u32 *)(blp + rgb * 32 * g.NT);
       for (int c4 = lane; c4 < 8 * g.NT; c4 += 64) *(u32 *)(stLo + row * g.pitchA + 4 * c4) = (src[c4] >> sh) & 0x03030303u;
     }
+#endif
     __syncthreads();
     // ---- product 2: c = fp * lifted mod p
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
@@ -2172,14 +2185,24 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + bb * N : nullptr, want_q2 ? lf : 0);
         auto out = [&](auto wq) {
 #pragma unroll
-          for (int i = 0; i < 16; i++) {
+          for (int j = 0; j < 4; j++) {                  // lookups of 4 rows x the strip's tiles in flight before their stores
+            u32 va[NTS][4], vb[NTS][4];
 #pragma unroll
-            for (int t = 0; t < NTS; t++) {
-              const int so = ((i & 3) + 8 * (i >> 2)) * N + 32 * (kb0 + t);
-              if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(m3_lut[lo[t][i] + hi[t][i]] & 3), rs_v, lane_off, so, ST_AUX);
-                if (decltype(wq)::value)
-                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(m3_lut[hi[t][i]] >> 2), rs_q2, lane_off, so, ST_AUX);
+            for (int t = 0; t < NTS; t++)
+#pragma unroll
+              for (int ii = 0; ii < 4; ii++) {
+                va[t][ii] = m3_lut[lo[t][4 * j + ii] + hi[t][4 * j + ii]];
+                vb[t][ii] = decltype(wq)::value ? (u32)m3_lut[hi[t][4 * j + ii]] : 0u;
+              }
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+#pragma unroll
+              for (int t = 0; t < NTS; t++) {
+                const int so = (ii + 8 * j) * N + 32 * (kb0 + t);
+                if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][4 * j + ii])) {
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(va[t][ii] & 3), rs_v, lane_off, so, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(vb[t][ii] >> 2), rs_q2, lane_off, so, ST_AUX);
+                }
               }
             }
           }
