@@ -1508,9 +1508,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_verify_keys_t(
 // ---- on-device ternary sampler: generateCustomArray (index.js:461-488) for one item per LANE ---------------------
 // Same procedure as the reference: [1]*n1 ++ [other]*n2 ++ [0]*..., then for i = N-1 .. 1: j = u32 % (i+1), swap.
 // The u32 of step t of item b is word t of the ChaCha20 keystream (RFC 8439 block function) under the caller's key with
-// nonce (b_lo, b_hi, "NTRU"), so any host can replay it with a stock ChaCha20.  The Fisher-Yates chain
-// is inherently sequential per item, so items are spread over lanes; each lane's row lives in LDS (pitch = odd number
-// of dwords: the lock-step accesses row[i] of all lanes hit distinct banks).
+// nonce (b_lo, b_hi, "NTRU"), so any host can replay it with a stock ChaCha20.  The Fisher-Yates chain is inherently
+// sequential per item, so items are spread over lanes.  A lane's row lives in LDS as 2-bit symbols (0, 1, 2 = `other`),
+// 16 per dword, pitch = odd number of dwords (the lock-step accesses of all lanes hit distinct banks): 13 KB per wave
+// instead of 52 KB as bytes, i.e. 12 waves per CU instead of 3.  i is wave-uniform, so u32 % (i+1) is a multiply by a
+// per-step reciprocal from an LDS table (floor(2^32 / d), one correction) instead of a 35-instruction division.
 struct ChaChaKey { u32 k[8]; };
 
 #define CHACHA_QR(a, b, c, d)                                                          \
@@ -1519,25 +1521,26 @@ struct ChaChaKey { u32 k[8]; };
 
 __global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u32 other, ChaChaKey key,
                                                        unsigned long long first_item, long B,
-                                                       uint8_t *__restrict__ out, int pitch) {
+                                                       uint8_t *__restrict__ out, int pd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  u32 *recip = (u32 *)lds;                               // [N + 1]: floor(2^32 / d)
+  u32 *rows = recip + ((N + 2) & ~1);                    // [64][pd] dwords of 16 symbols
   const int lane = threadIdx.x;
-  const int pd = pitch >> 2;
+  for (int d = lane; d <= N; d += 64) recip[d] = d >= 2 ? (u32)(0x100000000ULL / (unsigned)d) : 0u;
   for (long base = (long)blockIdx.x * 64; base < B; base += (long)gridDim.x * 64) {
     // all 64 rows start identical: fill them cooperatively, one dword at a time
     for (int idx = lane; idx < 64 * pd; idx += 64) {
-      const int c = (idx % pd) * 4;
+      const int c = (idx % pd) * 16;
       u32 w = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < 16; b++) {
         const int k = c + b;
-        const u32 v = k < n1 ? 1u : (k < n1 + n2 ? other : 0u);
-        w |= v << (8 * b);
+        w |= (k < n1 ? 1u : (k < n1 + n2 ? 2u : 0u)) << (2 * b);
       }
-      ((u32 *)lds)[idx] = w;
+      rows[idx] = w;
     }
     wave_lds_fence();
-    unsigned char *row = lds + (size_t)lane * pitch;
+    u32 *row = rows + (size_t)lane * pd;
     const unsigned long long item = first_item + (unsigned long long)(base + lane);
     const u32 n0 = (u32)item, nn1 = (u32)(item >> 32), nn2 = 0x4e545255u;
     int i = N - 1;
@@ -1555,20 +1558,29 @@ __global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u3
 #pragma unroll
       for (int w = 0; w < 16; w++) {
         if (i >= 1) {
-          const u32 j = ks[w] % (u32)(i + 1);
-          const unsigned char a = row[i], b = row[j];
-          row[i] = b; row[j] = a;
+          const u32 d = (u32)(i + 1);
+          u32 j = ks[w] - __umulhi(ks[w], recip[d]) * d;               // in [0, 2d)
+          j = j >= d ? j - d : j;
+          const int wi = i >> 4, si = 2 * (i & 15), wj = (int)(j >> 4), sj = 2 * (int)(j & 15);
+          const u32 a = row[wi], b = row[wj];
+          const u32 x = ((a >> si) ^ (b >> sj)) & 3u;                    // swap two 2-bit fields by their difference
+          const u32 na = a ^ (x << si);
+          row[wi] = na;
+          row[wj] = (wi == wj ? na : b) ^ (x << sj);                     // same dword: the second store wins
           i--;
         }
       }
     }
     wave_lds_fence();
-    // rows -> row-major output, coalesced: the wave walks one row at a time
+    // rows -> row-major byte output, coalesced: the wave walks one row at a time
     for (int rr = 0; rr < 64; rr++) {
       if (base + rr >= B) break;
       uint8_t *dst = out + (size_t)(base + rr) * N;
-      const unsigned char *src = lds + (size_t)rr * pitch;
-      for (int k = lane; k < N; k += 64) dst[k] = src[k];
+      const u32 *src = rows + (size_t)rr * pd;
+      for (int k = lane; k < N; k += 64) {
+        const u32 sym = (src[k >> 4] >> (2 * (k & 15))) & 3u;
+        dst[k] = (uint8_t)(sym == 2u ? other : sym);
+      }
     }
     wave_lds_fence();
   }
@@ -2872,7 +2884,7 @@ extern "C" int ntru_add_batch(ntru_engine_t *eng, int N, int mod, const uint16_t
   return NTRU_OK;
 }
 
-static int sampler_pitch(int N) { int pd = (N + 3) / 4; if ((pd & 1) == 0) pd++; return pd * 4; }
+static int sampler_pitch(int N) { int pd = (N + 15) / 16; if ((pd & 1) == 0) pd++; return pd; }   // dwords of 16 symbols
 
 extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
                                        uint64_t first_item, int64_t B, uint8_t *d_out) {
@@ -2884,7 +2896,7 @@ extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2
   if (B == 0) return NTRU_OK;
   if (!d_out) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: NULL buffer");
   const int pitch = sampler_pitch(N);
-  const size_t lds = (size_t)64 * pitch;
+  const size_t lds = (size_t)64 * pitch * 4 + (size_t)((N + 2) & ~1) * 4;
   if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the sampler's LDS rows");
   HIP_TRY(hipSetDevice(eng->device));
   ChaChaKey ck;
