@@ -1655,6 +1655,24 @@ struct MGeom {
 
 enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
 
+// -DNTRU_STAMPS: diagnostic build that records s_memtime at the phase boundaries of the matrix-core kernels for the
+// first row blocks of each workgroup (tools/phase_stamps.py reads them back); no stamp executes in the shipped library.
+#ifdef NTRU_STAMPS
+#define STAMP_SLOTS 24
+#define STAMP_BLOCKS 6
+__device__ unsigned long long g_stamps[1024][4][STAMP_BLOCKS][STAMP_SLOTS];
+#define STAMP(slot)                                                                                          \
+  do {                                                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024 && stamp_iter < STAMP_BLOCKS)                           \
+      g_stamps[blockIdx.x][threadIdx.x >> 6][stamp_iter][slot] = __builtin_amdgcn_s_memtime();               \
+  } while (0)
+extern "C" int ntru_debug_read_stamps(void *dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 // -DNTRU_ABLATE=1|2|3 builds timing-only variants (1: no result stores, 2: no matrix loops); never shipped.
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 1)
 #define ABL_STORE(x) && (x) == 0x7fffffff
@@ -1694,7 +1712,8 @@ template <int MODE, int NT_S, class Epi>
 static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__restrict__ st0,
                                                       const unsigned char *__restrict__ st1,
                                                       const u32 *__restrict__ tb0, const u32 *__restrict__ tb1,
-                                                      const MGeom &g, int kb0, const u32 (&mlow)[4], Epi epi) {
+                                                      const MGeom &g, int kb0, const u32 (&mlow)[4], Epi epi,
+                                                      int stamp_iter = 0, int stamp_base = 0) {
 #ifndef NTRU_ABLATE
 #define NTRU_ABLATE 0
 #endif
@@ -1788,6 +1807,7 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) block(ib, std::integral_constant<int, 1>{});   // below: high
   for (; ib < NT_; ib++) single(ib, accH);
   __builtin_amdgcn_s_setprio(0);
+  STAMP(stamp_base);
 #if NTRU_ABLATE & 128
   if (MODE == M_DEC1) { if (accL[0][0] == 0x7fffffff) epi(accL, accH); return; }
 #endif
@@ -1795,6 +1815,7 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   if (MODE == M_DEC2) { if (accL[0][0] == 0x7fffffff) epi(accL, accH); return; }
 #endif
   epi(accL, accH);
+  STAMP(stamp_base + 1);
 #if NTRU_ABLATE & 2
   (void)kb0_;
 #endif
@@ -1904,35 +1925,6 @@ static __device__ __forceinline__ v4i col_mask16(int c16, int N) {
   return mk;
 }
 
-// Copy rows [b0, b0+32) x [0, N) of a u8 batch array into a stage with 16-byte aligned rows, zero padded.  A wave
-// takes rows wave, wave+4, ...: all their loads are issued before the first shift.
-static __device__ __forceinline__ void stage_rows_u8(unsigned char *st, const MGeom &g, int N, const AlignedSrc &src,
-                                                     int wave, int lane) {
-  constexpr int RPW = 32 / WAVES_PER_BLOCK;
-  const int nch = 2 * g.NT;
-  for (int c = lane; c < nch; c += 64) {
-    RawChunks<1> raw[RPW];
-    int sh[RPW];
-#pragma unroll
-    for (int j = 0; j < RPW; j++) {
-      const int pos0 = src.a0 + (wave + WAVES_PER_BLOCK * j) * N;
-      sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
-      raw[j] = fake_raw<1>(pos0 + c);
-#else
-      raw[j] = load_raw<1>(src, pos0 + 16 * c, sh[j]);
-#endif
-    }
-    const v4i mk = col_mask16(16 * c, N);
-#pragma unroll
-    for (int j = 0; j < RPW; j++) {
-      v4i v[1];
-      shift_raw<1>(raw[j], sh[j], v);
-      *(v4i *)(st + (wave + WAVES_PER_BLOCK * j) * g.pitchA + 16 * c) = v[0] & mk;
-    }
-  }
-}
-
 // encryptBits on the matrix cores: e = (r * h + m) split by 1 - x^N; r in {0..3} bytes, h < q <= 8192.
 // h is taken in the representative hs = d0 + 128 d1, d0 in [-64,63], 4 d1 in [-128,124]; planes [r | 32 r] x [d0 ; 4 d1].
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, const u16 *__restrict__ h,
@@ -1950,7 +1942,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
   build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid0, BLOCK_THREADS);
   const bool want_q = quotE != nullptr;
   const long nrb = (B + 31) >> 5;
+  int sidx = 0, stamp_iter = -1;
   for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    stamp_iter++;
+    STAMP(0);
     // Re-materialise the lane index and N per row block: otherwise every per-lane address / predicate of the staging
     // and of the epilogues is hoisted out of this loop and spilled around the matrix loops.
     int lane = lane0, N = g.N, tid = tid0;
@@ -1961,31 +1956,56 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
     diag_low_mask(lane, mlow);
     const long b0 = rb << 5, left = (B - b0) * N;        // elements from this row block to the end of the batch
     const AlignedSrc src_r = aligned_src(r + b0 * N, left), src_m = aligned_src(m + b0 * N, left);
-    __syncthreads();                                    // the previous row block's readers are done (first pass: key arrays built)
-    stage_rows_u8(stA, g, N, src_r, wave, lane);
+    // All loads of the row block (r rows and the m image) are requested BEFORE the barrier: they land in registers, so
+    // they need not wait for the previous row block's readers, and the two HBM round trips become one that overlaps the
+    // barrier wait (phase stamps: 4.5 k + 4.5 k cycles back to back before).  N <= 1024: lane = 16-byte chunk of a row.
+    constexpr int RPW = 32 / WAVES_PER_BLOCK;
+    const int shm = __builtin_amdgcn_readfirstlane(src_m.a0);
+    RawChunks<1> in_r[RPW], in_m[8];
     {
-      const int shm = __builtin_amdgcn_readfirstlane(src_m.a0);
-      for (int i0 = tid * 16; i0 < 32 * N; i0 += 8 * BLOCK_THREADS * 16) {
-        RawChunks<1> raw[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int i = i0 + j * BLOCK_THREADS * 16;
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 8)
-          raw[j] = fake_raw<1>(i);
+      for (int j = 0; j < RPW; j++) {
+        const int pos0 = src_r.a0 + (wave + WAVES_PER_BLOCK * j) * N;
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
+        in_r[j] = fake_raw<1>(pos0 + lane);
 #else
-          raw[j] = load_raw<1>(src_m, src_m.a0 + i, shm);    // past the row block: next rows or zeros, not written
+        in_r[j] = load_raw<1>(src_r, pos0 + 16 * lane, 0);
 #endif
-        }
+      }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int i = i0 + j * BLOCK_THREADS * 16;
-          v4i v[1];
-          shift_raw<1>(raw[j], shm, v);
-          if (i < 32 * N) *(v4i *)(mimg + i) = v[0];
-        }
+      for (int j = 0; j < 8; j++) {
+        const int i = tid * 16 + j * BLOCK_THREADS * 16;
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 8)
+        in_m[j] = fake_raw<1>(i);
+#else
+        in_m[j] = load_raw<1>(src_m, src_m.a0 + i, 0);   // past the row block: next rows or zeros, not written
+#endif
       }
     }
+    __syncthreads();                                    // the previous row block's readers are done (first pass: key arrays built)
+    STAMP(1);
+    {
+      const v4i mk = col_mask16(16 * lane, N);
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const int row = wave + WAVES_PER_BLOCK * j;
+        v4i v[1];
+        shift_raw<1>(in_r[j], src_r.a0 + row * N, v);
+        if (lane < 2 * g.NT) *(v4i *)(stA + row * g.pitchA + 16 * lane) = v[0] & mk;
+      }
+      STAMP(16);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = tid * 16 + j * BLOCK_THREADS * 16;
+        v4i v[1];
+        shift_raw<1>(in_m[j], shm, v);
+        if (i < 32 * N) *(v4i *)(mimg + i) = v[0];
+      }
+    }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
+    sidx = 0;
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
       // Result register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31: a per-lane offset
       // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
@@ -1995,6 +2015,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
       auto epi = [&](auto &lo, auto &hi) {               // arrays of the strip's tiles
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
         long bb = b0;                                    // descriptors made where they are used: see k_decrypt_m
+#if NTRU_ABLATE & 512
+        bb = 0;                                          // timing only: every workgroup writes the first row block (L2-resident)
+#endif
         asm volatile("" : "+s"(bb));
         const long lf = (B - bb) * N;
         const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + bb * N, 2 * lf);
@@ -2030,11 +2053,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
         if (want_q) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
-        case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
-        case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
-        case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
-        default: toeplitz_strip<M_ENC, 4>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+        case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        default: toeplitz_strip<M_ENC, 4>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
       }
+      sidx++;
     });
   }
 }
@@ -2064,7 +2088,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
   const long nrb = (B + 31) >> 5;
   const int nch = 2 * g.NT;
   const u32 qm2 = (q - 1) * 0x00010001u;
+  int sidx = 0, stamp_iter = -1;
   for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    stamp_iter++;
+    STAMP(0);
     int lane = lane0, N = g.N;                           // see k_encrypt_m
     asm volatile("" : "+v"(lane), "+s"(N));
     const u32 *tbf = frag_lane_base(TF, g, lane), *tbp = frag_lane_base(TP, g, lane);
@@ -2074,8 +2101,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     diag_low_mask(lane, mlow);
     const long b0 = rb << 5, left = (B - b0) * N;
     const AlignedSrc src_e = aligned_src(e + b0 * N, 2 * left);
+    // (requesting these loads before the barrier, as k_encrypt_m does, measured 3 % slower here.)  lane = 16 coefficients.
     __syncthreads();
-    for (int c16 = lane; c16 < nch; c16 += 64) {
+    STAMP(1);
+    {
+      const int c16 = lane;
       constexpr int RPW = 32 / WAVES_PER_BLOCK;
       RawChunks<2> raw[RPW];
       int sh[RPW];
@@ -2111,13 +2141,18 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
           lo[c] = __builtin_amdgcn_perm(xb & 0x007F007Fu, xa & 0x007F007Fu, 0x06040200u);
           hi[c] = __builtin_amdgcn_perm((xb >> 6) & 0x00FE00FEu, (xa >> 6) & 0x00FE00FEu, 0x06040200u);
         }
-        *(uint4 *)(stLo + row * g.pitchA + 16 * c16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-        *(uint4 *)(stHi + row * g.pitchA + 16 * c16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        if (c16 < nch) {
+          *(uint4 *)(stLo + row * g.pitchA + 16 * c16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+          *(uint4 *)(stHi + row * g.pitchA + 16 * c16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        }
       }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
     // ---- product 1: a = f * e mod q; witness stores; lifted message -> packed image
+    sidx = 0;
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
       auto epi = [&](auto &lo, auto &hi) {
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
@@ -2165,13 +2200,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         else out(std::false_type{}, std::false_type{});
       };
       switch (nt) {
-        case 1: toeplitz_strip<M_DEC1, 1>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
-        case 2: toeplitz_strip<M_DEC1, 2>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
-        case 3: toeplitz_strip<M_DEC1, 3>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
-        default: toeplitz_strip<M_DEC1, 4>(st0, st1, tbf, tbf, g, kb0, mlow, epi); break;
+        case 1: toeplitz_strip<M_DEC1, 1>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 2: toeplitz_strip<M_DEC1, 2>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 3: toeplitz_strip<M_DEC1, 3>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        default: toeplitz_strip<M_DEC1, 4>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
       }
+      sidx++;
     });
     __syncthreads();                                    // every wave is done with the e stages; packed image complete
+    STAMP(8);
 #if !(NTRU_ABLATE & 64)
     for (int x = tid0; x <= (int)((p - 1) * (p - 1)) * N; x += BLOCK_THREADS) {
       const u32 rm = mod_small((u32)x, p);
@@ -2179,14 +2216,31 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     }
 #endif
 #if !(NTRU_ABLATE & 32)
-    for (int row = wave; row < 32; row += WAVES_PER_BLOCK) {
-      const int rgb = 2 * (row >> 3) + ((row >> 2) & 1), sh = 2 * (row & 3);
-      const u32 *src = (const u32 *)(blp + rgb * 32 * g.NT);
-      for (int c4 = lane; c4 < 8 * g.NT; c4 += 64) *(u32 *)(stLo + row * g.pitchA + 4 * c4) = (src[c4] >> sh) & 0x03030303u;
+    {   // packed image -> byte stage: all of a wave's reads in flight before the first write (as a read-write loop this
+        // pass was one LDS round trip per dword: 7 k cycles per row block in the phase stamps)
+      constexpr int RPW = 32 / WAVES_PER_BLOCK;
+      u32 pv[RPW][4];
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const int row = wave + WAVES_PER_BLOCK * j, rgb = 2 * (row >> 3) + ((row >> 2) & 1);
+        const u32 *src = (const u32 *)(blp + rgb * 32 * g.NT);
+#pragma unroll
+        for (int it = 0; it < 4; it++) pv[j][it] = src[(lane + 64 * it) < 8 * g.NT ? lane + 64 * it : 0];
+      }
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const int row = wave + WAVES_PER_BLOCK * j, sh = 2 * (row & 3);
+#pragma unroll
+        for (int it = 0; it < 4; it++)
+          if (lane + 64 * it < 8 * g.NT) *(u32 *)(stLo + row * g.pitchA + 4 * (lane + 64 * it)) = (pv[j][it] >> sh) & 0x03030303u;
+      }
     }
 #endif
+    STAMP(9);
     __syncthreads();
+    STAMP(10);
     // ---- product 2: c = fp * lifted mod p
+    sidx = 0;
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
       auto epi = [&](auto &lo, auto &hi) {
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
@@ -2222,11 +2276,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         if (want_q2) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
-        case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
-        case 2: toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
-        case 3: toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
-        default: toeplitz_strip<M_DEC2, 4>(st0, st0, tbp, tbp, g, kb0, mlow, epi); break;
+        case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 2: toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 3: toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        default: toeplitz_strip<M_DEC2, 4>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
       }
+      sidx++;
     });
   }
 }
@@ -2396,7 +2451,7 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
 // Matrix-core path (family 4): shared key, q a power of two <= 8192 (two int8 digit planes), LDS for a 32-row block.
 static bool make_mgeom(const ntru_engine *eng, int N, int q, MGeom *g) {
   if (eng->path != 0 && eng->path != 4) return false;
-  if (q > 8192 || N < (eng->path == 4 ? 2 : 64)) return false;
+  if (q > 8192 || N > 1024 || N < (eng->path == 4 ? 2 : 64)) return false;   // staging: lane = 16-byte chunk of a row
   g->N = N;
   g->NT = (N + 31) / 32;
   g->pitchA = 32 * g->NT + 16;
