@@ -200,6 +200,37 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d):
         eng.set_kernel_path(0)
 
 
+def test_matrix_core_path_random_parameter_sweep(eng):
+    """Differential sweep: 40 random (N, q, B) with N in [2, 1024] (odd and even, around the 32-tile boundaries), q any
+    power of two up to 8192, ragged B; matrix-core family (forced) against the CPU oracle, all outputs."""
+    rng = np.random.default_rng(20240)
+    p = 3
+    eng.set_kernel_path(4)
+    try:
+        for trial in range(40):
+            N = int(rng.choice([rng.integers(2, 1025), 32 * rng.integers(1, 33) + rng.integers(-1, 2)]))
+            N = max(2, min(1024, N))
+            q = 1 << int(rng.integers(5, 14))
+            B = int(rng.integers(1, 100))
+            d = max(0, min(N // 3, N - 1))
+            h = rng.integers(0, q, N)
+            f = ternary_rows(rng, 1, N, min(d + 1, N), min(d, N - min(d + 1, N)), two=-1)[0]
+            fp = rng.integers(0, p, N)
+            r = ternary_rows(rng, B, N, d, d)
+            m = rng.integers(0, 256, (B, N))
+            e, quot = eng.encrypt_batch(N, q, h, r, m)
+            assert eng.last_kernel() == "k_encrypt_m"
+            e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
+            assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
+            ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])
+            got = eng.decrypt_batch(N, q, p, f, fp, ein)
+            want = orc.decrypt_batch(N, q, p, f, fp, ein)
+            for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
+                assert np.array_equal(g_, w_), (N, q, B, name)
+    finally:
+        eng.set_kernel_path(0)
+
+
 @pytest.mark.parametrize("N,q", [(821, 4096), (167, 128), (701, 8192)])
 def test_device_pointers_at_any_alignment(eng, N, q):
     """The *_dev entry points take any pointer: the matrix-core kernels read rows through aligned chunks + shifts and
