@@ -25,9 +25,12 @@
  *     the results are in the caller's buffers.
  *   - there is no CPU fallback: without a usable HIP device ntru_engine_create fails.
  *   - symbol preconditions (what the reference itself always produces): r in {0,1,2}; f, g in {-1,0,1}; fp and the
- *     plaintext-side values below p.  The fast kernels step over these ternary operands by symbol class (0 / 1 /
- *     "the other symbol"); any other value is a caller error with unspecified results.  ntru_engine_set_kernel_path(1)
- *     selects the multiply-accumulate kernels, which accept arbitrary operand values for r and h, e, fq.
+ *     plaintext-side values below p.  The fast kernels rely on them (the ternary add path steps over these operands by
+ *     symbol class, the matrix-core path carries them as int8 digits: r <= 3, |f| <= 1); any other value is a caller
+ *     error with unspecified results.  ntru_engine_set_kernel_path(1) selects the multiply-accumulate kernels, which
+ *     accept arbitrary operand values for r and h, e, fq.
+ *   - shared-key encrypt / decrypt with 64 <= N <= 1024 and q <= 8192 run on the int8 matrix cores (batch x Toeplitz
+ *     matrix of the key, exact); everything else on the vector-ALU kernel families.  Pointers may have any alignment.
  */
 #ifndef NTRU_ENGINE_H
 #define NTRU_ENGINE_H
@@ -66,7 +69,7 @@ void ntru_engine_destroy(ntru_engine_t *eng);
 int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
 /* Tuning / test knob: 0 = pick the fastest applicable kernel family (default), 1 = always the packed-u16 MAC
  * kernels, 2 = the ternary add path wherever it applies, 3 = the add path without its dot8 product, 4 = the int8
- * matrix-core path wherever it applies (shared key, q <= 8192), even for small N.  Results are identical. */
+ * matrix-core path wherever it applies (shared key, q <= 8192, N <= 1024), even for small N.  Results are identical. */
 int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
 /* Name of the kernel the last *_dev call on this engine launched, e.g. "k_decrypt_s<13,13>" (for reports). */
 const char *ntru_engine_last_kernel(ntru_engine_t *eng);

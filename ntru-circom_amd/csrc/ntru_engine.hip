@@ -52,11 +52,6 @@ static __device__ __forceinline__ u32 as_u32(u16x2 v) { return __builtin_bit_cas
 
 // x mod a small runtime modulus; p = 3 (every NTRU parameter set) gets the constant-divisor sequence.
 static __device__ __forceinline__ u32 mod_small(u32 x, u32 m) { return m == 3u ? x % 3u : x % m; }
-// x mod 3 for x < 2^15 with 24-bit multiplies (the generic sequence uses the quarter-rate 32-bit multiply-high).
-static __device__ __forceinline__ u32 mod3_15(u32 x) {
-  const u32 qt = ((x & 0x7FFFu) * 0xAAABu) >> 17;       // operands provably below 2^24: v_mul_u32_u24
-  return x - 3u * qt;
-}
 
 // Order this wave's LDS writes before its later LDS reads (regions touched here are private to one wave).
 static __device__ __forceinline__ void wave_lds_fence() {
@@ -1835,12 +1830,6 @@ static __device__ __forceinline__ void for_each_strip(int NT, int wave, Body bod
   }
 }
 
-static __device__ __forceinline__ uint4 load16_unaligned(const void *p) {
-  uint4 v;
-  __builtin_memcpy(&v, p, 16);
-  return v;
-}
-
 static __device__ __forceinline__ void diag_low_mask(int lane, u32 (&mlow)[4]) {
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -1851,9 +1840,6 @@ static __device__ __forceinline__ void diag_low_mask(int lane, u32 (&mlow)[4]) {
     mlow[c] = mk;
   }
 }
-
-// Row of result register i of a 32x32 accumulator tile held by this lane (column = lane & 31).
-static __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
 // Buffer descriptor of `bytes` bytes at p: loads beyond the end return 0 and stores beyond it are dropped, which is how
 // the rows of a partial last row block are handled (the row block is rebased so that in-block offsets are small).
