@@ -137,6 +137,14 @@ int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t
                            const uint16_t *d_e, int64_t B, uint8_t *d_value, uint16_t *d_quot1,
                            uint16_t *d_rem1, uint8_t *d_quot2);
 
+/* generatePublicKeyH (index.js:72-79) for B keys: h[b] = remainder of ((p * fq[b]) mod q) * g[b] by 1 - x^N, mod q
+ * (before trimPolynomial).  fq: mod-q inverse of f, g in {-1,0,1}; p*(q-1) must fit 16 bits.  Per-item operands on both
+ * sides, so this runs on the vector-ALU product kernel.  [§8(f) #1, the part of key generation that is a product] */
+int ntru_public_key_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *fq, const int8_t *g, int64_t B,
+                          uint16_t *h);
+int ntru_public_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const uint16_t *d_fq, const int8_t *d_g,
+                              int64_t B, uint16_t *d_h);
+
 /* ---- verifyKeysInputs (index.js:141-197) for B independent key pairs (per-item operands).
  *      f, g [B][N] in {-1,0,1}; fq, h [B][N] in [0,q); fp [B][N] in [0,p).
  *      Three witnesses per item: fq*f mod q, fp*f mod p, (p*fq)*g mod q, each as quotient + remainder;

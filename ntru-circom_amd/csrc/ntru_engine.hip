@@ -320,10 +320,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt(Geom g, u32 q, u32 p,
 }
 
 // generic a*b mod `mod` split by I with per-item operands (multiplyPolynomials + dividePolynomials(.,I,.)).
-template <int K>
+// PUBKEY: generatePublicKeyH (index.js:72-79) for per-item keys: a = g in {-1,0,1} (int8, passed through `a`),
+// b = p*fq reduced mod q (scale = p), only the remainder (= h before trimming) is stored.
+template <int K, bool PUBKEY = false>
 __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod, int pow2,
                                                                  const u16 *__restrict__ a, const u16 *__restrict__ b,
-                                                                 long B, u16 *__restrict__ quot, u16 *__restrict__ rem) {
+                                                                 long B, u16 *__restrict__ quot, u16 *__restrict__ rem,
+                                                                 u32 scale = 1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const LaneId L = lane_id(g);
   const size_t raw_len = ((size_t)g.N + 1) & ~(size_t)1;                 // u16 slots per staged operand (dword aligned)
@@ -337,14 +340,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod
     const long item = grp * g.G + L.grp;
     const bool valid = L.active && item < B;
     const long row = (valid ? item : 0) * g.N;
-    stage_raw(raw, g.N, g.nl, ValU16{b + row}, L.sub, L.active);
-    stage_a((u16 *)a32, g, ValU16{a + row}, L.sub, L.active);
+    if (PUBKEY) {
+      stage_raw(raw, g.N, g.nl, ValU16x3m{b + row, scale, mod - 1}, L.sub, L.active);
+      stage_a((u16 *)a32, g, ValTernary{(const int8_t *)a + row, mod - 1}, L.sub, L.active);
+    } else {
+      stage_raw(raw, g.N, g.nl, ValU16{b + row}, L.sub, L.active);
+      stage_a((u16 *)a32, g, ValU16{a + row}, L.sub, L.active);
+    }
     wave_lds_fence();
     if (L.active) build_eo(eo, g, ValLds{raw}, L.sub, g.nl);
     wave_lds_fence();
     u16x2 r[K], qv[K];
     if (pow2) {
-      product_split<K, true>(eo, a32, g, L.sub, true, mod, r, qv);
+      product_split<K, true>(eo, a32, g, L.sub, !PUBKEY, mod, r, qv);
 #pragma unroll
       for (int t = 0; t < K; t++) r[t] = r[t] & (u16)(mod - 1);
     } else {
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod
     }
     if (valid) {
       store_pairs<K>(rem + row, g, L.sub, r);
-      store_pairs<K>(quot + row, g, L.sub, qv);
+      if (!PUBKEY) store_pairs<K>(quot + row, g, L.sub, qv);
     }
     wave_lds_fence();
   }
@@ -2657,6 +2665,26 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
   return NTRU_OK;
 }
 
+extern "C" int ntru_public_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const uint16_t *d_fq,
+                                         const int8_t *d_g, int64_t B, uint16_t *d_h) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (p < 1 || (long)p * (q - 1) >= 65536) return fail(NTRU_ERR_UNSUPPORTED, "p*(q-1) must fit 16 bits");
+  if (B == 0) return NTRU_OK;
+  if (!d_fq || !d_g || !d_h) return fail(NTRU_ERR_ARG, "ntru_public_key_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  Launch L;
+  if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
+  DISPATCH_K(L.K, {
+    if (int rc = allow_lds((k_polymul_split<KK, true>), L.lds)) return rc;
+    if (int rc = resident_grid(eng, (k_polymul_split<KK, true>), L.lds, (long)L.grid.x, &L.grid)) return rc;
+    note_kernel(eng, "k_public_key", KK, -1);
+    hipLaunchKernelGGL((k_polymul_split<KK, true>), L.grid, dim3(BLOCK_THREADS), L.lds, eng->stream, L.g, (u32)q, 1,
+                       (const u16 *)d_g, d_fq, (long)B, (u16 *)nullptr, d_h, (u32)p);
+  });
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
 extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f,
                                           const int8_t *d_g, const uint16_t *d_fq, const uint8_t *d_fp,
                                           const uint16_t *d_h, int64_t B, uint16_t *d_quot_fq, uint16_t *d_rem_fq,
@@ -2844,6 +2872,27 @@ extern "C" int ntru_polymul_split(ntru_engine_t *eng, int N, int mod, const uint
       return rc;
     D2H(quot + o * N, dq, n * row);
     D2H(rem + o * N, dr, n * row);
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+  }
+  return NTRU_OK;
+}
+
+extern "C" int ntru_public_key_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *fq, const int8_t *g,
+                                     int64_t B, uint16_t *h) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!fq || !g || !h) return fail(NTRU_ERR_ARG, "ntru_public_key_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
+  DevBuf dfq, dg, dh;
+  if (dfq.alloc(C * (size_t)N * 2) || dg.alloc(C * (size_t)N) || dh.alloc(C * (size_t)N * 2)) return NTRU_ERR_HIP;
+  for (int64_t o = 0; o < B; o += C) {
+    const int64_t n = B - o < C ? B - o : C;
+    H2D(dfq, fq + o * N, n * (size_t)N * 2);
+    H2D(dg, g + o * N, n * (size_t)N);
+    if (int rc = ntru_public_key_batch_dev(eng, N, q, p, (const uint16_t *)dfq.p, (const int8_t *)dg.p, n, (uint16_t *)dh.p))
+      return rc;
+    D2H(h + o * N, dh, n * (size_t)N * 2);
     HIP_TRY(hipStreamSynchronize(eng->stream));
   }
   return NTRU_OK;

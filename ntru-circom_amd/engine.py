@@ -34,6 +34,8 @@ _SIGS = {
     "ntru_last_error": (C.c_char_p, []),
     "ntru_engine_supports": (C.c_int, [_i, _i]),
 }
+for _sfx in ("", "_dev"):
+    _SIGS["ntru_public_key_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp])
 _SIGS["ntru_sample_ternary"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _SIGS["ntru_sample_ternary_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _ip = C.POINTER(C.c_int)
@@ -228,6 +230,18 @@ class Engine:
                                                    _ptr(out["rem_fp"]), _ptr(out["quot_h"]), _ptr(out["rem_h"]),
                                                    _ptr(out["flags"])))
         return out
+
+    def public_key_batch(self, N, q, p, fq, g):
+        """generatePublicKeyH for B keys: rows of (p*fq mod q) * g mod (x^N - 1, q), untrimmed."""
+        fq, g = _np(fq, np.uint16).reshape(-1, N), _np(g, np.int8).reshape(-1, N)
+        B = fq.shape[0]
+        h = np.empty((B, N), np.uint16)
+        self._chk(self._lib.ntru_public_key_batch(self._h, N, q, p, _ptr(fq), _ptr(g), B, _ptr(h)))
+        return h
+
+    def public_key_batch_dev(self, N, q, p, d_fq, d_g, B, d_h):
+        dp = self._dp
+        self._chk(self._lib.ntru_public_key_batch_dev(self._h, N, q, p, dp(d_fq), dp(d_g), B, dp(d_h)))
 
     # ---- device pointers (asynchronous) -------------------------------------------------------------------
     @staticmethod

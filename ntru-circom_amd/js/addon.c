@@ -131,6 +131,20 @@ static napi_value AddBatch(napi_env env, napi_callback_info info) {
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
+/* publicKeyBatch(N, q, p, fq:Uint16Array[B*N], g:Int8Array[B*N], B, h:Uint16Array[B*N]) */
+static napi_value PublicKeyBatch(napi_env env, napi_callback_info info) {
+  ARGS(7)
+  int32_t N, q, p, B; void *fq, *g, *h;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) || !get_i32(env, argv[5], &B) ||
+      N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[3], napi_uint16_array, n, 0, &fq) || !get_buf(env, argv[4], napi_int8_array, n, 0, &g) ||
+      !get_buf(env, argv[6], napi_uint16_array, n, 0, &h)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_public_key_batch(g_engine, N, q, p, fq, g, B, h);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
 /* encryptBatch(N, q, h:Uint16Array[N], r:Uint8Array[B*N], m:Uint8Array[B*N], B, e:Uint16Array, quotE:Uint16Array|null) */
 static napi_value EncryptBatch(napi_env env, napi_callback_info info) {
   ARGS(8)
@@ -249,6 +263,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"encryptBatch", NULL, EncryptBatch, NULL, NULL, NULL, napi_default, NULL},
     {"decryptBatch", NULL, DecryptBatch, NULL, NULL, NULL, napi_default, NULL},
     {"verifyKeysBatch", NULL, VerifyKeysBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"publicKeyBatch", NULL, PublicKeyBatch, NULL, NULL, NULL, napi_default, NULL},
     {"sampleTernary", NULL, SampleTernary, NULL, NULL, NULL, napi_default, NULL},
     {"packParams", NULL, PackParams, NULL, NULL, NULL, napi_default, NULL},
     {"packBatch", NULL, PackBatch, NULL, NULL, NULL, napi_default, NULL},

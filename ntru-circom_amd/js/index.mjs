@@ -12,7 +12,7 @@
 // There is no JavaScript arithmetic fallback: without the addon or a GPU the first call throws.
 //
 // Out of scope (SURVEY.md 8f): key generation / inversion (loadPrivateKeyF, generatePrivateKeyF,
-// generateNewPublicKeyGH, generatePublicKeyH, polyInv, extendedEuclideanAlgorithm, generic long division).
+// generateNewPublicKeyGH, polyInv, extendedEuclideanAlgorithm, generic long division); generatePublicKeyH is provided.
 // Keys are supplied through the options object, as README.md:81 of the reference already allows.
 import { createRequire } from 'module';
 import { randomFillSync } from 'crypto';
@@ -217,6 +217,15 @@ export default class NTRU {
       },
       params: [q, this.calculateNq(), p, this.calculateNp(), N],
     };
+  }
+
+  generatePublicKeyH() {                                         // index.js:72-79 (fq must be supplied: no polyInv here)
+    if (!this.f) throw new Error('missing private key F');
+    if (!this.g) throw new Error('missing private key G');
+    const { N, p, q } = this;
+    const h = new Uint16Array(N);
+    addon.publicKeyBatch(N, q, p, Uint16Array.from(expandArray(this.fq, N, 0)), Int8Array.from(expandArray(this.g, N, 0)), 1, h);
+    this.h = trimPolynomial(Array.from(h));
   }
 
   verifyKeysInputs() {                                           // index.js:141-197

@@ -226,6 +226,19 @@ class NTRU:
             "params": [q, self.calculateNq(), p, self.calculateNp(), N],
         }
 
+    # -- generatePublicKeyH, index.js:72-79 ----------------------------------------------------------------
+    def generatePublicKeyH(self):
+        """h = trim((p*fq mod q) * g mod (x^N - 1, q)) on the device.  (Inverting f -- loadPrivateKeyF / polyInv -- is not
+        provided: pass fq in the options.)"""
+        if not self.f:
+            raise ValueError("missing private key F")
+        if not self.g:
+            raise ValueError("missing private key G")
+        if not self.fq:
+            raise TypeError("Cannot read property 'map' of null")              # what index.js:76 does without fq
+        h = self.engine.public_key_batch(self.N, self.q, self.p, [expandArray(self.fq, self.N)], [expandArray(self.g, self.N)])
+        self.h = trimPolynomial(h[0].tolist())
+
     # -- verifyKeysInputs, index.js:141-197 ---------------------------------------------------------------
     def verifyKeysInputs(self):
         for attr, msg in (("f", "missing private key F"), ("fq", "missing private key Fq"),

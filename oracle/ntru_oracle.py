@@ -219,6 +219,14 @@ def verify_keys_batch(N, q, p, f, g, fq, fp, h, mode=EXACT):
     return out
 
 
+def public_key_batch(N, q, p, fq, g, mode=EXACT):
+    """generatePublicKeyH (index.js:72-79): remainder of ((p*fq) % q) * g by I, mod q, untrimmed rows."""
+    fq = _c(fq, np.uint16).reshape(-1, N).astype(np.int64)
+    g = _c(g, np.int8).reshape(-1, N).astype(np.int64)
+    _, rem = polymul_split_batch(N, q, (fq * p) % q, g % q, mode)
+    return rem
+
+
 def chacha20_block(key, counter, nonce):
     key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32)); nonce = np.ascontiguousarray(np.asarray(nonce, dtype=np.uint32))
     out = np.zeros(16, np.uint32)

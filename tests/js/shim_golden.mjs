@@ -41,6 +41,11 @@ for (const profile of ['n17_q32', 'n167_q128', 'n509_q2048', 'n821_q4096', 'n701
     for (const d of key.degenerate) { deepStrictEqual(ntru.decryptBits(d.e), d.decrypt); checks++; }
     deepStrictEqual(ntru.verifyKeysInputs(), key.verifyKeysInputs);
     checks++;
+    // generatePublicKeyH (index.js:72-79) on the device reproduces the captured h from fq and g
+    const regen = new NTRU({ ...g.options, f: key.f, fq: key.fq, g: key.g });
+    regen.generatePublicKeyH();
+    deepStrictEqual(regen.h, key.h);
+    checks++;
   }
   // test/reference.test.js:6-25 with a captured key; q = 1 mod 3 never round-trips in the reference (SURVEY.md 0.4)
   if (g.options.q % 3 === 2 && g.options.N >= 88) {

@@ -277,6 +277,29 @@ def test_device_pointers_at_any_alignment(eng, N, q):
         eng.set_stream(None)
 
 
+def test_public_key_batch_equals_reference_and_oracle(eng, scheme_golden):
+    """generatePublicKeyH on the device: captured keys (through the host mirror and the batch entry point) and random
+    per-item operands against the oracle."""
+    o = scheme_golden["options"]
+    N, q, p = o["N"], o["q"], o["p"]
+    pad = lambda a: list(a) + [0] * (N - len(a))
+    keys = scheme_golden["keys"]
+    for key in keys:
+        n = pkg.NTRU(dict(o, f=key["f"], fq=key["fq"], g=key["g"]), engine=eng)
+        n.generatePublicKeyH()
+        assert n.h == key["h"]
+    h = eng.public_key_batch(N, q, p, [pad(k["fq"]) for k in keys], [pad(k["g"]) for k in keys])
+    assert eng.last_kernel().startswith("k_public_key")
+    for row, key in zip(h, keys):
+        assert orc.trim(row.tolist()) == list(key["h"])
+    rng = np.random.default_rng(N + q)
+    B = 77
+    fq = rng.integers(0, q, (B, N)); g = ternary_rows(rng, B, N, N // 4, N // 4, two=-1)
+    assert np.array_equal(eng.public_key_batch(N, q, p, fq, g), orc.public_key_batch(N, q, p, fq, g))
+    with pytest.raises(ValueError, match="missing private key G"):
+        pkg.NTRU(dict(o, f=keys[0]["f"], fq=keys[0]["fq"]), engine=eng).generatePublicKeyH()
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 6, 7, 8, 13, 29, 257])
 def test_ragged_batch_sizes(eng, B):
     # N=17 packs 7 items per wavefront, N=167 two: batches that do not fill a wave / a workgroup

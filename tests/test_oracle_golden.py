@@ -190,3 +190,15 @@ def test_field_packing_matches_reference():
         un = orc.unpack_batch(v["maxVal"], v["packedBits"], limbs)
         assert un.shape[1] == v["unpackedSize"]
         assert orc.trim(un[0]) == v["unpacked"]
+
+
+def test_public_key_equals_reference_keys(scheme_golden):
+    """generatePublicKeyH (index.js:72-79): the oracle's (p*fq)*g mod q reproduces h of every captured key, in both
+    the exact and the reference-equivalent mode."""
+    o = scheme_golden["options"]
+    N, q, p = o["N"], o["q"], o["p"]
+    pad = lambda a: list(a) + [0] * (N - len(a))
+    for key in scheme_golden["keys"]:
+        for mode in (orc.EXACT, orc.FAITHFUL):
+            h = orc.public_key_batch(N, q, p, [pad(key["fq"])], [pad(key["g"])], mode)[0].tolist()
+            assert orc.trim(h) == list(key["h"])
