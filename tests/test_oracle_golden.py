@@ -1,5 +1,8 @@
 """Pins the CPU oracle (oracle/) to vectors captured from the unmodified reference
 (tests/golden/gen_golden.mjs).  CPU only."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -202,3 +205,44 @@ def test_public_key_equals_reference_keys(scheme_golden):
         for mode in (orc.EXACT, orc.FAITHFUL):
             h = orc.public_key_batch(N, q, p, [pad(key["fq"])], [pad(key["g"])], mode)[0].tolist()
             assert orc.trim(h) == list(key["h"])
+
+
+# ---- key inversion: oracle/ntru_keygen.py against the reference -------------------------------
+
+def test_key_inversion_equals_reference_keys(scheme_golden):
+    """loadPrivateKeyF (index.js:30-49): fq and fp of every captured key from its f."""
+    from oracle import ntru_keygen as kg
+    o = scheme_golden["options"]
+    N, q, p = o["N"], o["q"], o["p"]
+    if N > 600:
+        pytest.skip("covered by the smaller parameter sets here; the large keys are checked on the GPU side")
+    pad = lambda a: list(a) + [0] * (N - len(a))
+    for key in scheme_golden["keys"]:
+        fq, fp = kg.load_private_key(pad(key["f"]), N, q, p)
+        assert fq.tolist() == pad(key["fq"]) and fp.tolist() == pad(key["fp"])
+
+
+def test_key_inversion_failing_and_quirky_cases():
+    """tests/golden/keygen_cases.json (gen_keygen_cases.mjs): 123 seeded ternary f at small / even N; the oracle throws
+    what the reference throws and returns what it returns, including the non-units its `&&` checks accept."""
+    from oracle import ntru_keygen as kg
+    with open(os.path.join(os.path.dirname(__file__), "golden", "keygen_cases.json")) as fh:
+        cases = json.load(fh)["cases"]
+    n_err = n_quirk = 0
+    for c in cases:
+        N, q, p, f = c["N"], c["q"], c["p"], c["f"]
+        try:
+            fq, fp = kg.load_private_key(f, N, q, p)
+            got = (fq.tolist(), fp.tolist())
+        except kg.InvalidGcd:
+            got = "invalid_gcd"
+        except ValueError as e:
+            got = str(e)
+        if "error" in c:
+            assert got == c["error"]
+            n_err += 1
+        else:
+            pad = lambda a: list(a) + [0] * (N - len(a))
+            assert got == (pad(c["fq"]), pad(c["fp"]))
+            n_quirk += not (kg.is_unit(f, N, 2) and kg.is_unit(f, N, 3))
+    assert n_err >= 40 and n_quirk >= 30
