@@ -53,6 +53,9 @@ extern "C" {
 #define NTRU_FLAG_INVALID_FQ 1
 #define NTRU_FLAG_INVALID_FP 2
 #define NTRU_FLAG_INVALID_H 4
+/* bits of the per-key flags byte written by ntru_invert_key_batch */
+#define NTRU_FLAG_NOT_UNIT_MOD2 8  /* f has no inverse modulo 2 (hence none modulo q): fq is zero */
+#define NTRU_FLAG_NOT_UNIT_MODP 16 /* f has no inverse modulo p: fp is zero */
 
 typedef struct ntru_engine ntru_engine_t;
 
@@ -136,6 +139,17 @@ int ntru_decrypt_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f,
 int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp,
                            const uint16_t *d_e, int64_t B, uint8_t *d_value, uint16_t *d_quot1,
                            uint16_t *d_rem1, uint8_t *d_quot2);
+
+/* loadPrivateKeyF / polyInv (index.js:30-49, 491-514) for B keys: fq[b] = f[b]^-1 in Z_q[x]/(x^N - 1) (q a power of two:
+ * inverse modulo 2, then Newton rounds v <- 2v - f v^2), fp[b] = f[b]^-1 modulo p = 3; f in {-1,0,1}.  The inverse is
+ * unique, so for units the result equals the reference's Euclidean algorithm bit for bit.  For f that is not a unit the
+ * matching flag is set and the row is zero; the reference throws 'invalid_gcd' / 'invalid fq' for most such f but its
+ * `&&` checks (index.js:41-45, :451) accept some and return meaningless polynomials -- that artefact is not reproduced.
+ * [§8(f) #1] */
+int ntru_invert_key_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, int64_t B, uint16_t *fq, uint8_t *fp,
+                          uint8_t *flags);
+int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, int64_t B, uint16_t *d_fq,
+                              uint8_t *d_fp, uint8_t *d_flags);
 
 /* generatePublicKeyH (index.js:72-79) for B keys: h[b] = remainder of ((p * fq[b]) mod q) * g[b] by 1 - x^N, mod q
  * (before trimPolynomial).  fq: mod-q inverse of f, g in {-1,0,1}; p*(q-1) must fit 16 bits.  Per-item operands on both

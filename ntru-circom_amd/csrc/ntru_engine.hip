@@ -1590,6 +1590,141 @@ __global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u3
 }
 
 
+// ---- key inversion: polyInv / loadPrivateKeyF (index.js:30-49, 491-514) for one key per LANE --------
+// f^-1 in Z_P[x]/(x^N - 1), P = 2 or 3, by 2N - 1 Bernstein-Yang division steps on the reversed polynomials: the control
+// flow is the same for every key (a conditional swap and two multiply-accumulates by per-lane scalars per step), which is
+// what 64 keys in lock-step need; the reference's Euclidean algorithm returns the same polynomial because the inverse is
+// unique.  f is not a unit iff the gcd left in `ff` is not a constant: reported in `flags` (the reference's own `&&`
+// checks accept some non-units and return garbage for them: tests/golden/keygen_cases.json).  Polynomials are bit
+// planes in LDS, [array][word][lane]; GF(3) uses two planes per polynomial (plane 0: coefficient == 1, plane 1: == 2).
+
+template <int P>
+__global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restrict__ f, long B, u16 *__restrict__ out16,
+                                                   uint8_t *__restrict__ out8, uint8_t *__restrict__ flags, u32 flag_bit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PL = P == 2 ? 1 : 2;                      // bit planes per polynomial
+  const int lane = threadIdx.x, NW = (N + 1 + 31) >> 5;    // N + 1 coefficients: the reversed modulus has degree N
+  u32 *base = (u32 *)lds;
+  auto at = [&](int arr, int pl, int w) -> u32 & { return base[((arr * PL + pl) * NW + w) * 64 + lane]; };
+  enum { AF = 0, AG = 1, AV = 2, AW = 3 };
+  for (long k0 = (long)blockIdx.x * 64; k0 < B; k0 += (long)gridDim.x * 64) {
+    const long key = k0 + lane;
+    const bool have = key < B;
+    const int8_t *fk = f + (have ? key : 0) * N;
+    // ff = rev(x^N - 1) = 1 - x^N, gg = rev_{N-1}(f), vv = 0, ww = 1
+    for (int w = 0; w < NW; w++) {
+      u32 g1 = 0, g2 = 0;
+      for (int b = 0; b < 32; b++) {
+        const int i = 32 * w + b;                         // coefficient i of gg is f[N-1-i]
+        if (i < N && have) {
+          int c = fk[N - 1 - i];
+          c = c < 0 ? c + P : c;
+          c %= P;
+          g1 |= (u32)(c == 1) << b;
+          g2 |= (u32)(c == 2) << b;
+        }
+      }
+      const u32 top = (32 * w <= N && N < 32 * w + 32) ? 1u << (N & 31) : 0u;   // coefficient N of ff is -1
+      if (P == 2) {
+        at(AF, 0, w) = (w == 0 ? 1u : 0u) | top; at(AG, 0, w) = g1;
+        at(AV, 0, w) = 0; at(AW, 0, w) = w == 0 ? 1u : 0u;
+      } else {
+        at(AF, 0, w) = w == 0 ? 1u : 0u; at(AF, 1, w) = top;
+        at(AG, 0, w) = g1; at(AG, 1, w) = g2;
+        at(AV, 0, w) = 0; at(AV, 1, w) = 0; at(AW, 0, w) = w == 0 ? 1u : 0u; at(AW, 1, w) = 0;
+      }
+    }
+    int delta = 1;
+    // GF(3) helpers on (is-one, is-two) plane pairs
+    auto mul3 = [](u32 a0, u32 a1, u32 m1, u32 m2, u32 &r0, u32 &r1) {   // by a scalar given as masks (==1, ==2)
+      r0 = (a0 & m1) | (a1 & m2); r1 = (a1 & m1) | (a0 & m2);
+    };
+    auto add3 = [](u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
+      const u32 az = ~(a0 | a1), bz = ~(b0 | b1);
+      r0 = (a0 & bz) | (az & b0) | (a1 & b1);
+      r1 = (a1 & bz) | (az & b1) | (a0 & b0);
+    };
+    for (int step = 0; step < 2 * N - 1; step++) {
+      const u32 f0w0 = at(AF, 0, 0), g0w0 = at(AG, 0, 0);
+      const u32 f0w1 = P == 3 ? at(AF, 1, 0) : 0u, g0w1 = P == 3 ? at(AG, 1, 0) : 0u;
+      const int fc = (int)(f0w0 & 1u) + 2 * (int)(f0w1 & 1u), gc = (int)(g0w0 & 1u) + 2 * (int)(g0w1 & 1u);   // constant terms
+      const bool swap = delta > 0 && gc != 0;
+      const u32 sm = swap ? ~0u : 0u;
+      delta = (swap ? -delta : delta) + 1;
+      const int c1 = swap ? gc : fc;                      // new f(0): multiplies g and w
+      const int c2 = (P - (swap ? fc : gc)) % P;           // -(new g(0)): multiplies f and v
+      const u32 c1m1 = c1 == 1 ? ~0u : 0u, c1m2 = c1 == 2 ? ~0u : 0u, c2m1 = c2 == 1 ? ~0u : 0u, c2m2 = c2 == 2 ? ~0u : 0u;
+      u32 vcar[PL], gprev[PL];
+#pragma unroll
+      for (int pl = 0; pl < PL; pl++) { vcar[pl] = 0; gprev[pl] = 0; }
+      for (int w = 0; w < NW; w++) {
+        u32 F[PL], G[PL], V[PL], W[PL];
+#pragma unroll
+        for (int pl = 0; pl < PL; pl++) {
+          F[pl] = at(AF, pl, w); G[pl] = at(AG, pl, w); W[pl] = at(AW, pl, w);
+          const u32 v = at(AV, pl, w);
+          V[pl] = (v << 1) | vcar[pl];                    // v = x v
+          vcar[pl] = v >> 31;
+          u32 t = sm & (F[pl] ^ G[pl]); F[pl] ^= t; G[pl] ^= t;      // conditional swaps
+          t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
+        }
+        u32 NG[PL], NWW[PL];
+        if (P == 2) {                                     // c1 = 1; c2 = g(0)
+          NG[0] = G[0] ^ (c2m1 & F[0]);
+          NWW[0] = W[0] ^ (c2m1 & V[0]);
+        } else {
+          u32 a0, a1, b0, b1;
+          mul3(G[0], G[1], c1m1, c1m2, a0, a1); mul3(F[0], F[1], c2m1, c2m2, b0, b1); add3(a0, a1, b0, b1, NG[0], NG[1]);
+          mul3(W[0], W[1], c1m1, c1m2, a0, a1); mul3(V[0], V[1], c2m1, c2m2, b0, b1); add3(a0, a1, b0, b1, NWW[0], NWW[1]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < PL; pl++) {
+          at(AF, pl, w) = F[pl]; at(AV, pl, w) = V[pl]; at(AW, pl, w) = NWW[pl];
+          if (w > 0) at(AG, pl, w - 1) = (gprev[pl] >> 1) | (NG[pl] << 31);      // g = g / x, one word behind
+          gprev[pl] = NG[pl];
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < PL; pl++) at(AG, pl, NW - 1) = gprev[pl] >> 1;
+    }
+    // unit iff the gcd (in ff) is a non-zero constant
+    u32 rest = 0;
+    for (int w = 0; w < NW; w++)
+      for (int pl = 0; pl < PL; pl++) rest |= at(AF, pl, w) & (w == 0 ? ~1u : ~0u);
+    const int fc = (int)(at(AF, 0, 0) & 1u) + (P == 3 ? 2 * (int)(at(AF, 1, 0) & 1u) : 0);
+    const bool unit = rest == 0 && fc != 0;
+    if (have) {
+      if (!unit) flags[key] = (uint8_t)(flags[key] | flag_bit);
+      // inverse[i] = fc^-1 * vv[N-1-i]; in GF(3) fc^-1 = fc
+      for (int i = 0; i < N; i++) {
+        const int j = N - 1 - i;
+        int c = (int)((at(AV, 0, j >> 5) >> (j & 31)) & 1u);
+        if (P == 3) {
+          const int c2 = (int)((at(AV, 1, j >> 5) >> (j & 31)) & 1u);
+          c = c + 2 * c2;
+          if (fc == 2) c = (2 * c) % 3;
+        }
+        c = unit ? c : 0;
+        if (out16) out16[key * N + i] = (u16)c;
+        if (out8) out8[key * N + i] = (uint8_t)c;
+      }
+    }
+  }
+}
+
+// f in {-1,0,1} -> its residue mod q as u16 (elementwise)
+__global__ void k_signed_to_u16(const int8_t *__restrict__ f, long n, u32 q, u16 *__restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int v = f[i];
+    out[i] = (u16)(v < 0 ? (u32)(v + (int)q) : (u32)v);
+  }
+}
+// one Newton round of polyInv (index.js:499-506): v <- (2 v - u) mod q, u = f * v * v
+__global__ void k_newton_combine(u16 *__restrict__ v, const u16 *__restrict__ u, long n, u32 q) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    v[i] = (u16)((2u * v[i] - u[i]) & (q - 1));
+}
+
 // ---- BN254 field-element packing (index.js:572-620): elementwise, HBM-bound ---------------------------------------
 // One thread per 64-bit limb of the output: out[b][o] = sum_j data[b][o*per + j] << (j*bits), four LE limbs per element.
 __global__ void k_pack(int bits, int per, int data_len, int out_size, const u16 *__restrict__ data, long B,
@@ -2874,6 +3009,81 @@ extern "C" int ntru_polymul_split(ntru_engine_t *eng, int N, int mod, const uint
     D2H(rem + o * N, dr, n * row);
     HIP_TRY(hipStreamSynchronize(eng->stream));
   }
+  return NTRU_OK;
+}
+
+template <int P>
+static int launch_invert(ntru_engine *eng, int N, const int8_t *d_f, long B, uint16_t *d16, uint8_t *d8, uint8_t *d_flags,
+                         unsigned bit) {
+  const size_t lds = (size_t)(P == 2 ? 4 : 8) * ((N + 32) / 32) * 64 * 4;
+  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the inversion kernel's LDS planes");
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_invert_key<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_invert_key<P>, 64, lds));
+  long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_invert_key<P>, dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, d_f, B, (u16 *)d16, d8, d_flags,
+                     (u32)bit);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, int64_t B,
+                                         uint16_t *d_fq, uint8_t *d_fp, uint8_t *d_flags) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (p != 3) return fail(NTRU_ERR_UNSUPPORTED, "key inversion implements p = 3 (and q a power of two)");
+  if (B == 0) return NTRU_OK;
+  if (!d_f || !d_fq || !d_fp || !d_flags) return fail(NTRU_ERR_ARG, "ntru_invert_key_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipMemsetAsync(d_flags, 0, (size_t)B, eng->stream));
+  // mod 2 inverse straight into d_fq (as 0/1 coefficients), then Newton rounds v <- 2v - f v^2 mod q (index.js:499-506;
+  // the reference runs log2(q) - 1 of them, the unique inverse mod q is reached once 2^rounds >= log2(q))
+  if (int rc = launch_invert<2>(eng, N, d_f, (long)B, d_fq, nullptr, d_flags, NTRU_FLAG_NOT_UNIT_MOD2)) return rc;
+  int k = 0;
+  while ((1 << k) < q) k++;
+  int rounds = 0;
+  while ((1 << rounds) < k) rounds++;
+  if (rounds > 0) {
+    const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;     // temporaries for C keys at a time
+    const size_t row = (size_t)N * 2;
+    DevBuf f16, t, u, qs;
+    if (f16.alloc(C * row) || t.alloc(C * row) || u.alloc(C * row) || qs.alloc(C * row)) return NTRU_ERR_HIP;
+    for (int64_t o = 0; o < B; o += C) {
+      const int64_t n = B - o < C ? B - o : C;
+      uint16_t *v = d_fq + o * N;
+      hipLaunchKernelGGL(k_signed_to_u16, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, d_f + o * N, (long)(n * N),
+                         (u32)q, (u16 *)f16.p);
+      for (int r = 0; r < rounds; r++) {
+        if (int rc = ntru_polymul_split_dev(eng, N, q, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p)) return rc;
+        if (int rc = ntru_polymul_split_dev(eng, N, q, (const uint16_t *)f16.p, (const uint16_t *)t.p, n, (uint16_t *)qs.p,
+                                            (uint16_t *)u.p)) return rc;
+        hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, (u16 *)v,
+                           (const u16 *)u.p, (long)(n * N), (u32)q);
+      }
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(eng->stream));          // the temporaries are reused by the next chunk / freed on return
+    }
+  }
+  if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");
+  return NTRU_OK;
+}
+
+extern "C" int ntru_invert_key_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, int64_t B, uint16_t *fq,
+                                     uint8_t *fp, uint8_t *flags) {
+  if (int rc = check_common(eng, N, q, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!f || !fq || !fp || !flags) return fail(NTRU_ERR_ARG, "ntru_invert_key_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  DevBuf df, dfq, dfp, dfl;
+  if (df.alloc((size_t)B * N) || dfq.alloc((size_t)B * N * 2) || dfp.alloc((size_t)B * N) || dfl.alloc((size_t)B)) return NTRU_ERR_HIP;
+  H2D(df, f, (size_t)B * N);
+  if (int rc = ntru_invert_key_batch_dev(eng, N, q, p, (const int8_t *)df.p, B, (uint16_t *)dfq.p, (uint8_t *)dfp.p, (uint8_t *)dfl.p))
+    return rc;
+  D2H(fq, dfq, (size_t)B * N * 2);
+  D2H(fp, dfp, (size_t)B * N);
+  D2H(flags, dfl, (size_t)B);
+  HIP_TRY(hipStreamSynchronize(eng->stream));
   return NTRU_OK;
 }
 

@@ -9,6 +9,7 @@ _LIB = None
 
 ERR_NAMES = {1: "NTRU_ERR_NO_DEVICE", 2: "NTRU_ERR_ARG", 3: "NTRU_ERR_UNSUPPORTED", 4: "NTRU_ERR_HIP"}
 FLAG_INVALID_FQ, FLAG_INVALID_FP, FLAG_INVALID_H = 1, 2, 4
+FLAG_NOT_UNIT_MOD2, FLAG_NOT_UNIT_MODP = 8, 16
 
 
 class EngineError(RuntimeError):
@@ -36,6 +37,7 @@ _SIGS = {
 }
 for _sfx in ("", "_dev"):
     _SIGS["ntru_public_key_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp])
+    _SIGS["ntru_invert_key_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp])
 _SIGS["ntru_sample_ternary"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _SIGS["ntru_sample_ternary_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _ip = C.POINTER(C.c_int)
@@ -238,6 +240,18 @@ class Engine:
         h = np.empty((B, N), np.uint16)
         self._chk(self._lib.ntru_public_key_batch(self._h, N, q, p, _ptr(fq), _ptr(g), B, _ptr(h)))
         return h
+
+    def invert_key_batch(self, N, q, p, f):
+        """loadPrivateKeyF / polyInv for B keys: (fq [B][N] u16, fp [B][N] u8, flags [B]); a set flag = not a unit."""
+        f = _np(f, np.int8).reshape(-1, N)
+        B = f.shape[0]
+        fq, fp, flags = np.empty((B, N), np.uint16), np.empty((B, N), np.uint8), np.empty(B, np.uint8)
+        self._chk(self._lib.ntru_invert_key_batch(self._h, N, q, p, _ptr(f), B, _ptr(fq), _ptr(fp), _ptr(flags)))
+        return fq, fp, flags
+
+    def invert_key_batch_dev(self, N, q, p, d_f, B, d_fq, d_fp, d_flags):
+        dp = self._dp
+        self._chk(self._lib.ntru_invert_key_batch_dev(self._h, N, q, p, dp(d_f), B, dp(d_fq), dp(d_fp), dp(d_flags)))
 
     def public_key_batch_dev(self, N, q, p, d_fq, d_g, B, d_h):
         dp = self._dp

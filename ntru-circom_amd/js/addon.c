@@ -131,6 +131,20 @@ static napi_value AddBatch(napi_env env, napi_callback_info info) {
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
+/* invertKeyBatch(N, q, p, f:Int8Array[B*N], B, fq:Uint16Array[B*N], fp:Uint8Array[B*N], flags:Uint8Array[B]) */
+static napi_value InvertKeyBatch(napi_env env, napi_callback_info info) {
+  ARGS(8)
+  int32_t N, q, p, B; void *f, *fq, *fp, *flags;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) || !get_i32(env, argv[4], &B) ||
+      N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[3], napi_int8_array, n, 0, &f) || !get_buf(env, argv[5], napi_uint16_array, n, 0, &fq) ||
+      !get_buf(env, argv[6], napi_uint8_array, n, 0, &fp) || !get_buf(env, argv[7], napi_uint8_array, (size_t)B, 0, &flags)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc = ntru_invert_key_batch(g_engine, N, q, p, f, B, fq, fp, flags);
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
 /* publicKeyBatch(N, q, p, fq:Uint16Array[B*N], g:Int8Array[B*N], B, h:Uint16Array[B*N]) */
 static napi_value PublicKeyBatch(napi_env env, napi_callback_info info) {
   ARGS(7)
@@ -264,6 +278,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"decryptBatch", NULL, DecryptBatch, NULL, NULL, NULL, napi_default, NULL},
     {"verifyKeysBatch", NULL, VerifyKeysBatch, NULL, NULL, NULL, napi_default, NULL},
     {"publicKeyBatch", NULL, PublicKeyBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"invertKeyBatch", NULL, InvertKeyBatch, NULL, NULL, NULL, napi_default, NULL},
     {"sampleTernary", NULL, SampleTernary, NULL, NULL, NULL, napi_default, NULL},
     {"packParams", NULL, PackParams, NULL, NULL, NULL, napi_default, NULL},
     {"packBatch", NULL, PackBatch, NULL, NULL, NULL, napi_default, NULL},

@@ -11,8 +11,8 @@
 // All polynomial products and splits run on the GPU through the N-API addon -> C ABI (include/ntru_engine.h).
 // There is no JavaScript arithmetic fallback: without the addon or a GPU the first call throws.
 //
-// Out of scope (SURVEY.md 8f): key generation / inversion (loadPrivateKeyF, generatePrivateKeyF,
-// generateNewPublicKeyGH, polyInv, extendedEuclideanAlgorithm, generic long division); generatePublicKeyH is provided.
+// Key generation runs on the device too (loadPrivateKeyF, generatePrivateKeyF, generateNewPublicKeyGH,
+// generatePublicKeyH); the stand-alone helpers polyInv / extendedEuclideanAlgorithm / generic long division are not exported.
 // Keys are supplied through the options object, as README.md:81 of the reference already allows.
 import { createRequire } from 'module';
 import { randomFillSync } from 'crypto';
@@ -219,7 +219,31 @@ export default class NTRU {
     };
   }
 
-  generatePublicKeyH() {                                         // index.js:72-79 (fq must be supplied: no polyInv here)
+  loadPrivateKeyF(fArr) {                                        // index.js:30-49: fq, fp by inversion on the device
+    const { N, p, q } = this;
+    const fq = new Uint16Array(N), fp = new Uint8Array(N), flags = new Uint8Array(1);
+    addon.invertKeyBatch(N, q, p, Int8Array.from(expandArray(fArr, N, 0)), 1, fq, fp, flags);
+    // not a unit: the reference throws 'invalid_gcd' / 'invalid fq' for most such f (and accepts a few by accident)
+    if (flags[0] & 24) throw new Error('invalid_gcd');
+    this.f = fArr;
+    this.fq = trimPolynomial(Array.from(fq));
+    this.fp = trimPolynomial(Array.from(fp));
+    return true;
+  }
+
+  generatePrivateKeyF() {                                        // index.js:51-65
+    for (let i = 0; i < 100; i++) {
+      try { return this.loadPrivateKeyF(generateCustomArray(this.N, this.df, this.df - 1)); } catch (error) { /* next f */ }
+    }
+    throw new Error('Could not find invertible f');
+  }
+
+  generateNewPublicKeyGH() {                                     // index.js:67-70
+    this.g = generateCustomArray(this.N, this.dg, this.dg);
+    this.generatePublicKeyH();
+  }
+
+  generatePublicKeyH() {                                         // index.js:72-79
     if (!this.f) throw new Error('missing private key F');
     if (!this.g) throw new Error('missing private key G');
     const { N, p, q } = this;

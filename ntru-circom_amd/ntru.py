@@ -226,10 +226,34 @@ class NTRU:
             "params": [q, self.calculateNq(), p, self.calculateNp(), N],
         }
 
+    # -- loadPrivateKeyF, index.js:30-49 -------------------------------------------------------------------
+    def loadPrivateKeyF(self, fArr):
+        """fq = f^-1 mod q, fp = f^-1 mod p on the device.  For f that is not a unit this raises 'invalid_gcd' (the
+        reference throws that or 'invalid fq' for most such f and accepts a few through its `&&` checks)."""
+        from .engine import FLAG_NOT_UNIT_MOD2, FLAG_NOT_UNIT_MODP
+        fq, fp, flags = self.engine.invert_key_batch(self.N, self.q, self.p, [expandArray(list(fArr), self.N)])
+        if int(flags[0]) & (FLAG_NOT_UNIT_MOD2 | FLAG_NOT_UNIT_MODP):
+            raise ValueError("invalid_gcd")
+        self.f = list(fArr)
+        self.fq, self.fp = trimPolynomial(fq[0].tolist()), trimPolynomial(fp[0].tolist())
+        return True
+
+    def generatePrivateKeyF(self, max_tries=100):
+        """index.js:51-65: draw f with df ones and df - 1 minus ones until it is invertible."""
+        for _ in range(max_tries):
+            try:
+                return self.loadPrivateKeyF(generateCustomArray(self.N, self.df, self.df - 1))
+            except ValueError:
+                continue
+        raise ValueError("Could not find invertible f")
+
+    def generateNewPublicKeyGH(self):                                       # index.js:67-70
+        self.g = generateCustomArray(self.N, self.dg, self.dg)
+        self.generatePublicKeyH()
+
     # -- generatePublicKeyH, index.js:72-79 ----------------------------------------------------------------
     def generatePublicKeyH(self):
-        """h = trim((p*fq mod q) * g mod (x^N - 1, q)) on the device.  (Inverting f -- loadPrivateKeyF / polyInv -- is not
-        provided: pass fq in the options.)"""
+        """h = trim((p*fq mod q) * g mod (x^N - 1, q)) on the device."""
         if not self.f:
             raise ValueError("missing private key F")
         if not self.g:

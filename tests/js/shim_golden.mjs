@@ -45,7 +45,12 @@ for (const profile of ['n17_q32', 'n167_q128', 'n509_q2048', 'n821_q4096', 'n701
     const regen = new NTRU({ ...g.options, f: key.f, fq: key.fq, g: key.g });
     regen.generatePublicKeyH();
     deepStrictEqual(regen.h, key.h);
-    checks++;
+    // loadPrivateKeyF (index.js:30-49) on the device: fq and fp from f alone
+    const inv = new NTRU({ ...g.options });
+    inv.loadPrivateKeyF(key.f);
+    deepStrictEqual(inv.fq, key.fq);
+    deepStrictEqual(inv.fp, key.fp);
+    checks += 3;
   }
   // test/reference.test.js:6-25 with a captured key; q = 1 mod 3 never round-trips in the reference (SURVEY.md 0.4)
   if (g.options.q % 3 === 2 && g.options.N >= 88) {

@@ -300,6 +300,67 @@ def test_public_key_batch_equals_reference_and_oracle(eng, scheme_golden):
         pkg.NTRU(dict(o, f=keys[0]["f"], fq=keys[0]["fq"]), engine=eng).generatePublicKeyH()
 
 
+def test_key_inversion_equals_reference_keys(eng, scheme_golden):
+    """loadPrivateKeyF on the device (ntru_invert_key_batch): fq and fp of every captured key from its f, then the public
+    key from (fq, g): the whole key schedule except the random draws."""
+    o = scheme_golden["options"]
+    N, q, p = o["N"], o["q"], o["p"]
+    pad = lambda a: list(a) + [0] * (N - len(a))
+    keys = scheme_golden["keys"]
+    fq, fp, flags = eng.invert_key_batch(N, q, p, [pad(k["f"]) for k in keys])
+    assert not flags.any()
+    for i, key in enumerate(keys):
+        assert fq[i].tolist() == pad(key["fq"]) and fp[i].tolist() == pad(key["fp"])
+        n = pkg.NTRU(dict(o, g=key["g"]), engine=eng)
+        n.loadPrivateKeyF(key["f"])
+        assert n.fq == key["fq"] and n.fp == key["fp"]
+        n.generatePublicKeyH()
+        assert n.h == key["h"]
+        assert n.verifyKeysInputs() == key["verifyKeysInputs"]
+
+
+def test_key_inversion_captured_cases_and_random_keys(eng):
+    """tests/golden/keygen_cases.json: for every f that IS a unit mod 2 and mod 3 the device equals the reference; for the
+    others the matching flag is set (the reference throws for most of them and accepts some: documented deviation).
+    Random keys at BASELINE sizes: f * fq = 1 mod q and f * fp = 1 mod p through the product entry point."""
+    from oracle import ntru_keygen as kg
+    with open(os.path.join(os.path.dirname(__file__), "golden", "keygen_cases.json")) as fh:
+        cases = json.load(fh)["cases"]
+    by = {}
+    for c in cases:
+        by.setdefault((c["N"], c["q"], c["p"]), []).append(c)
+    n_unit = n_flag = 0
+    for (N, q, p), cs in by.items():
+        fq, fp, flags = eng.invert_key_batch(N, q, p, [c["f"] for c in cs])
+        for i, c in enumerate(cs):
+            u2, u3 = kg.is_unit(c["f"], N, 2), kg.is_unit(c["f"], N, 3)
+            assert bool(flags[i] & pkg.engine.FLAG_NOT_UNIT_MOD2) == (not u2), (N, c["f"])
+            assert bool(flags[i] & pkg.engine.FLAG_NOT_UNIT_MODP) == (not u3), (N, c["f"])
+            if u2 and u3:
+                pad = lambda a: list(a) + [0] * (N - len(a))
+                assert "error" not in c
+                assert fq[i].tolist() == pad(c["fq"]) and fp[i].tolist() == pad(c["fp"])
+                n_unit += 1
+            else:
+                n_flag += 1
+    assert n_unit >= 30 and n_flag >= 40
+    rng = np.random.default_rng(8)
+    for N, q, d in ((821, 4096, 273), (701, 8192, 233), (509, 2048, 169), (1024, 65536, 341)):
+        B = 70
+        f = ternary_rows(rng, B, N, d, d - 1, two=-1)
+        fq, fp, flags = eng.invert_key_batch(N, q, 3, f)
+        ok = flags == 0
+        assert ok.any()
+        for i in np.nonzero(~ok)[0][:2]:                     # a flagged key really is a non-unit (slow CPU check: two per size)
+            assert not (kg.is_unit(f[i], N, 2) and kg.is_unit(f[i], N, 3))
+            assert bool(flags[i] & pkg.engine.FLAG_NOT_UNIT_MOD2) == (not kg.is_unit(f[i], N, 2))
+        one = np.zeros(N, np.int64); one[0] = 1
+        _, rem = eng.polymul_split(N, q, (f % q).astype(np.uint16), fq)
+        assert all(np.array_equal(rem[i], one) for i in range(B) if ok[i])
+        _, rem3 = orc.polymul_split_batch(N, 3, f % 3, fp)
+        assert all(np.array_equal(rem3[i], one) for i in range(B) if ok[i])
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 6, 7, 8, 13, 29, 257])
 def test_ragged_batch_sizes(eng, B):
     # N=17 packs 7 items per wavefront, N=167 two: batches that do not fill a wave / a workgroup
