@@ -77,6 +77,37 @@ def sampler_config(profile, logB):
             "kernel": eng.last_kernel(), "ms": ms, "samples_per_s": B / (ms * 1e-3), "hbm_GBps": N * B / (ms * 1e-3) / 1e9}
 
 
+def keygen_config(profile, logB):
+    """SURVEY.md 8d config 5 with REAL keys: f sampled on the device (df ones, df - 1 minus ones), inverted mod q and
+    mod p, g sampled, h = p*fq*g; then verifyKeysInputs over the generated keys must raise no flag."""
+    o, _, _, _ = bench.load_key(profile)
+    N, q, p, df, dg = o["N"], o["q"], o["p"], o["df"], o["dg"]
+    B = 1 << logB
+    key = (np.arange(8, dtype=np.uint32) * 0x85EBCA6B + 7).astype(np.uint32)
+    fs = torch.empty((B, N), dtype=torch.uint8, device=dev); gs = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    eng.sample_ternary_dev(N, df, df - 1, 255, key, 0, B, fs.data_ptr())          # 255 = -1 as int8
+    eng.sample_ternary_dev(N, dg, dg, 255, key, 1 << 40, B, gs.data_ptr())
+    f, g = fs.view(torch.int8), gs.view(torch.int8)
+    fq = torch.empty((B, N), dtype=torch.int16, device=dev); fp = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    fl = torch.empty(B, dtype=torch.uint8, device=dev); h = torch.empty((B, N), dtype=torch.int16, device=dev)
+
+    def gen():
+        eng.invert_key_batch_dev(N, q, p, f.data_ptr(), B, fq.data_ptr(), fp.data_ptr(), fl.data_ptr())
+        eng.public_key_batch_dev(N, q, p, fq.data_ptr(), g.data_ptr(), B, h.data_ptr())
+    ms = timed(gen, steps=3, warmup=1)
+    units = int((fl == 0).sum())
+    o16 = lambda: torch.empty((B, N), dtype=torch.int16, device=dev)
+    o8 = lambda: torch.empty((B, N), dtype=torch.uint8, device=dev)
+    outs = [o16(), o16(), o8(), o8(), o16(), o16()]
+    vflags = torch.empty(B, dtype=torch.uint8, device=dev)
+    vms = timed(lambda: eng.verify_keys_batch_dev(N, q, p, f.data_ptr(), g.data_ptr(), fq.data_ptr(), fp.data_ptr(), h.data_ptr(),
+                                                  B, *[t.data_ptr() for t in outs], vflags.data_ptr()), steps=3, warmup=1)
+    bad = int(((vflags != 0) & (fl == 0)).sum())
+    return {"config": "N=%d q=%d key generation batch=2^%d (sample f, g; invert mod q and mod p; h) then verifyKeysInputs on the "
+                      "generated keys, 1 GPU" % (N, q, logB), "keygen_ms": ms, "keys_per_s": B / (ms * 1e-3), "units": units,
+            "verify_ms": vms, "verify_keys_per_s": B / (vms * 1e-3), "verify_flags_on_valid_keys": bad}
+
+
 def add_config(N, q, logB):
     B = 1 << logB
     gen = torch.Generator(device=dev); gen.manual_seed(9)
@@ -92,5 +123,5 @@ def add_config(N, q, logB):
 
 if __name__ == "__main__":
     for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
-                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20)):
+                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), keygen_config("n821_q4096", 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20)):
         print(json.dumps(res), flush=True)
