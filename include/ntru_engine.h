@@ -145,7 +145,8 @@ int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t
  * unique, so for units the result equals the reference's Euclidean algorithm bit for bit.  For f that is not a unit the
  * matching flag is set and the row is zero; the reference throws 'invalid_gcd' / 'invalid fq' for most such f but its
  * `&&` checks (index.js:41-45, :451) accept some and return meaningless polynomials -- that artefact is not reproduced.
- * [§8(f) #1] */
+ * The _dev form allocates its Newton temporaries itself (4 x 2N bytes per key, at most 65536 keys at a time) and waits
+ * for the stream once per such chunk.  [§8(f) #1] */
 int ntru_invert_key_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, int64_t B, uint16_t *fq, uint8_t *fp,
                           uint8_t *flags);
 int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, int64_t B, uint16_t *d_fq,
