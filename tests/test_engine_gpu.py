@@ -210,7 +210,7 @@ def test_matrix_core_path_random_parameter_sweep(eng):
         for trial in range(40):
             N = int(rng.choice([rng.integers(2, 1025), 32 * rng.integers(1, 33) + rng.integers(-1, 2)]))
             N = max(2, min(1024, N))
-            q = 1 << int(rng.integers(5, 14))
+            q = 1 << int(rng.integers(1, 14))
             B = int(rng.integers(1, 100))
             d = max(0, min(N // 3, N - 1))
             h = rng.integers(0, q, N)
