@@ -1868,9 +1868,9 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     if (MODE == M_ENC) {
       const u32 *p1 = tb1 - 8 * d;
       w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
-    } else if (MODE == M_DEC1) {                       // 64 f from f in {-1,0,1}: bit 0 -> bit 6, sign bit kept
-#pragma unroll
-      for (int c = 0; c < 4; c++) w1[c] = (int)((((u32)w0[c] & 0x01010101u) << 6) | ((u32)w0[c] & 0x80808080u));
+    } else if (MODE == M_DEC1) {                       // 64 f from f in {-1,0,1} (0xFF, 0, 1): the two low bits of every
+#pragma unroll                                         // byte land in its bits 6-7; what the byte below shifts in is masked off
+      for (int c = 0; c < 4; c++) w1[c] = (int)(((u32)w0[c] << 6) & 0xC0C0C0C0u);
     } else {
       w1 = w0;
     }
