@@ -261,7 +261,8 @@ def main():
             "metric": "NTRU encrypt+decrypt round trips per second at N=%d, q=%d" % (N, q),
             "value": total / elapsed, "unit": "round_trips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "i8 (int32 accumulate, exact)" if mfma else "u16", "data": "synthetic",
             "config": {"workload": "N=%d q=%d p=%d d=%d, batch=2^%d round trips per GPU per step, shared golden key, "
                                    "%s outputs" % (N, q, p, d, args.batch_log2,
                                                    "full-witness" if witness else "value-only"),
