@@ -262,11 +262,12 @@ def main():
             "value": total / elapsed, "unit": "round_trips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8 (int32 accumulate, exact)" if mfma else "u16", "data": "synthetic",
+            "dtype": "i8" if mfma else "u16", "data": "synthetic",
             "config": {"workload": "N=%d q=%d p=%d d=%d, batch=2^%d round trips per GPU per step, shared golden key, "
                                    "%s outputs" % (N, q, p, d, args.batch_log2,
                                                    "full-witness" if witness else "value-only"),
-                       "mode": args.mode, "kernel_path": args.kernel_path, "seed": 20240, "r_source": "device sampler" if args.sample_r else "torch",
+                       "mode": args.mode, "kernel_path": args.kernel_path,
+                       "arithmetic": "int8 digit planes on the matrix cores, int32 accumulation (exact)" if mfma else "exact u16 vector ALU", "seed": 20240, "r_source": "device sampler" if args.sample_r else "torch",
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "verified_bit_exact_rows": int(rows.numel()),
             "kernels_ms": {names.get("encrypt", "k_encrypt"): enc_ms, dname: dec_ms},
