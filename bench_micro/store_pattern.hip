@@ -1,0 +1,61 @@
+// Micro-benchmark: store throughput of the matrix-core epilogue's access pattern.
+// A workgroup (4 waves) writes a [32 rows][N] u16 block (row pitch 2N bytes, N = 821) strip by strip, like k_encrypt_m:
+//   pattern 0: one instruction = lanes 0-31 -> 32 consecutive columns of row r, lanes 32-63 -> the same columns of row r+4
+//              (the accumulator layout of v_mfma_i32_32x32x32_i8)
+//   pattern 1: one instruction = 64 consecutive columns of ONE row (after a v_permlane32_swap between two tiles)
+// hipcc -O3 --offload-arch=gfx950 -o store_pattern store_pattern.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+template <int PAT>
+__global__ __launch_bounds__(256) void k(unsigned short* out, long nrb, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    unsigned short* blk = out + rb * 32 * N;
+    for (int strip = wave; strip < 8; strip += 4) {           // 8 strips of 3-4 tiles; here: 3 tiles of 32 columns (+1 for even strips)
+      const int kb0 = strip * 3 + (strip < 2 ? strip : 2), nt = strip < 2 ? 4 : 3;
+      for (int j = 0; j < 4; j++)
+        for (int ii = 0; ii < 4; ii++) {
+          const int ro = ii + 8 * j;
+          if (PAT == 0) {
+            for (int t = 0; t < nt; t++) {
+              const int col = 32 * (kb0 + t) + (lane & 31), row = ro + 4 * (lane >> 5);
+              if (col < N) blk[row * N + col] = (unsigned short)(rb + col);
+            }
+          } else if (PAT == 2) {                                 // quad-packed: one 8-byte store per lane = 4 columns of row (lane & 3)
+            if (ii == 0)
+              for (int t = 0; t < nt; t++) {
+                const int col = 32 * (kb0 + t) + (lane & 28), row = 8 * j + (lane & 3) + 4 * (lane >> 5);
+                if (col + 4 <= N) *(unsigned long long*)(blk + row * N + col) = (unsigned long long)(rb + col) * 0x0001000100010001ull;
+              }
+          } else {
+            for (int half = 0; half < 2; half++)                 // rows ro and ro + 4, each as 64-column instructions
+              for (int t = 0; t < nt; t += 2) {
+                const int col = 32 * (kb0 + t) + lane, row = ro + 4 * half;
+                if (col < N && (t + 1 < nt || lane < 32)) blk[row * N + col] = (unsigned short)(rb + col);
+              }
+          }
+        }
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount; const int N = argc > 1 ? atoi(argv[1]) : 821;
+  const long nrb = 32768;
+  unsigned short* d; CK(hipMalloc(&d, (size_t)nrb * 32 * N * 2));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int pat = 0; pat < 3; pat++)
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipEventRecord(e0));
+      if (pat == 0) k<0><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 1) k<1><<<cus * 2, 256>>>(d, nrb, N); else k<2><<<cus * 2, 256>>>(d, nrb, N);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep == 2) printf("pattern %d (%s): %.3f ms  %.0f GB/s\n", pat, pat == 0 ? "2 rows x 64 B per instruction" : pat == 1 ? "1 row x 128 B per instruction" : "8 rows x 64 B per instruction (8 B per lane)", ms,
+                           (double)nrb * 32 * N * 2 / ms * 1e-6);
+    }
+  return 0;
+}
