@@ -1598,20 +1598,29 @@ __global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u3
 // checks accept some non-units and return garbage for them: tests/golden/keygen_cases.json).  Polynomials are bit
 // planes in LDS, [array][word][lane]; GF(3) uses two planes per polynomial (plane 0: coefficient == 1, plane 1: == 2).
 
-template <int P>
+// NWC > 0: the planes are NWC words per polynomial held in REGISTERS (every word loop is unrolled, so all indices are
+// compile-time): no LDS traffic and 8 waves per CU instead of 3; NWC = 0: any N, planes in LDS.
+template <int P, int NWC>
 __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restrict__ f, long B, u16 *__restrict__ out16,
                                                    uint8_t *__restrict__ out8, uint8_t *__restrict__ flags, u32 flag_bit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PL = P == 2 ? 1 : 2;                      // bit planes per polynomial
-  const int lane = threadIdx.x, NW = (N + 1 + 31) >> 5;    // N + 1 coefficients: the reversed modulus has degree N
+  constexpr int UNR = NWC ? 64 : 1;                       // word loops: fully unrolled for register planes
+  const int lane = threadIdx.x;
+  const int NW = NWC ? NWC : (N + 1 + 31) >> 5;            // N + 1 coefficients: the reversed modulus has degree N
   u32 *base = (u32 *)lds;
-  auto at = [&](int arr, int pl, int w) -> u32 & { return base[((arr * PL + pl) * NW + w) * 64 + lane]; };
+  u32 regs[NWC ? 4 * PL * NWC : 1];
+  auto at = [&](int arr, int pl, int w) -> u32 & {
+    if constexpr (NWC > 0) return regs[(arr * PL + pl) * NWC + w];
+    else return base[((arr * PL + pl) * NW + w) * 64 + lane];
+  };
   enum { AF = 0, AG = 1, AV = 2, AW = 3 };
   for (long k0 = (long)blockIdx.x * 64; k0 < B; k0 += (long)gridDim.x * 64) {
     const long key = k0 + lane;
     const bool have = key < B;
     const int8_t *fk = f + (have ? key : 0) * N;
     // ff = rev(x^N - 1) = 1 - x^N, gg = rev_{N-1}(f), vv = 0, ww = 1
+#pragma unroll UNR
     for (int w = 0; w < NW; w++) {
       u32 g1 = 0, g2 = 0;
       for (int b = 0; b < 32; b++) {
@@ -1657,6 +1666,7 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       u32 vcar[PL], gprev[PL];
 #pragma unroll
       for (int pl = 0; pl < PL; pl++) { vcar[pl] = 0; gprev[pl] = 0; }
+#pragma unroll UNR
       for (int w = 0; w < NW; w++) {
         u32 F[PL], G[PL], V[PL], W[PL];
 #pragma unroll
@@ -1689,24 +1699,27 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
     }
     // unit iff the gcd (in ff) is a non-zero constant
     u32 rest = 0;
+#pragma unroll UNR
     for (int w = 0; w < NW; w++)
+#pragma unroll
       for (int pl = 0; pl < PL; pl++) rest |= at(AF, pl, w) & (w == 0 ? ~1u : ~0u);
     const int fc = (int)(at(AF, 0, 0) & 1u) + (P == 3 ? 2 * (int)(at(AF, 1, 0) & 1u) : 0);
     const bool unit = rest == 0 && fc != 0;
     if (have) {
       if (!unit) flags[key] = (uint8_t)(flags[key] | flag_bit);
       // inverse[i] = fc^-1 * vv[N-1-i]; in GF(3) fc^-1 = fc
-      for (int i = 0; i < N; i++) {
-        const int j = N - 1 - i;
-        int c = (int)((at(AV, 0, j >> 5) >> (j & 31)) & 1u);
-        if (P == 3) {
-          const int c2 = (int)((at(AV, 1, j >> 5) >> (j & 31)) & 1u);
-          c = c + 2 * c2;
-          if (fc == 2) c = (2 * c) % 3;
+#pragma unroll UNR
+      for (int w = 0; w < NW; w++) {
+        const u32 p0 = at(AV, 0, w), p1 = P == 3 ? at(AV, 1, w) : 0u;
+        for (int b = 0; b < 32; b++) {
+          const int i = N - 1 - (32 * w + b);
+          if (i < 0) break;
+          int c = (int)((p0 >> b) & 1u) + 2 * (int)((p1 >> b) & 1u);
+          if (P == 3 && fc == 2) c = (2 * c) % 3;
+          c = unit ? c : 0;
+          if (out16) out16[key * N + i] = (u16)c;
+          if (out8) out8[key * N + i] = (uint8_t)c;
         }
-        c = unit ? c : 0;
-        if (out16) out16[key * N + i] = (u16)c;
-        if (out8) out8[key * N + i] = (uint8_t)c;
       }
     }
   }
@@ -3012,20 +3025,32 @@ extern "C" int ntru_polymul_split(ntru_engine_t *eng, int N, int mod, const uint
   return NTRU_OK;
 }
 
+template <int P, int NWC>
+static int launch_invert_nw(ntru_engine *eng, int N, const int8_t *d_f, long B, uint16_t *d16, uint8_t *d8, uint8_t *d_flags,
+                            unsigned bit) {
+  const size_t lds = NWC ? 0 : (size_t)(P == 2 ? 4 : 8) * ((N + 32) / 32) * 64 * 4;
+  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the inversion kernel's LDS planes");
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_invert_key<P, NWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_invert_key<P, NWC>, 64, lds));
+  long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((k_invert_key<P, NWC>), dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, d_f, B, (u16 *)d16, d8,
+                     d_flags, (u32)bit);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+// Register-resident planes for the word counts below (N + 1 bits rounded up to the next size), LDS planes otherwise.
 template <int P>
 static int launch_invert(ntru_engine *eng, int N, const int8_t *d_f, long B, uint16_t *d16, uint8_t *d8, uint8_t *d_flags,
                          unsigned bit) {
-  const size_t lds = (size_t)(P == 2 ? 4 : 8) * ((N + 32) / 32) * 64 * 4;
-  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the inversion kernel's LDS planes");
-  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_invert_key<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_invert_key<P>, 64, lds));
-  long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_invert_key<P>, dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, d_f, B, (u16 *)d16, d8, d_flags,
-                     (u32)bit);
-  HIP_TRY(hipGetLastError());
-  return NTRU_OK;
+  const int nw = (N + 32) / 32;
+#define INV_CASE(W) if (nw <= W) return launch_invert_nw<P, W>(eng, N, d_f, B, d16, d8, d_flags, bit);
+  INV_CASE(2) INV_CASE(6) INV_CASE(12) INV_CASE(16) INV_CASE(22) INV_CASE(26)
+  if constexpr (P == 2) { INV_CASE(32) }
+#undef INV_CASE
+  return launch_invert_nw<P, 0>(eng, N, d_f, B, d16, d8, d_flags, bit);
 }
 
 extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, int64_t B,
