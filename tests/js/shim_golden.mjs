@@ -63,6 +63,13 @@ for (const profile of ['n17_q32', 'n167_q128', 'n509_q2048', 'n821_q4096', 'n701
       const wrong = new NTRU({ ...g.options, f: other.f, fp: other.fp, h: k.h });
       notStrictEqual(wrong.decryptStr(ntru.encryptStr('Hello World')), 'Hello World');
     }
+    // test/reference.test.js:6-14 verbatim: a key generated from scratch (all of it on the device) round-trips
+    const fresh = new NTRU({ ...g.options });
+    fresh.generatePrivateKeyF();
+    fresh.generateNewPublicKeyGH();
+    fresh.verifyKeysInputs();                             // throws if fq, fp or h were wrong
+    strictEqual(fresh.decryptStr(fresh.encryptStr('Hello World')), 'Hello World');
+    checks++;
     globalThis.crypto = { getRandomValues(a) { for (let i = 0; i < a.length; i++) a[i] = tape[pos++]; return a; } };
     checks += 2;
   }

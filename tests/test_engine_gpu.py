@@ -319,6 +319,16 @@ def test_key_inversion_equals_reference_keys(eng, scheme_golden):
         assert n.verifyKeysInputs() == key["verifyKeysInputs"]
 
 
+def test_fresh_key_round_trip_like_reference_test(eng):
+    """test/reference.test.js:6-14 with nothing supplied: generatePrivateKeyF + generateNewPublicKeyGH on the device,
+    verifyKeysInputs accepts the key, a string survives encrypt + decrypt (q = 128 is 2 mod 3: SURVEY 0.4)."""
+    n = pkg.NTRU(dict(N=167, q=128, p=3, df=61, dg=20, dr=18), engine=eng)
+    n.generatePrivateKeyF()
+    n.generateNewPublicKeyGH()
+    n.verifyKeysInputs()
+    assert n.decryptStr(n.encryptStr("Hello World")) == "Hello World"
+
+
 def test_key_inversion_captured_cases_and_random_keys(eng):
     """tests/golden/keygen_cases.json: for every f that IS a unit mod 2 and mod 3 the device equals the reference; for the
     others the matching flag is set (the reference throws for most of them and accepts some: documented deviation).
