@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix"], default="auto",
                     help="kernel family: packed-u16 MAC, ternary add path, or the engine's choice (same results)")
+    ap.add_argument("--row-pitch", type=int, default=0,
+                    help="row pitch of the batch arrays in elements (0 = dense rows of N elements; -1 = N rounded up to "
+                         "a multiple of 64, i.e. rows on cache-line boundaries: ntru_*_batch_pitched_dev)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only for rehearsing the launch path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="override the HIP device (default LOCAL_RANK)")
@@ -61,11 +64,13 @@ def load_key(profile):
     return o, pad(key["h"], np.uint16), pad(key["f"], np.int8), pad(key["fp"], np.uint8)
 
 
-def make_inputs(torch, dev, B, N, d, seed):
-    """m iid uniform {0,1}; r = d ones and d twos per row, shuffled."""
+def make_inputs(torch, dev, B, N, d, seed, ld=None):
+    """m iid uniform {0,1}; r = d ones and d twos per row, shuffled.  Rows at a pitch of ld
+    elements (default N); pad elements are zero."""
+    ld = ld or N
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    r = torch.zeros((B, N), dtype=torch.uint8, device=dev)
+    r = torch.zeros((B, ld), dtype=torch.uint8, device=dev)
     chunk = min(B, 1 << 16)
     for o in range(0, B, chunk):
         n = min(chunk, B - o)
@@ -74,6 +79,10 @@ def make_inputs(torch, dev, B, N, d, seed):
         r[o:o + n].scatter_(1, idx[:, d:2 * d], 2)
         del idx
     m = torch.randint(0, 2, (B, N), dtype=torch.uint8, device=dev, generator=gen)
+    if ld != N:
+        mp = torch.zeros((B, ld), dtype=torch.uint8, device=dev)
+        mp[:, :N] = m
+        m = mp
     return r, m
 
 
@@ -147,13 +156,15 @@ def main():
     B = 1 << args.batch_log2
     sh = pkg.sharding
     seed = sh.shard_seed(20240, rank)
-    r, m = make_inputs(torch, dev, B, N, d, seed)
+    LD = N if args.row_pitch == 0 else ((N + 63) // 64 * 64 if args.row_pitch < 0 else args.row_pitch)
+    pitched = LD != N
+    r, m = make_inputs(torch, dev, B, N, d, seed, LD)
     h = torch.from_numpy(h_np.view(np.int16)).to(dev)
     f = torch.from_numpy(f_np).to(dev)
     fp = torch.from_numpy(fp_np).to(dev)
     witness = args.mode == "witness"
-    b16 = lambda: torch.empty((B, N), dtype=torch.int16, device=dev)     # raw uint16 patterns
-    b8 = lambda: torch.empty((B, N), dtype=torch.uint8, device=dev)
+    b16 = lambda: torch.empty((B, LD), dtype=torch.int16, device=dev)    # raw uint16 patterns
+    b8 = lambda: torch.empty((B, LD), dtype=torch.uint8, device=dev)
     e, value = b16(), b8()
     quotE, quot1, rem1, quot2 = (b16(), b16(), b16(), b8()) if witness else (None, None, None, None)
     ptr = lambda t: t.data_ptr() if t is not None else None
@@ -163,18 +174,23 @@ def main():
     eng.set_stream(stream.cuda_stream)
     if args.sample_r:
         key = np.arange(8, dtype=np.uint32) * 0x9E3779B1 + 20240
+        if pitched:
+            raise SystemExit("bench: --sample-r writes dense rows; use it with --row-pitch 0")
         eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
         torch.cuda.synchronize()
     eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4}[args.kernel_path])
 
     names = {}
 
-    def step(ev=None):
+    bufs = (r, m, e, quotE, value, quot1, rem1, quot2)
+
+    def step(ev=None, bufs=bufs, ld=LD if pitched else None):
+        r_, m_, e_, qe_, v_, q1_, r1_, q2_ = bufs
         if ev: ev[0].record(stream)
-        eng.encrypt_batch_dev(N, q, ptr(h), ptr(r), ptr(m), B, ptr(e), ptr(quotE))
+        eng.encrypt_batch_dev(N, q, ptr(h), ptr(r_), ptr(m_), B, ptr(e_), ptr(qe_), ld=ld)
         names["encrypt"] = eng.last_kernel()
         if ev: ev[1].record(stream)
-        eng.decrypt_batch_dev(N, q, p, ptr(f), ptr(fp), ptr(e), B, ptr(value), ptr(quot1), ptr(rem1), ptr(quot2))
+        eng.decrypt_batch_dev(N, q, p, ptr(f), ptr(fp), ptr(e_), B, ptr(v_), ptr(q1_), ptr(r1_), ptr(q2_), ld=ld)
         names["decrypt"] = eng.last_kernel()
         if ev: ev[2].record(stream)
 
@@ -193,7 +209,7 @@ def main():
     # ---- bit-exact check of a sample against the CPU oracle (outside the timed region) --------------------
     from oracle import ntru_oracle as orc
     rows = torch.tensor(sorted(set(list(range(0, B, max(1, B // 48))) + [B - 1])), device=dev)
-    host = lambda t: (lambda a: a.view(np.uint16) if a.dtype == np.int16 else a)(t[rows].cpu().numpy())
+    host = lambda t: (lambda a: a.view(np.uint16) if a.dtype == np.int16 else a)(t[rows][:, :N].contiguous().cpu().numpy())
     e_o, qe_o = orc.encrypt_batch(N, q, h_np, host(r), host(m))
     v_o, q1_o, r1_o, q2_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)
     ok = np.array_equal(host(e), e_o) and np.array_equal(host(value), v_o)
@@ -267,6 +283,7 @@ def main():
                                    "%s outputs" % (N, q, p, d, args.batch_log2,
                                                    "full-witness" if witness else "value-only"),
                        "mode": args.mode, "kernel_path": args.kernel_path,
+                       "row_pitch_elements": LD,
                        "arithmetic": "int8 digit planes on the matrix cores, int32 accumulation (exact)" if mfma else "exact u16 vector ALU", "seed": 20240, "r_source": "device sampler" if args.sample_r else "torch",
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "verified_bit_exact_rows": int(rows.numel()),
@@ -284,13 +301,17 @@ def main():
         if world == 1 and args.kernel_path == "auto" and names.get("decrypt", "").endswith("_m"):
             # The wavefront-per-ciphertext VALU families (BASELINE north_star's design), same buffers, outside the timed
             # region: a few steps, and their outputs must equal the ones just verified.
-            ref_out = [t.clone() for t in (e, value)]
+            ref_out = [t[:, :N].clone() for t in (e, value)]
+            alt = bufs
+            if pitched:      # those families read and write dense rows: give them dense copies of the same inputs
+                dense = lambda t: None if t is None else torch.empty((B, N), dtype=t.dtype, device=dev)
+                alt = (r[:, :N].contiguous(), m[:, :N].contiguous()) + tuple(dense(t) for t in bufs[2:])
             eng.set_kernel_path(2)
-            step(); torch.cuda.synchronize()
-            same = all(bool(torch.equal(a, b)) for a, b in zip(ref_out, (e, value)))
+            step(None, alt, None); torch.cuda.synchronize()
+            same = all(bool(torch.equal(a, b)) for a, b in zip(ref_out, (alt[2], alt[4])))
             alt_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(3)]
             for ev in alt_ev:
-                step(ev)
+                step(ev, alt, None)
             torch.cuda.synchronize()
             a_enc = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in alt_ev]))
             a_dec = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in alt_ev]))
@@ -307,7 +328,7 @@ def main():
             out["gather"] = gathered
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = 4096
-            rr, mm = r[:n_cpu].cpu().numpy(), m[:n_cpu].cpu().numpy()
+            rr, mm = r[:n_cpu, :N].contiguous().cpu().numpy(), m[:n_cpu, :N].contiguous().cpu().numpy()
             faithful, optimized = cpu_baseline(N, q, p, h_np, f_np, fp_np, rr, mm, args.cpu_seconds)
             out["cpu_baseline"] = faithful
             out["cpu_baseline_optimized"] = optimized

@@ -140,6 +140,22 @@ int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t
                            const uint16_t *d_e, int64_t B, uint8_t *d_value, uint16_t *d_quot1,
                            uint16_t *d_rem1, uint8_t *d_quot2);
 
+/* The same two operations on PITCHED batch arrays: row b of every batch array (r, m, e, quotE / e, value, quot1, rem1,
+ * quot2) starts at element b * ld of its array, ld >= N elements (so 2 * ld bytes for the uint16 arrays and ld bytes for
+ * the byte arrays); each array holds B * ld elements, the ld - N pad elements of a row are neither read into the result
+ * nor written.  ld == N is the dense layout of the entry points above.  A pitch that makes rows start on cache-line
+ * boundaries (ld a multiple of 64) lets the result stores go out as whole lines: at N = 821 the store pattern alone
+ * reaches 3.3 TB/s at ld = 832 against 2.4 TB/s at ld = 821; inside the kernels that is worth 5-7 % of encrypt and
+ * 2-3 % of a round trip (profiles/r01_bench_row_pitch_ab.jsonl).  The reference has no memory
+ * layout of its own (JS arrays, index.js:87-140), so the pitch is purely the host binding's choice.
+ * Only the matrix-core kernels take a pitch: with ld != N the call fails with NTRU_ERR_UNSUPPORTED where they do not
+ * apply (kernel path 1-3 forced, q > 8192, N or ld > 1024, p != 3). */
+int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, int ld, const uint16_t *d_h, const uint8_t *d_r,
+                                   const uint8_t *d_m, int64_t B, uint16_t *d_e, uint16_t *d_quotE);
+int ntru_decrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, int p, int ld, const int8_t *d_f,
+                                   const uint8_t *d_fp, const uint16_t *d_e, int64_t B, uint8_t *d_value,
+                                   uint16_t *d_quot1, uint16_t *d_rem1, uint8_t *d_quot2);
+
 /* loadPrivateKeyF / polyInv (index.js:30-49, 491-514) for B keys: fq[b] = f[b]^-1 in Z_q[x]/(x^N - 1) (q a power of two:
  * inverse modulo 2, then Newton rounds v <- 2v - f v^2), fp[b] = f[b]^-1 modulo p = 3; f in {-1,0,1}.  The inverse is
  * unique, so for units the result equals the reference's Euclidean algorithm bit for bit.  For f that is not a unit the

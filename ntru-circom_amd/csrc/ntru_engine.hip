@@ -1802,6 +1802,7 @@ struct MGeom {
   int NT;       // 32-wide tiles per row: ceil(N / 32)
   int pitchA;   // bytes per row of an operand stage: 32 NT + 16
   int tpitch;   // dwords per byte-shifted copy of a reversed key array (= 8 mod 32: the 4 copies use disjoint banks)
+  int ld;       // row pitch of every batch array in ELEMENTS (>= N; N for the dense layout of the plain entry points)
 };
 
 enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
@@ -2076,7 +2077,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;
   unsigned char *stA = (unsigned char *)(T1 + 4 * g.tpitch);
-  unsigned char *mimg = stA + 32 * g.pitchA;             // rows b0..b0+31 of m exactly as in memory (pitch N)
+  unsigned char *mimg = stA + 32 * g.pitchA;             // rows b0..b0+31 of m exactly as in memory (pitch g.ld)
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int hthr = (int)(q >> 1) - 65;
   auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
@@ -2090,14 +2091,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
     STAMP(0);
     // Re-materialise the lane index and N per row block: otherwise every per-lane address / predicate of the staging
     // and of the epilogues is hoisted out of this loop and spilled around the matrix loops.
-    int lane = lane0, N = g.N, tid = tid0;
-    asm volatile("" : "+v"(lane), "+s"(N), "+v"(tid));
+    int lane = lane0, N = g.N, LD = g.ld, tid = tid0;
+    asm volatile("" : "+v"(lane), "+s"(N), "+s"(LD), "+v"(tid));
     const u32 *tb0 = frag_lane_base(T0, g, lane), *tb1 = frag_lane_base(T1, g, lane);
     const unsigned char *st0 = stA + (lane & 31) * g.pitchA + 16 * (lane >> 5);
     u32 mlow[4];
     diag_low_mask(lane, mlow);
-    const long b0 = rb << 5, left = (B - b0) * N;        // elements from this row block to the end of the batch
-    const AlignedSrc src_r = aligned_src(r + b0 * N, left), src_m = aligned_src(m + b0 * N, left);
+    const long b0 = rb << 5, left = (B - b0) * LD;       // elements from this row block to the end of the batch
+    const AlignedSrc src_r = aligned_src(r + b0 * LD, left), src_m = aligned_src(m + b0 * LD, left);
     // All loads of the row block (r rows and the m image) are requested BEFORE the barrier: they land in registers, so
     // they need not wait for the previous row block's readers, and the two HBM round trips become one that overlaps the
     // barrier wait (phase stamps: 4.5 k + 4.5 k cycles back to back before).  N <= 1024: lane = 16-byte chunk of a row.
@@ -2107,7 +2108,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
     {
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
-        const int pos0 = src_r.a0 + (wave + WAVES_PER_BLOCK * j) * N;
+        const int pos0 = src_r.a0 + (wave + WAVES_PER_BLOCK * j) * LD;
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
         in_r[j] = fake_raw<1>(pos0 + lane);
 #else
@@ -2132,7 +2133,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
       for (int j = 0; j < RPW; j++) {
         const int row = wave + WAVES_PER_BLOCK * j;
         v4i v[1];
-        shift_raw<1>(in_r[j], src_r.a0 + row * N, v);
+        shift_raw<1>(in_r[j], src_r.a0 + row * LD, v);
         if (lane < 2 * g.NT) *(v4i *)(stA + row * g.pitchA + 16 * lane) = v[0] & mk;
       }
       STAMP(16);
@@ -2141,7 +2142,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
         const int i = tid * 16 + j * BLOCK_THREADS * 16;
         v4i v[1];
         shift_raw<1>(in_m[j], shm, v);
-        if (i < 32 * N) *(v4i *)(mimg + i) = v[0];
+        if (i < 32 * LD) *(v4i *)(mimg + i) = v[0];
       }
     }
     STAMP(2);
@@ -2153,7 +2154,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
       // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
       // (Packing 4 columns per lane with in-quad transposes and 64-bit stores was measured 8 % slower: the rows are only
       // 2-byte aligned.)
-      const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
+      const int lane_off = (lane >> 5) * 4 * LD + (lane & 31);
       auto epi = [&](auto &lo, auto &hi) {               // arrays of the strip's tiles
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
         long bb = b0;                                    // descriptors made where they are used: see k_decrypt_m
@@ -2161,9 +2162,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
         bb = 0;                                          // timing only: every workgroup writes the first row block (L2-resident)
 #endif
         asm volatile("" : "+s"(bb));
-        const long lf = (B - bb) * N;
-        const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + bb * N, 2 * lf);
-        const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quotE + bb * N : e + bb * N, 2 * lf);
+        const long lf = (B - bb) * LD;
+        const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + bb * LD, 2 * lf);
+        const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quotE + bb * LD : e + bb * LD, 2 * lf);
         const unsigned char *m_l = mimg + 32 * kb0 + lane_off;
         auto out = [&](auto wq) {
 #pragma unroll
@@ -2172,10 +2173,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
 #pragma unroll
             for (int t = 0; t < NTS; t++)
 #pragma unroll
-              for (int ii = 0; ii < 4; ii++) mv[t][ii] = m_l[(8 * j + ii) * N + 32 * t];
+              for (int ii = 0; ii < 4; ii++) mv[t][ii] = m_l[(8 * j + ii) * LD + 32 * t];
 #pragma unroll
             for (int t = 0; t < NTS; t++) {
-              const int so = 2 * (8 * j * N + 32 * (kb0 + t));
+              const int so = 2 * (8 * j * LD + 32 * (kb0 + t));
               u32 ev[4], qv[4];
 #pragma unroll
               for (int ii = 0; ii < 4; ii++) {
@@ -2185,8 +2186,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
               if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][4 * j])) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ii++) {
-                  __builtin_amdgcn_raw_buffer_store_b16((u16)ev[ii], rs_e, 2 * lane_off, so + 2 * ii * N, ST_AUX);
-                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)qv[ii], rs_q, 2 * lane_off, so + 2 * ii * N, ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b16((u16)ev[ii], rs_e, 2 * lane_off, so + 2 * ii * LD, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)qv[ii], rs_q, 2 * lane_off, so + 2 * ii * LD, ST_AUX);
                 }
               }
             }
@@ -2234,15 +2235,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
   for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     stamp_iter++;
     STAMP(0);
-    int lane = lane0, N = g.N;                           // see k_encrypt_m
-    asm volatile("" : "+v"(lane), "+s"(N));
+    int lane = lane0, N = g.N, LD = g.ld;                // see k_encrypt_m
+    asm volatile("" : "+v"(lane), "+s"(N), "+s"(LD));
     const u32 *tbf = frag_lane_base(TF, g, lane), *tbp = frag_lane_base(TP, g, lane);
     const unsigned char *st0 = stLo + (lane & 31) * g.pitchA + 16 * (lane >> 5);
     const unsigned char *st1 = stHi + (lane & 31) * g.pitchA + 16 * (lane >> 5);
     u32 mlow[4];
     diag_low_mask(lane, mlow);
-    const long b0 = rb << 5, left = (B - b0) * N;
-    const AlignedSrc src_e = aligned_src(e + b0 * N, 2 * left);
+    const long b0 = rb << 5, left = (B - b0) * LD;
+    const AlignedSrc src_e = aligned_src(e + b0 * LD, 2 * left);
     // (requesting these loads before the barrier, as k_encrypt_m does, measured 3 % slower here.)  lane = 16 coefficients.
     __syncthreads();
     STAMP(1);
@@ -2253,7 +2254,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       int sh[RPW];
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
-        const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * N;
+        const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * LD;
         sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
         raw[j] = fake_raw<2>(pos0 + c16);
@@ -2292,7 +2293,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     STAMP(2);
     __syncthreads();
     STAMP(3);
-    const int lane_off = (lane >> 5) * 4 * N + (lane & 31);
+    const int lane_off = (lane >> 5) * 4 * LD + (lane & 31);
     // ---- product 1: a = f * e mod q; witness stores; lifted message -> packed image
     sidx = 0;
     for_each_strip(g.NT, wave, [&](int kb0, int nt) {
@@ -2303,9 +2304,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         // waterfall loop)
         long bb = b0;
         asm volatile("" : "+s"(bb));
-        const long lf = (B - bb) * N;
-        const __amdgpu_buffer_rsrc_t rs_r1 = rows_rsrc(want_r1 ? rem1 + bb * N : nullptr, want_r1 ? 2 * lf : 0);
-        const __amdgpu_buffer_rsrc_t rs_q1 = rows_rsrc(want_q1 ? quot1 + bb * N : nullptr, want_q1 ? 2 * lf : 0);
+        const long lf = (B - bb) * LD;
+        const __amdgpu_buffer_rsrc_t rs_r1 = rows_rsrc(want_r1 ? rem1 + bb * LD : nullptr, want_r1 ? 2 * lf : 0);
+        const __amdgpu_buffer_rsrc_t rs_q1 = rows_rsrc(want_q1 ? quot1 + bb * LD : nullptr, want_q1 ? 2 * lf : 0);
         auto out = [&](auto wr, auto wq) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {                  // 4 rows x the strip's tiles at a time: remainders (and their
@@ -2317,7 +2318,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
               for (int t = 0; t < NTS; t++) {
                 const u32 x = (u32)(lo[t][i] + hi[t][i]) & (q - 1);
                 xs[t][ii] = x;
-                const int so = 2 * (ro * N + 32 * (kb0 + t));
+                const int so = 2 * (ro * LD + 32 * (kb0 + t));
                 if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
                   if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, 2 * lane_off, so, ST_AUX);
                   if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, 2 * lane_off, so, ST_AUX);
@@ -2388,9 +2389,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
         long bb = b0;                                    // see product 1
         asm volatile("" : "+s"(bb));
-        const long lf = (B - bb) * N;
-        const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value + bb * N, lf);
-        const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + bb * N : nullptr, want_q2 ? lf : 0);
+        const long lf = (B - bb) * LD;
+        const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value + bb * LD, lf);
+        const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + bb * LD : nullptr, want_q2 ? lf : 0);
         auto out = [&](auto wq) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {                  // lookups of 4 rows x the strip's tiles in flight before their stores
@@ -2406,7 +2407,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
             for (int ii = 0; ii < 4; ii++) {
 #pragma unroll
               for (int t = 0; t < NTS; t++) {
-                const int so = (ii + 8 * j) * N + 32 * (kb0 + t);
+                const int so = (ii + 8 * j) * LD + 32 * (kb0 + t);
                 if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][4 * j + ii])) {
                   __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(va[t][ii] & 3), rs_v, lane_off, so, ST_AUX);
                   if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(vb[t][ii] >> 2), rs_q2, lane_off, so, ST_AUX);
@@ -2591,10 +2592,11 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
 }
 
 // Matrix-core path (family 4): shared key, q a power of two <= 8192 (two int8 digit planes), LDS for a 32-row block.
-static bool make_mgeom(const ntru_engine *eng, int N, int q, MGeom *g) {
+static bool make_mgeom(const ntru_engine *eng, int N, int q, int ld, MGeom *g) {
   if (eng->path != 0 && eng->path != 4) return false;
-  if (q > 8192 || N > 1024 || N < (eng->path == 4 ? 2 : 64)) return false;   // staging: lane = 16-byte chunk of a row
+  if (q > 8192 || N > 1024 || ld > 1024 || N < (eng->path == 4 || ld != N ? 2 : 64)) return false;   // staging: lane = 16-byte chunk of a row
   g->N = N;
+  g->ld = ld;
   g->NT = (N + 31) / 32;
   g->pitchA = 32 * g->NT + 16;
   g->tpitch = ((16 * g->NT + 31) / 32) * 32 + 8;
@@ -2671,17 +2673,30 @@ static int check_common(const ntru_engine *eng, int N, int q, long B) {
   return NTRU_OK;
 }
 
+static int check_pitch(int N, int ld) {
+  if (ld < N || ld > 1024) return fail(NTRU_ERR_ARG, "row pitch must satisfy N <= ld <= 1024 elements");
+  return NTRU_OK;
+}
+static const char *const kPitchedOnly = "a row pitch other than N needs the matrix-core kernels (kernel path 0 or 4, q <= 8192, N <= 1024, p == 3)";
+
 extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const uint16_t *d_h, const uint8_t *d_r,
                                       const uint8_t *d_m, int64_t B, uint16_t *d_e, uint16_t *d_quotE) {
+  return ntru_encrypt_batch_pitched_dev(eng, N, q, N, d_h, d_r, d_m, B, d_e, d_quotE);
+}
+
+extern "C" int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, int ld, const uint16_t *d_h,
+                                              const uint8_t *d_r, const uint8_t *d_m, int64_t B, uint16_t *d_e,
+                                              uint16_t *d_quotE) {
   if (int rc = check_common(eng, N, q, B)) return rc;
+  if (ld != N) if (int rc = check_pitch(N, ld)) return rc;
   if (B == 0) return NTRU_OK;
   if (!d_h || !d_r || !d_m || !d_e) return fail(NTRU_ERR_ARG, "ntru_encrypt_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
   {
     MGeom mg;
-    const size_t lds = make_mgeom(eng, N, q, &mg)
-                           ? (size_t)32 * mg.tpitch + (size_t)32 * mg.pitchA + (((size_t)32 * N + 15) & ~(size_t)15) + 16 : 0;
+    const size_t lds = make_mgeom(eng, N, q, ld, &mg)
+                           ? (size_t)32 * mg.tpitch + (size_t)32 * mg.pitchA + (((size_t)32 * ld + 15) & ~(size_t)15) + 16 : 0;
     if (lds && lds <= 160 * 1024) {
       if (int rc = allow_lds(k_encrypt_m, lds)) return rc;
       if (int rc = resident_grid(eng, k_encrypt_m, lds, (long)((B + 31) / 32), &L.grid)) return rc;
@@ -2692,6 +2707,7 @@ extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const ui
       return NTRU_OK;
     }
   }
+  if (ld != N) return fail(NTRU_ERR_UNSUPPORTED, kPitchedOnly);
   if (const int me = add_path_me(eng, N, q)) {
     Geom g0 = make_geom(N, pick_K(N));
     if (int rc = plan_add(eng, N, B, (size_t)g0.eo_len * 8, (size_t)g0.nl * 4, &L)) return rc;
@@ -2720,7 +2736,14 @@ extern "C" int ntru_encrypt_batch_dev(ntru_engine_t *eng, int N, int q, const ui
 extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f,
                                       const uint8_t *d_fp, const uint16_t *d_e, int64_t B, uint8_t *d_value,
                                       uint16_t *d_quot1, uint16_t *d_rem1, uint8_t *d_quot2) {
+  return ntru_decrypt_batch_pitched_dev(eng, N, q, p, N, d_f, d_fp, d_e, B, d_value, d_quot1, d_rem1, d_quot2);
+}
+
+extern "C" int ntru_decrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, int p, int ld, const int8_t *d_f,
+                                              const uint8_t *d_fp, const uint16_t *d_e, int64_t B, uint8_t *d_value,
+                                              uint16_t *d_quot1, uint16_t *d_rem1, uint8_t *d_quot2) {
   if (int rc = check_common(eng, N, q, B)) return rc;
+  if (ld != N) if (int rc = check_pitch(N, ld)) return rc;
   if (is_pow2(p) || !ntru_engine_supports(N, p))
     return fail(NTRU_ERR_UNSUPPORTED, "unsupported p: need a small non-power-of-two modulus with N*(p-1)^2 < 65536");
   if (B == 0) return NTRU_OK;
@@ -2729,7 +2752,7 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
   Launch L;
   {
     MGeom mg;
-    const size_t lds = (p == 3 && make_mgeom(eng, N, q, &mg))
+    const size_t lds = (p == 3 && make_mgeom(eng, N, q, ld, &mg))
                            ? (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT + (((size_t)q + 15) & ~(size_t)15) : 0;
     if (lds && lds <= 160 * 1024) {
       if (int rc = allow_lds(k_decrypt_m, lds)) return rc;
@@ -2741,6 +2764,7 @@ extern "C" int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, c
       return NTRU_OK;
     }
   }
+  if (ld != N) return fail(NTRU_ERR_UNSUPPORTED, kPitchedOnly);
   {
     int me = 0;
     if (const int KS = shared_path_K(eng, N, q, p, &me)) {

@@ -52,6 +52,8 @@ for _sfx in ("", "_dev"):
     _SIGS["ntru_encrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
     _SIGS["ntru_decrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
     _SIGS["ntru_verify_keys_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i] + [_vp] * 5 + [_i64] + [_vp] * 7)
+_SIGS["ntru_encrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
+_SIGS["ntru_decrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
 
 
 def _preload_hip_runtime():
@@ -274,14 +276,24 @@ class Engine:
         dp = self._dp
         self._chk(self._lib.ntru_add_batch_dev(self._h, N, mod, dp(d_a), dp(d_b), B, dp(d_out)))
 
-    def encrypt_batch_dev(self, N, q, d_h, d_r, d_m, B, d_e, d_quotE=None):
+    def encrypt_batch_dev(self, N, q, d_h, d_r, d_m, B, d_e, d_quotE=None, ld=None):
+        """ld: row pitch of r, m, e, quotE in elements (None = dense rows of N; see ntru_encrypt_batch_pitched_dev)."""
         dp = self._dp
-        self._chk(self._lib.ntru_encrypt_batch_dev(self._h, N, q, dp(d_h), dp(d_r), dp(d_m), B, dp(d_e), dp(d_quotE)))
+        if ld is None:
+            self._chk(self._lib.ntru_encrypt_batch_dev(self._h, N, q, dp(d_h), dp(d_r), dp(d_m), B, dp(d_e), dp(d_quotE)))
+        else:
+            self._chk(self._lib.ntru_encrypt_batch_pitched_dev(self._h, N, q, int(ld), dp(d_h), dp(d_r), dp(d_m), B,
+                                                               dp(d_e), dp(d_quotE)))
 
-    def decrypt_batch_dev(self, N, q, p, d_f, d_fp, d_e, B, d_value, d_quot1=None, d_rem1=None, d_quot2=None):
+    def decrypt_batch_dev(self, N, q, p, d_f, d_fp, d_e, B, d_value, d_quot1=None, d_rem1=None, d_quot2=None, ld=None):
+        """ld: row pitch of e, value, quot1, rem1, quot2 in elements (None = dense rows of N)."""
         dp = self._dp
-        self._chk(self._lib.ntru_decrypt_batch_dev(self._h, N, q, p, dp(d_f), dp(d_fp), dp(d_e), B, dp(d_value),
-                                                   dp(d_quot1), dp(d_rem1), dp(d_quot2)))
+        if ld is None:
+            self._chk(self._lib.ntru_decrypt_batch_dev(self._h, N, q, p, dp(d_f), dp(d_fp), dp(d_e), B, dp(d_value),
+                                                       dp(d_quot1), dp(d_rem1), dp(d_quot2)))
+        else:
+            self._chk(self._lib.ntru_decrypt_batch_pitched_dev(self._h, N, q, p, int(ld), dp(d_f), dp(d_fp), dp(d_e), B,
+                                                               dp(d_value), dp(d_quot1), dp(d_rem1), dp(d_quot2)))
 
     def verify_keys_batch_dev(self, N, q, p, d_f, d_g, d_fq, d_fp, d_h, B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp,
                               d_quot_h, d_rem_h, d_flags):

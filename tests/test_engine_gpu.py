@@ -277,6 +277,79 @@ def test_device_pointers_at_any_alignment(eng, N, q):
         eng.set_stream(None)
 
 
+@pytest.mark.parametrize("N,q,ld", [(821, 4096, 832), (821, 4096, 822), (821, 4096, 1024), (167, 128, 192), (701, 8192, 704),
+                                    (509, 2048, 509), (64, 32, 80), (33, 8192, 47)])
+def test_pitched_rows_equal_oracle(eng, N, q, ld):
+    """ntru_*_batch_pitched_dev: rows at a pitch of ld >= N elements.  Pad elements of the inputs hold garbage and must
+    not reach any result; pad elements of the outputs must stay untouched; a ragged batch (B % 32 != 0) must not write
+    past row B - 1."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N * 7 + ld)
+    p, B, d = 3, 77, N // 3
+    h = rng.integers(0, q, N); f = ternary_rows(rng, 1, N, d, d - 1, two=-1)[0]; fp = rng.integers(0, p, N)
+    r = ternary_rows(rng, B, N, d, d); m = rng.integers(0, 256, (B, N))
+    e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
+    want = orc.decrypt_batch(N, q, p, f, fp, e_o)
+
+    def pitched(a, dtype, hi):                            # [B][ld] with random pads, plus two guard rows behind the batch
+        buf = rng.integers(0, hi, (B + 2, ld)).astype(dtype)
+        buf[:B, :N] = a
+        return torch.from_numpy(buf).to(dev)
+
+    def outbuf(dtype, fill):
+        return torch.full((B + 2, ld), fill, dtype=dtype, device=dev)
+
+    def check(t, want_rows, fill, what):
+        a = t.cpu().numpy().astype(np.int64) & (0xFFFF if t.dtype == torch.int16 else 0xFF)
+        assert np.array_equal(a[:B, :N], want_rows), what
+        assert (a[:B, N:] == fill).all() and (a[B:] == fill).all(), what + ": wrote outside the rows"
+
+    dh = torch.from_numpy(h.astype(np.int16)).to(dev); df = torch.from_numpy(f.astype(np.int8)).to(dev)
+    dfp = torch.from_numpy(fp.astype(np.uint8)).to(dev)
+    dr = pitched(r, np.uint8, 256); dm = pitched(m, np.uint8, 256)
+    de = outbuf(torch.int16, 0x5A5A); dq = outbuf(torch.int16, 0x5A5A)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        eng.encrypt_batch_dev(N, q, dh.data_ptr(), dr.data_ptr(), dm.data_ptr(), B, de.data_ptr(), dq.data_ptr(), ld=ld)
+        torch.cuda.synchronize()
+        check(de, e_o, 0x5A5A, "e"); check(dq, quot_o, 0x5A5A, "quotE")
+        # decrypt reads the pitched ciphertext it just got (pads = 0x5A5A garbage)
+        dv = outbuf(torch.uint8, 0xA5); dq2 = outbuf(torch.uint8, 0xA5)
+        dq1 = outbuf(torch.int16, 0x5A5A); dr1 = outbuf(torch.int16, 0x5A5A)
+        eng.decrypt_batch_dev(N, q, p, df.data_ptr(), dfp.data_ptr(), de.data_ptr(), B, dv.data_ptr(), dq1.data_ptr(),
+                              dr1.data_ptr(), dq2.data_ptr(), ld=ld)
+        torch.cuda.synchronize()
+        check(dv, want[0], 0xA5, "value"); check(dq1, want[1], 0x5A5A, "quot1")
+        check(dr1, want[2], 0x5A5A, "rem1"); check(dq2, want[3], 0xA5, "quot2")
+        # value-only mode on pitched rows
+        dv2 = outbuf(torch.uint8, 0xA5)
+        eng.decrypt_batch_dev(N, q, p, df.data_ptr(), dfp.data_ptr(), de.data_ptr(), B, dv2.data_ptr(), ld=ld)
+        torch.cuda.synchronize()
+        check(dv2, want[0], 0xA5, "value (value-only)")
+    finally:
+        eng.set_stream(None)
+
+
+def test_pitched_rows_are_refused_off_the_matrix_core_path(eng):
+    """Only the matrix-core kernels take a pitch: anything else must fail loudly, not fall back to dense rows."""
+    import torch
+    dev = torch.device("cuda:0")
+    N, q, ld, B = 167, 128, 192, 4
+    z8 = torch.zeros((B, ld), dtype=torch.uint8, device=dev); z16 = torch.zeros((B, ld), dtype=torch.int16, device=dev)
+    dh = torch.zeros(N, dtype=torch.int16, device=dev)
+    eng.set_kernel_path(2)
+    try:
+        with pytest.raises(pkg.EngineError):
+            eng.encrypt_batch_dev(N, q, dh.data_ptr(), z8.data_ptr(), z8.data_ptr(), B, z16.data_ptr(), None, ld=ld)
+    finally:
+        eng.set_kernel_path(0)
+    with pytest.raises(pkg.EngineError):                  # ld < N
+        eng.encrypt_batch_dev(N, q, dh.data_ptr(), z8.data_ptr(), z8.data_ptr(), B, z16.data_ptr(), None, ld=N - 1)
+    with pytest.raises(pkg.EngineError):                  # q too wide for two int8 digit planes
+        eng.encrypt_batch_dev(N, 16384, dh.data_ptr(), z8.data_ptr(), z8.data_ptr(), B, z16.data_ptr(), None, ld=ld)
+
+
 def test_public_key_batch_equals_reference_and_oracle(eng, scheme_golden):
     """generatePublicKeyH on the device: captured keys (through the host mirror and the batch entry point) and random
     per-item operands against the oracle."""
