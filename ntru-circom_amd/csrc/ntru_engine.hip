@@ -2166,6 +2166,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
         const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + bb * LD, 2 * lf);
         const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quotE + bb * LD : e + bb * LD, 2 * lf);
         const unsigned char *m_l = mimg + 32 * kb0 + lane_off;
+        // columns >= N (last tile only) get an offset beyond any descriptor: the hardware drops those lanes, no
+        // exec-mask region per store
+        int voff[NTS];
+#pragma unroll
+        for (int t = 0; t < NTS; t++) voff[t] = 32 * (kb0 + t) + (lane & 31) < N ? 2 * lane_off : (int)0x80000000;
         auto out = [&](auto wq) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {                  // 4 rows per half-wave at a time, across the strip's tiles
@@ -2183,11 +2188,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
                 ev[ii] = (u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + (int)mv[t][ii]) & (q - 1);
                 qv[ii] = (u32)(0 - hi[t][4 * j + ii]) & (q - 1);
               }
-              if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][4 * j])) {
+              if (1 ABL_STORE(lo[t][4 * j])) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ii++) {
-                  __builtin_amdgcn_raw_buffer_store_b16((u16)ev[ii], rs_e, 2 * lane_off, so + 2 * ii * LD, ST_AUX);
-                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)qv[ii], rs_q, 2 * lane_off, so + 2 * ii * LD, ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b16((u16)ev[ii], rs_e, voff[t], so + 2 * ii * LD, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)qv[ii], rs_q, voff[t], so + 2 * ii * LD, ST_AUX);
                 }
               }
             }
@@ -2307,6 +2312,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         const long lf = (B - bb) * LD;
         const __amdgpu_buffer_rsrc_t rs_r1 = rows_rsrc(want_r1 ? rem1 + bb * LD : nullptr, want_r1 ? 2 * lf : 0);
         const __amdgpu_buffer_rsrc_t rs_q1 = rows_rsrc(want_q1 ? quot1 + bb * LD : nullptr, want_q1 ? 2 * lf : 0);
+        int voff[NTS];                                   // see k_encrypt_m
+#pragma unroll
+        for (int t = 0; t < NTS; t++) voff[t] = 32 * (kb0 + t) + (lane & 31) < N ? 2 * lane_off : (int)0x80000000;
         auto out = [&](auto wr, auto wq) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {                  // 4 rows x the strip's tiles at a time: remainders (and their
@@ -2319,9 +2327,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
                 const u32 x = (u32)(lo[t][i] + hi[t][i]) & (q - 1);
                 xs[t][ii] = x;
                 const int so = 2 * (ro * LD + 32 * (kb0 + t));
-                if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][i])) {
-                  if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, 2 * lane_off, so, ST_AUX);
-                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, 2 * lane_off, so, ST_AUX);
+                if (1 ABL_STORE(lo[t][i])) {
+                  if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, voff[t], so, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, voff[t], so, ST_AUX);
                 }
               }
             }
@@ -2392,6 +2400,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         const long lf = (B - bb) * LD;
         const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value + bb * LD, lf);
         const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + bb * LD : nullptr, want_q2 ? lf : 0);
+        int voff[NTS];                                   // see k_encrypt_m
+#pragma unroll
+        for (int t = 0; t < NTS; t++) voff[t] = 32 * (kb0 + t) + (lane & 31) < N ? lane_off : (int)0x80000000;
         auto out = [&](auto wq) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {                  // lookups of 4 rows x the strip's tiles in flight before their stores
@@ -2408,9 +2419,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
 #pragma unroll
               for (int t = 0; t < NTS; t++) {
                 const int so = (ii + 8 * j) * LD + 32 * (kb0 + t);
-                if (32 * (kb0 + t) + (lane & 31) < N ABL_STORE(lo[t][4 * j + ii])) {
-                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(va[t][ii] & 3), rs_v, lane_off, so, ST_AUX);
-                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(vb[t][ii] >> 2), rs_q2, lane_off, so, ST_AUX);
+                if (1 ABL_STORE(lo[t][4 * j + ii])) {
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(va[t][ii] & 3), rs_v, voff[t], so, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(vb[t][ii] >> 2), rs_q2, voff[t], so, ST_AUX);
                 }
               }
             }
