@@ -2221,13 +2221,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
                                                              uint8_t *__restrict__ value, u16 *__restrict__ quot1,
                                                              u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  u32 *TF = (u32 *)lds, *TP = TF + 4 * g.tpitch;
-  unsigned char *stLo = (unsigned char *)(TP + 4 * g.tpitch);
-  unsigned char *stHi = stLo + 32 * g.pitchA;
-  unsigned char *blp = stHi + 32 * g.pitchA;             // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
+  // LDS layout: the e_hi stage comes FIRST because the mod-p table of product 2 is overlaid on it: at LDS address 0 its
+  // lookups need no base add (ds_read_u8 v, index offset:0|1)
+  unsigned char *stHi = lds;
+  unsigned char *stLo = stHi + 32 * g.pitchA;
+  u32 *TF = (u32 *)(stLo + 32 * g.pitchA), *TP = TF + 4 * g.tpitch;
+  unsigned char *blp = (unsigned char *)(TP + 4 * g.tpitch);   // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
   unsigned char *lift_lut = blp + 256 * g.NT;            // [q]: centred lift followed by mod p, index.js:117 verbatim
-  unsigned char *m3_lut = stHi;                          // [(p-1)^2 N + 1], rebuilt per row block once the e stages are dead:
-                                                         // x mod p in bits 0-1, (-x) mod p in bits 2-3
+  unsigned char *m3_lut = lds;                           // [(p-1)^2 N + 1][2], rebuilt per row block once the e stages are
+                                                         // dead: byte 2x = x mod p, byte 2x + 1 = (-x) mod p
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid0, BLOCK_THREADS);
   build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid0, BLOCK_THREADS);
@@ -2363,7 +2365,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
 #if !(NTRU_ABLATE & 64)
     for (int x = tid0; x <= (int)((p - 1) * (p - 1)) * N; x += BLOCK_THREADS) {
       const u32 rm = mod_small((u32)x, p);
-      m3_lut[x] = (unsigned char)(rm | ((rm ? p - rm : 0u) << 2));
+      *(u16 *)(m3_lut + 2 * x) = (u16)(rm | ((rm ? p - rm : 0u) << 8));
     }
 #endif
 #if !(NTRU_ABLATE & 32)
@@ -2411,8 +2413,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
             for (int t = 0; t < NTS; t++)
 #pragma unroll
               for (int ii = 0; ii < 4; ii++) {
-                va[t][ii] = m3_lut[lo[t][4 * j + ii] + hi[t][4 * j + ii]];
-                vb[t][ii] = decltype(wq)::value ? (u32)m3_lut[hi[t][4 * j + ii]] : 0u;
+                va[t][ii] = lds[(u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii]) << 1];
+                vb[t][ii] = decltype(wq)::value ? (u32)lds[((u32)hi[t][4 * j + ii] << 1) + 1] : 0u;
               }
 #pragma unroll
             for (int ii = 0; ii < 4; ii++) {
@@ -2420,8 +2422,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
               for (int t = 0; t < NTS; t++) {
                 const int so = (ii + 8 * j) * LD + 32 * (kb0 + t);
                 if (1 ABL_STORE(lo[t][4 * j + ii])) {
-                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(va[t][ii] & 3), rs_v, voff[t], so, ST_AUX);
-                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(vb[t][ii] >> 2), rs_q2, voff[t], so, ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)va[t][ii], rs_v, voff[t], so, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)vb[t][ii], rs_q2, voff[t], so, ST_AUX);
                 }
               }
             }
