@@ -2259,6 +2259,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       constexpr int RPW = 32 / WAVES_PER_BLOCK;
       RawChunks<2> raw[RPW];
       int sh[RPW];
+      u32 cmask[8];                                      // columns >= N of the last chunk(s) are zero; coefficients mod q
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int left2 = N - (16 * c16 + 2 * c);
+        cmask[c] = qm2 & (left2 >= 2 ? 0xFFFFFFFFu : (left2 == 1 ? 0x0000FFFFu : 0u));
+      }
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
         const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * LD;
@@ -2277,17 +2283,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         u32 x[8];
 #pragma unroll
         for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
-        if (16 * c16 + 16 > N) {                         // columns >= N of the last chunk(s) are zero
-#pragma unroll
-          for (int c = 0; c < 8; c++) {
-            const int left2 = N - (16 * c16 + 2 * c);
-            x[c] &= left2 >= 2 ? 0xFFFFFFFFu : (left2 == 1 ? 0x0000FFFFu : 0u);
-          }
-        }
         u32 lo[4], hi[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-          const u32 xa = x[2 * c] & qm2, xb = x[2 * c + 1] & qm2;
+          const u32 xa = x[2 * c] & cmask[2 * c], xb = x[2 * c + 1] & cmask[2 * c + 1];
           lo[c] = __builtin_amdgcn_perm(xb & 0x007F007Fu, xa & 0x007F007Fu, 0x06040200u);
           hi[c] = __builtin_amdgcn_perm((xb >> 6) & 0x00FE00FEu, (xa >> 6) & 0x00FE00FEu, 0x06040200u);
         }
