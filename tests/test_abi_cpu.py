@@ -86,3 +86,25 @@ def test_host_helpers_match_reference(pure_golden):
         assert (n.calculateNq(), n.calculateNp()) == (v["Nq"], v["Np"])
     with pytest.raises(ValueError, match="Invalid array length"):
         pkg.expandArray([1, 2, 3], 2)
+
+
+def test_plain_c_consumer_builds_and_fails_loudly_without_a_gpu(lib, tmp_path):
+    """tests/c/abi_round_trip.c (a C host of the ABI: gcc, no HIP headers) must compile and link against the in-tree
+    library; on a box without a GPU it must stop at ntru_engine_create with the no-device error, not compute anything."""
+    import shutil
+    import subprocess
+    import torch
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    so = pkg.library_path()
+    libdir, libname, orc_dir = os.path.dirname(so), os.path.basename(so), os.path.join(ROOT, "oracle")
+    exe = str(tmp_path / "abi_round_trip")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_round_trip.c"), "-o", exe,
+                           "-L" + libdir, "-l:" + libname, "-L" + orc_dir, "-lntru_oracle",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath," + orc_dir])
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_c_abi_gpu.py runs the program")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "no CPU fallback" in out.stderr, out.stdout + out.stderr
+    assert "identical" not in out.stdout
