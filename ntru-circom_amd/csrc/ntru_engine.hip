@@ -2441,6 +2441,255 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
   }
 }
 
+// ---- family 4 for PER-ITEM operands: verifyKeysInputs (index.js:141-197) on the matrix cores ---------------------
+// No matrix is shared by the batch, but one product c = a * s is itself a 32-row matrix product per tile distance
+// d = kb - ib (tools/peritem_mfma_model.py): C[kb][k'] += sum_i' F[kb - d][i'] G_d[i'][k'] with F the 32-coefficient chunks
+// of a (rows = output tiles, read as aligned 16-byte pieces of a zero-padded natural-order byte array) and G_d the
+// Toeplitz tile of s (fragments of the reversed cyclic array, as above).  One accumulator pair (low / high) holds the whole
+// product of an item; a 13-bit operand contributes two digit planes with SEPARATE accumulators (value = acc0 + 128 acc1),
+// so nothing is scaled.  2 NT - 1 (+1 for the split diagonal) matrix instructions per plane.  One item per wave, all LDS
+// regions private to the wave, no workgroup barrier.
+constexpr int PI_PAD = 32;          // zero chunks on either side of the chunk matrix: rows 0..31, distances +-(NT-1)
+constexpr int PI_WAVES = 2;         // waves per workgroup (LDS, not registers, bounds the residency: ~15 KB per wave)
+struct PGeom { int N, NT, tpitch; };
+static __host__ __device__ inline size_t pi_fa_bytes(const PGeom &g) { return (size_t)32 * (g.NT + 2 * PI_PAD); }
+static __host__ __device__ inline size_t pi_nat_bytes(const PGeom &g) { return ((size_t)3 * g.N + 64 + 15) & ~(size_t)15; }
+static __host__ __device__ inline size_t pi_wave_bytes(const PGeom &g) {
+  return 2 * pi_fa_bytes(g) + pi_nat_bytes(g) + (size_t)16 * g.tpitch;
+}
+
+// Reversed cyclic array (4 byte-shifted copies) of the 16 bytes per lane in sv (coefficients 16 lane .. 16 lane + 15 of a
+// ternary operand, zero at and beyond N): three periods in natural order (period k starts at byte k N, any alignment:
+// unaligned LDS stores), then T[c][w] = bytes rev[4w + c + j], rev[y] = s[(Y0 - y) mod N], as byte-swapped unaligned reads.
+static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T, const PGeom &g, int lane, v4i sv) {
+  const int N = g.N, Y0 = 32 * g.NT - 1;
+  if (16 * lane < N) {
+    union { v4i v; unsigned char c[16]; } u; u.v = sv;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (16 * lane + 16 <= N) *(v4i *)(nat + k * N + 16 * lane) = sv;
+      else for (int j = 0; j < 16; j++) if (16 * lane + j < N) nat[k * N + 16 * lane + j] = u.c[j];
+    }
+    if (lane < 4) *(v4i *)(nat + 3 * N + 16 * lane) = sv;                 // N >= 64
+  }
+  wave_lds_fence();
+  for (int x = lane; x < 4 * g.tpitch; x += 64) {
+    const int c = x / g.tpitch, w = x - c * g.tpitch;
+    int P = Y0 + 2 * N - (4 * w + c);
+    P = P < 3 ? 3 : P;                                                    // pad words of a copy are never read
+    T[x] = __builtin_bswap32(*(const u32 *)(nat + P - 3));
+  }
+  wave_lds_fence();
+}
+
+// Digit planes of 16 values < q (u16 pairs in x[8]) -> natural-order int8 bytes; hs = d0 + 128 d1 is the signed
+// representative used by k_encrypt_m.  MUL3: the operand is (3 v) mod q (index.js:155).
+template <bool MUL3>
+static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, int i0, int N, v4i &o0, v4i &o1) {
+  union { v4i v; signed char c[16]; } d0, d1;
+  const int hthr = (int)(q >> 1) - 65;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    u32 v = (x[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+    if (MUL3) v *= 3u;
+    int hs = i0 + j < N ? (int)(v & (q - 1)) : 0;
+    hs = hs > hthr ? hs - (int)q : hs;
+    const int lo = ((hs + 64) & 127) - 64;
+    d0.c[j] = (signed char)lo;
+    d1.c[j] = (signed char)((hs - lo) >> 7);
+  }
+  o0 = d0.v; o1 = d1.v;
+}
+
+// One plane-pair product: acc{L,H}{0,1} += chunk matrices fa0 / fa1 (x) Toeplitz fragments of T.  TWO = false: one plane.
+template <bool TWO>
+static __device__ __forceinline__ void pi_product(const unsigned char *pa0, const unsigned char *pa1, const u32 *tb, int NT,
+                                                  const u32 (&mlow)[4], v16i &L0, v16i &L1, v16i &H0, v16i &H1) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
+  for (int d = -(NT - 1); d < 0; d++) {
+    const u32 *p = tb - 8 * d;
+    const v4i w = {(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+    H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa0 - 32 * d), w, H0, 0, 0, 0);
+    if (TWO) H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa1 - 32 * d), w, H1, 0, 0, 0);
+  }
+  {
+    const v4i w = {(int)tb[0], (int)tb[1], (int)tb[2], (int)tb[3]};
+    const v4i wl = and4(w, mlow);
+    const v4i wh = {(int)((u32)w[0] & ~mlow[0]), (int)((u32)w[1] & ~mlow[1]), (int)((u32)w[2] & ~mlow[2]), (int)((u32)w[3] & ~mlow[3])};
+    const v4i a0 = *(const v4i *)pa0;
+    L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wl, L0, 0, 0, 0);
+    H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wh, H0, 0, 0, 0);
+    if (TWO) {
+      const v4i a1 = *(const v4i *)pa1;
+      L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wl, L1, 0, 0, 0);
+      H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wh, H1, 0, 0, 0);
+    }
+  }
+  for (int d = 1; d < NT; d++) {
+    const u32 *p = tb - 8 * d;
+    const v4i w = {(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+    L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa0 - 32 * d), w, L0, 0, 0, 0);
+    if (TWO) L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa1 - 32 * d), w, L1, 0, 0, 0);
+  }
+}
+
+static __device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+  return v;
+}
+
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_verify_keys_m(
+    PGeom g, u32 q, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
+    const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
+    u16 *__restrict__ rem_fq, uint8_t *__restrict__ quot_fp, uint8_t *__restrict__ rem_fp, u16 *__restrict__ quot_h,
+    u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa1 + pi_fa_bytes(g);
+  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
+  const int N = g.N, NT = g.NT;
+  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  const int y0 = 32 * NT - 1 - r + 16 * hh;
+  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
+  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
+  u32 mlow[4];
+  diag_low_mask(lane, mlow);
+  const bool stager = 16 * lane < 32 * NT;                                 // lanes that hold a 16-coefficient chunk of a row
+  const v4i cmask = col_mask16(16 * lane, N);                              // bytes of this lane's chunk that are below N
+  wave_lds_fence();
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
+    const long row = item * N, left = (B - item) * N;
+    u32 fl = 0;
+    // Operands are fetched where they are first needed (rows at any alignment: aligned chunks + a wave-uniform byte
+    // shift); holding all five across the products costs ~40 registers and a wave of occupancy.
+    auto fetch8 = [&](const void *base) {                                 // 16 bytes per lane of a byte row
+      const AlignedSrc sr = aligned_src(base, left);
+      const RawChunks<1> rw = load_raw<1>(sr, sr.a0 + 16 * lane, 0);
+      v4i v[1];
+      shift_raw<1>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
+      return v[0];
+    };
+    auto fetch_fq = [&](u32 (&x)[8]) {                                    // 16 coefficients per lane as u16 pairs
+      const AlignedSrc sr = aligned_src(fq + row, 2 * left);
+      const RawChunks<2> rw = load_raw<2>(sr, sr.a0 + 32 * lane, 0);
+      v4i v[2];
+      shift_raw<2>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
+#pragma unroll
+      for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
+    };
+    // ternary operands: any negative byte is -1 (ValTernary), bytes at and beyond N are zero
+    auto ternary = [&](v4i v) {
+      union { v4i v; signed char c[16]; } u; u.v = v & cmask;
+#pragma unroll
+      for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
+      return u.v;
+    };
+    // ---- product 1: fq * f mod q (index.js:158-160)
+    {
+      u32 xq[8];
+      fetch_fq(xq);
+      const v4i tf = ternary(fetch8(f + row));
+      if (stager) {
+        v4i o0, o1;
+        pi_digits<false>(xq, q, 16 * lane, N, o0, o1);
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
+      }
+      pi_build_array(nat, T, g, lane, tf);
+    }
+    v16i L0, L1, H0, H1;
+    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      bool nz_hi = false, first_not_one = false;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
+        if (kb < NT && k < N) {
+          const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+          const u32 rv = (u32)(lo + hi) & (q - 1);
+          rem_fq[row + k] = (u16)rv;
+          quot_fq[row + k] = (u16)((u32)(0 - hi) & (q - 1));
+          nz_hi |= k >= 1 && rv != 0;
+          first_not_one |= k == 0 && rv != 1;
+        }
+      }
+      if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
+    }
+    wave_lds_fence();
+    // ---- product 2: fp * f mod p (index.js:161-163): the array of f serves again, one plane of fp mod 3
+    {
+      const v4i vfp = fetch8(fp + row);
+      union { v4i v; unsigned char c[16]; } u; u.v = vfp & cmask;
+#pragma unroll
+      for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
+      if (stager) *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = u.v;
+    }
+    wave_lds_fence();
+    pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      bool nz_hi = false, first_not_one = false;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
+        if (kb < NT && k < N) {
+          const int x = L0[i] + H0[i], y = 0 - H0[i];
+          const int xm = x % 3, ym = y % 3;
+          const u32 rv = (u32)(xm < 0 ? xm + 3 : xm), qv = (u32)(ym < 0 ? ym + 3 : ym);
+          rem_fp[row + k] = (uint8_t)rv;
+          quot_fp[row + k] = (uint8_t)qv;
+          nz_hi |= k >= 1 && rv != 0;
+          first_not_one |= k == 0 && rv != 1;
+        }
+      }
+      if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
+    }
+    wave_lds_fence();
+    // ---- product 3: ((p fq) mod q) * g mod q, compared with h below its trimmed length (index.js:155,164-166)
+    {
+      u32 xq[8];
+      fetch_fq(xq);
+      const v4i tg = ternary(fetch8(gg + row));
+      if (stager) {
+        v4i o0, o1;
+        pi_digits<true>(xq, q, 16 * lane, N, o0, o1);
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
+      }
+      pi_build_array(nat, T, g, lane, tg);
+    }
+    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      int top = -1;
+      u32 differs = 0;                                                  // bit i: h differs from the remainder at this lane's i-th index
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
+        if (kb < NT && k < N) {
+          const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+          const u32 rv = (u32)(lo + hi) & (q - 1), hv = h[row + k];
+          rem_h[row + k] = (u16)rv;
+          quot_h[row + k] = (u16)((u32)(0 - hi) & (q - 1));
+          if (hv) top = k > top ? k : top;
+          differs |= hv != rv ? 1u << i : 0u;
+        }
+      }
+      const int wtop = wave_max(top);
+      const int hl = wtop >= 0 ? wtop + 1 : 1;                          // trimmed length of h (1 for the zero polynomial)
+      bool bad = false;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
+        bad |= ((differs >> i) & 1u) && k < hl;
+      }
+      if (__ballot(bad) != 0) fl |= NTRU_FLAG_INVALID_H;
+    }
+    if (lane == 0) flags[item] = (uint8_t)fl;
+    wave_lds_fence();
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
@@ -2884,6 +3133,22 @@ extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int 
     return fail(NTRU_ERR_ARG, "ntru_verify_keys_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
+  // matrix-core kernel for per-item keys: p == 3, q <= 8192 (two int8 digit planes), 64 <= N <= 1024; automatic from N = 128
+  if ((eng->path == 0 || eng->path == 4) && p == 3 && q <= 8192 && N <= 1024 && N >= (eng->path == 4 ? 64 : 128)) {
+    PGeom pg;
+    pg.N = N; pg.NT = (N + 31) / 32; pg.tpitch = ((16 * pg.NT + 31) / 32) * 32 + 8;
+    const size_t lds = PI_WAVES * pi_wave_bytes(pg);
+    if (int rc = allow_lds(k_verify_keys_m, lds)) return rc;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_verify_keys_m, 64 * PI_WAVES, lds));
+    long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
+    if (blocks > work) blocks = work;
+    snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_verify_keys_m");
+    hipLaunchKernelGGL(k_verify_keys_m, dim3((unsigned)blocks), dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, d_f, d_g,
+                       d_fq, d_fp, d_h, (long)B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h, d_flags);
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  }
   if (const int me = p == 3 ? add_path_me(eng, N, q) : 0) {
     L.K = pick_K(N);
     L.g = make_geom(N, L.K);

@@ -494,6 +494,79 @@ def test_verify_keys_batch_equals_oracle(eng, N, q, d, ):
         assert np.array_equal(got[k], want[k]), k
 
 
+def test_verify_keys_matrix_core_kernel_sweep(eng):
+    """k_verify_keys_m (per-item products on the matrix cores): random (N, q) incl. N = 64 / multiples of 32 / 1024 and
+    q from 2 to 8192, against the oracle and against the vector-ALU kernels."""
+    rng = np.random.default_rng(2024)
+    cases = [(64, 2), (64, 8192), (96, 64), (128, 4096), (1024, 8192), (1023, 2048), (821, 4096), (257, 4), (640, 1024)]
+    cases += [(int(rng.integers(64, 1025)), 1 << int(rng.integers(1, 14))) for _ in range(10)]
+    p = 3
+    for N, q in cases:
+        B = int(rng.integers(1, 40)); d = N // 3
+        f = ternary_rows(rng, B, N, d, max(d - 1, 0), two=-1); g = ternary_rows(rng, B, N, d, d, two=-1)
+        fq = rng.integers(0, q, (B, N)); fp = rng.integers(0, p, (B, N)); h = rng.integers(0, q, (B, N))
+        if B > 2:
+            h[1, N // 3:] = 0; h[2] = 0
+            fq[0, :] = 0; fq[0, 0] = 1; f[0, :] = 0; f[0, 0] = 1            # fq * f = 1: no 'invalid fq' flag
+        eng.set_kernel_path(4)
+        got = eng.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+        assert eng.last_kernel() == "k_verify_keys_m", (N, q, eng.last_kernel())
+        eng.set_kernel_path(1)
+        alt = eng.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+        assert eng.last_kernel() != "k_verify_keys_m"
+        eng.set_kernel_path(0)
+        want = orc.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (N, q, k)
+            assert np.array_equal(alt[k], want[k]), (N, q, k, "vector-ALU kernel")
+    # the automatic choice takes it from N = 128
+    N, q, B = 509, 2048, 5
+    f = ternary_rows(rng, B, N, 100, 99, two=-1); g = ternary_rows(rng, B, N, 100, 100, two=-1)
+    eng.verify_keys_batch(N, q, p, f, g, rng.integers(0, q, (B, N)), rng.integers(0, p, (B, N)), rng.integers(0, q, (B, N)))
+    assert eng.last_kernel() == "k_verify_keys_m"
+
+
+def test_verify_keys_device_pointers_at_any_alignment(eng):
+    """ntru_verify_keys_batch_dev with every array at an odd byte offset (uint16 arrays stay 2-aligned): the matrix-core
+    kernel reads rows through aligned chunks + shifts and must neither read garbage nor write outside its rows."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    N, q, p, B = 821, 4096, 3, 19
+    f = ternary_rows(rng, B, N, 270, 269, two=-1); g = ternary_rows(rng, B, N, 270, 270, two=-1)
+    fq = rng.integers(0, q, (B, N)); fp = rng.integers(0, p, (B, N)); h = rng.integers(0, q, (B, N))
+    want = orc.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for off in (1, 3, 6, 13):
+            def place(a, dtype):
+                raw = np.ascontiguousarray(a.astype(dtype)).view(np.uint8).ravel()
+                o = off * np.dtype(dtype).itemsize
+                buf = torch.full((raw.size + 64,), 0x7F, dtype=torch.uint8, device=dev)
+                buf[o:o + raw.size] = torch.from_numpy(raw).to(dev)
+                return buf, buf.data_ptr() + o
+            def out(dtype, n):
+                o = off * np.dtype(dtype).itemsize
+                buf = torch.full((n * np.dtype(dtype).itemsize + 64,), 0xAB, dtype=torch.uint8, device=dev)
+                return buf, buf.data_ptr() + o
+            ins = [place(f, np.int8), place(g, np.int8), place(fq, np.uint16), place(fp, np.uint8), place(h, np.uint16)]
+            spec = [("quot_fq", np.uint16), ("rem_fq", np.uint16), ("quot_fp", np.uint8), ("rem_fp", np.uint8),
+                    ("quot_h", np.uint16), ("rem_h", np.uint16)]
+            outs = [out(dt, B * N) for _, dt in spec]
+            fl = out(np.uint8, B)
+            eng.verify_keys_batch_dev(N, q, p, *[x[1] for x in ins], B, *[x[1] for x in outs], fl[1])
+            torch.cuda.synchronize()
+            assert eng.last_kernel() == "k_verify_keys_m"
+            for (name, dt), (buf, _) in zip(spec, outs):
+                a = buf.cpu().numpy(); o = off * np.dtype(dt).itemsize; n = B * N * np.dtype(dt).itemsize
+                assert (a[:o] == 0xAB).all() and (a[o + n:] == 0xAB).all(), (off, name, "wrote outside")
+                assert np.array_equal(a[o:o + n].view(dt).reshape(B, N), want[name]), (off, name)
+            a = fl[0].cpu().numpy()
+            assert np.array_equal(a[off:off + B], want["flags"]) and (a[:off] == 0xAB).all() and (a[off + B:] == 0xAB).all()
+    finally:
+        eng.set_stream(None)
+
+
 def test_verify_keys_true_keys_and_corruptions(eng, scheme_golden):
     opts = scheme_golden["options"]
     N, q, p = opts["N"], opts["q"], opts["p"]
