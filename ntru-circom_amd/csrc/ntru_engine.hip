@@ -2473,12 +2473,13 @@ static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T
     if (lane < 4) *(v4i *)(nat + 3 * N + 16 * lane) = sv;                 // N >= 64
   }
   wave_lds_fence();
-  for (int x = lane; x < 4 * g.tpitch; x += 64) {
-    const int c = x / g.tpitch, w = x - c * g.tpitch;
-    int P = Y0 + 2 * N - (4 * w + c);
-    P = P < 3 ? 3 : P;                                                    // pad words of a copy are never read
-    T[x] = __builtin_bswap32(*(const u32 *)(nat + P - 3));
-  }
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+    for (int w = lane; w < g.tpitch; w += 64) {
+      int P = Y0 + 2 * N - (4 * w + c);
+      P = P < 3 ? 3 : P;                                                  // pad words of a copy are never read
+      T[c * g.tpitch + w] = __builtin_bswap32(*(const u32 *)(nat + P - 3));
+    }
   wave_lds_fence();
 }
 
@@ -2507,30 +2508,42 @@ static __device__ __forceinline__ void pi_product(const unsigned char *pa0, cons
                                                   const u32 (&mlow)[4], v16i &L0, v16i &L1, v16i &H0, v16i &H1) {
 #pragma unroll
   for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
-  for (int d = -(NT - 1); d < 0; d++) {
+  // operands of distance d: fragment of the reversed array 8 d dwords below the lane's base, chunk rows shifted by d.
+  // The operands of the next distance are requested before the current products (one past the end reads pad bytes).
+  auto ld = [&](int d, v4i &a0, v4i &a1, v4i &w) {
     const u32 *p = tb - 8 * d;
-    const v4i w = {(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
-    H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa0 - 32 * d), w, H0, 0, 0, 0);
-    if (TWO) H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa1 - 32 * d), w, H1, 0, 0, 0);
+    w = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+    a0 = *(const v4i *)(pa0 - 32 * d);
+    if (TWO) a1 = *(const v4i *)(pa1 - 32 * d);
+  };
+  v4i a0, a1, w;
+  ld(-(NT - 1), a0, a1, w);
+  for (int d = -(NT - 1); d < 0; d++) {
+    v4i n0, n1, nw;
+    ld(d + 1, n0, n1, nw);
+    H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w, H0, 0, 0, 0);
+    if (TWO) H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w, H1, 0, 0, 0);
+    a0 = n0; a1 = n1; w = nw;
   }
   {
-    const v4i w = {(int)tb[0], (int)tb[1], (int)tb[2], (int)tb[3]};
+    v4i n0, n1, nw;
+    ld(1, n0, n1, nw);
     const v4i wl = and4(w, mlow);
     const v4i wh = {(int)((u32)w[0] & ~mlow[0]), (int)((u32)w[1] & ~mlow[1]), (int)((u32)w[2] & ~mlow[2]), (int)((u32)w[3] & ~mlow[3])};
-    const v4i a0 = *(const v4i *)pa0;
     L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wl, L0, 0, 0, 0);
     H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wh, H0, 0, 0, 0);
     if (TWO) {
-      const v4i a1 = *(const v4i *)pa1;
       L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wl, L1, 0, 0, 0);
       H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wh, H1, 0, 0, 0);
     }
+    a0 = n0; a1 = n1; w = nw;
   }
   for (int d = 1; d < NT; d++) {
-    const u32 *p = tb - 8 * d;
-    const v4i w = {(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
-    L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa0 - 32 * d), w, L0, 0, 0, 0);
-    if (TWO) L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa1 - 32 * d), w, L1, 0, 0, 0);
+    v4i n0, n1, nw;
+    ld(d + 1, n0, n1, nw);
+    L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w, L0, 0, 0, 0);
+    if (TWO) L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w, L1, 0, 0, 0);
+    a0 = n0; a1 = n1; w = nw;
   }
 }
 
