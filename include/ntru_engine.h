@@ -30,7 +30,9 @@
  *     error with unspecified results.  ntru_engine_set_kernel_path(1) selects the multiply-accumulate kernels, which
  *     accept arbitrary operand values for r and h, e, fq.
  *   - shared-key encrypt / decrypt with 64 <= N <= 1024 and q <= 8192 run on the int8 matrix cores (batch x Toeplitz
- *     matrix of the key, exact); everything else on the vector-ALU kernel families.  Pointers may have any alignment.
+ *     matrix of the key, exact), and so does verify_keys with 128 <= N <= 1024, q <= 8192, p == 3 (each per-item product
+ *     as a 32-row matrix product per tile distance); everything else on the vector-ALU kernel families.  Pointers may
+ *     have any alignment.
  */
 #ifndef NTRU_ENGINE_H
 #define NTRU_ENGINE_H
@@ -72,7 +74,8 @@ void ntru_engine_destroy(ntru_engine_t *eng);
 int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
 /* Tuning / test knob: 0 = pick the fastest applicable kernel family (default), 1 = always the packed-u16 MAC
  * kernels, 2 = the ternary add path wherever it applies, 3 = the add path without its dot8 product, 4 = the int8
- * matrix-core path wherever it applies (shared key, q <= 8192, N <= 1024), even for small N.  Results are identical. */
+ * matrix-core path wherever it applies (encrypt / decrypt: shared key, q <= 8192, N <= 1024; verify_keys: q <= 8192,
+ * p == 3, 64 <= N <= 1024), even for small N.  Results are identical. */
 int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
 /* Name of the kernel the last *_dev call on this engine launched, e.g. "k_decrypt_s<13,13>" (for reports). */
 const char *ntru_engine_last_kernel(ntru_engine_t *eng);
@@ -179,7 +182,8 @@ int ntru_public_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const uin
 /* ---- verifyKeysInputs (index.js:141-197) for B independent key pairs (per-item operands).
  *      f, g [B][N] in {-1,0,1}; fq, h [B][N] in [0,q); fp [B][N] in [0,p).
  *      Three witnesses per item: fq*f mod q, fp*f mod p, (p*fq)*g mod q, each as quotient + remainder;
- *      flags[B] gets the NTRU_FLAG_* bits. */
+ *      flags[B] gets the NTRU_FLAG_* bits.  One key pair per wavefront; on the matrix cores where the note at the top
+ *      of this file says so (k_verify_keys_m), otherwise on the ternary add path / the multiply-accumulate kernels. */
 int ntru_verify_keys_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, const int8_t *g,
                            const uint16_t *fq, const uint8_t *fp, const uint16_t *h, int64_t B,
                            uint16_t *quot_fq, uint16_t *rem_fq, uint8_t *quot_fp, uint8_t *rem_fp,
