@@ -173,7 +173,8 @@ int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int
 
 /* generatePublicKeyH (index.js:72-79) for B keys: h[b] = remainder of ((p * fq[b]) mod q) * g[b] by 1 - x^N, mod q
  * (before trimPolynomial).  fq: mod-q inverse of f, g in {-1,0,1}; p*(q-1) must fit 16 bits.  Per-item operands on both
- * sides, so this runs on the vector-ALU product kernel.  [§8(f) #1, the part of key generation that is a product] */
+ * sides: one key per wavefront on the matrix cores (k_public_key_m) for 128 <= N <= 1024 and q <= 8192, the vector-ALU
+ * product kernel otherwise.  [§8(f) #1, the part of key generation that is a product] */
 int ntru_public_key_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *fq, const int8_t *g, int64_t B,
                           uint16_t *h);
 int ntru_public_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const uint16_t *d_fq, const int8_t *d_g,

@@ -2484,15 +2484,13 @@ static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T
 }
 
 // Digit planes of 16 values < q (u16 pairs in x[8]) -> natural-order int8 bytes; hs = d0 + 128 d1 is the signed
-// representative used by k_encrypt_m.  MUL3: the operand is (3 v) mod q (index.js:155).
-template <bool MUL3>
-static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, int i0, int N, v4i &o0, v4i &o1) {
+// representative used by k_encrypt_m.  mul: the operand is (mul v) mod q (p fq of index.js:155; 1 otherwise).
+static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 mul, int i0, int N, v4i &o0, v4i &o1) {
   union { v4i v; signed char c[16]; } d0, d1;
   const int hthr = (int)(q >> 1) - 65;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
-    u32 v = (x[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-    if (MUL3) v *= 3u;
+    const u32 v = ((x[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) * mul;
     int hs = i0 + j < N ? (int)(v & (q - 1)) : 0;
     hs = hs > hthr ? hs - (int)q : hs;
     const int lo = ((hs + 64) & 127) - 64;
@@ -2606,7 +2604,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       const v4i tf = ternary(fetch8(f + row));
       if (stager) {
         v4i o0, o1;
-        pi_digits<false>(xq, q, 16 * lane, N, o0, o1);
+        pi_digits(xq, q, 1u, 16 * lane, N, o0, o1);
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
       }
@@ -2666,7 +2664,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       const v4i tg = ternary(fetch8(gg + row));
       if (stager) {
         v4i o0, o1;
-        pi_digits<true>(xq, q, 16 * lane, N, o0, o1);
+        pi_digits(xq, q, 3u, 16 * lane, N, o0, o1);
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
       }
@@ -2699,6 +2697,65 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       if (__ballot(bad) != 0) fl |= NTRU_FLAG_INVALID_H;
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
+    wave_lds_fence();
+  }
+}
+
+// One per-item product on the matrix cores: rem (and quot) of ((mul a) mod q) * s split by 1 - x^N, a < 2^16 per item,
+// s ternary per item: generatePublicKeyH (index.js:72-79, mul = p) and the f * t product of polyInv's Newton rounds
+// (index.js:499-506, mul = 1).  Same machinery as k_verify_keys_m.
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_product_tern_m(
+    PGeom g, u32 q, u32 mul, const u16 *__restrict__ a, const int8_t *__restrict__ s, long B, u16 *__restrict__ quot,
+    u16 *__restrict__ rem) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa1 + pi_fa_bytes(g);
+  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
+  const int N = g.N, NT = g.NT;
+  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  const int y0 = 32 * NT - 1 - r + 16 * hh;
+  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
+  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
+  u32 mlow[4];
+  diag_low_mask(lane, mlow);
+  const bool stager = 16 * lane < 32 * NT;
+  const v4i cmask = col_mask16(16 * lane, N);
+  const bool want_q = quot != nullptr;
+  wave_lds_fence();
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
+    const long row = item * N, left = (B - item) * N;
+    {
+      const AlignedSrc sa = aligned_src(a + row, 2 * left), ss = aligned_src(s + row, left);
+      const RawChunks<2> ra = load_raw<2>(sa, sa.a0 + 32 * lane, 0);
+      const RawChunks<1> rs = load_raw<1>(ss, ss.a0 + 16 * lane, 0);
+      v4i va[2], vs[1];
+      shift_raw<2>(ra, __builtin_amdgcn_readfirstlane(sa.a0), va);
+      shift_raw<1>(rs, __builtin_amdgcn_readfirstlane(ss.a0), vs);
+      u32 xa[8];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { xa[c] = (u32)va[0][c]; xa[4 + c] = (u32)va[1][c]; }
+      union { v4i v; signed char c[16]; } u; u.v = vs[0] & cmask;        // any negative byte is -1 (ValTernary)
+#pragma unroll
+      for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
+      if (stager) {
+        v4i o0, o1;
+        pi_digits(xa, q, mul, 16 * lane, N, o0, o1);
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
+      }
+      pi_build_array(nat, T, g, lane, u.v);
+    }
+    v16i L0, L1, H0, H1;
+    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
+      if (kb < NT && k < N) {
+        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        rem[row + k] = (u16)((u32)(lo + hi) & (q - 1));
+        if (want_q) quot[row + k] = (u16)((u32)(0 - hi) & (q - 1));
+      }
+    }
     wave_lds_fence();
   }
 }
@@ -3111,6 +3168,27 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
   return NTRU_OK;
 }
 
+// Per-item products with a ternary operand on the matrix cores: q a power of two <= 8192, 64 <= N <= 1024 (automatic
+// from N = 128).
+static bool product_tern_m_applies(const ntru_engine *eng, int N, int q) {
+  return (eng->path == 0 || eng->path == 4) && is_pow2(q) && q <= 8192 && N <= 1024 && N >= (eng->path == 4 ? 64 : 128);
+}
+static int launch_product_tern_m(ntru_engine *eng, int N, int q, u32 mul, const u16 *d_a, const int8_t *d_s, long B,
+                                 u16 *d_quot, u16 *d_rem) {
+  PGeom pg;
+  pg.N = N; pg.NT = (N + 31) / 32; pg.tpitch = ((16 * pg.NT + 31) / 32) * 32 + 8;
+  const size_t lds = PI_WAVES * pi_wave_bytes(pg);
+  if (int rc = allow_lds(k_product_tern_m, lds)) return rc;
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_product_tern_m, 64 * PI_WAVES, lds));
+  long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
+  if (blocks > work) blocks = work;
+  hipLaunchKernelGGL(k_product_tern_m, dim3((unsigned)blocks), dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, mul, d_a,
+                     d_s, B, d_quot, d_rem);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
 extern "C" int ntru_public_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const uint16_t *d_fq,
                                          const int8_t *d_g, int64_t B, uint16_t *d_h) {
   if (int rc = check_common(eng, N, q, B)) return rc;
@@ -3118,6 +3196,10 @@ extern "C" int ntru_public_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   if (B == 0) return NTRU_OK;
   if (!d_fq || !d_g || !d_h) return fail(NTRU_ERR_ARG, "ntru_public_key_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
+  if (product_tern_m_applies(eng, N, q)) {
+    snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_public_key_m");
+    return launch_product_tern_m(eng, N, q, (u32)p, d_fq, d_g, (long)B, nullptr, d_h);
+  }
   Launch L;
   if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
   DISPATCH_K(L.K, {
@@ -3394,8 +3476,10 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
                          (u32)q, (u16 *)f16.p);
       for (int r = 0; r < rounds; r++) {
         if (int rc = ntru_polymul_split_dev(eng, N, q, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p)) return rc;
-        if (int rc = ntru_polymul_split_dev(eng, N, q, (const uint16_t *)f16.p, (const uint16_t *)t.p, n, (uint16_t *)qs.p,
-                                            (uint16_t *)u.p)) return rc;
+        if (product_tern_m_applies(eng, N, q)) {          // f * t with f ternary: per-item product on the matrix cores
+          if (int rc = launch_product_tern_m(eng, N, q, 1u, (const u16 *)t.p, d_f + o * N, (long)n, nullptr, (u16 *)u.p)) return rc;
+        } else if (int rc = ntru_polymul_split_dev(eng, N, q, (const uint16_t *)f16.p, (const uint16_t *)t.p, n,
+                                                   (uint16_t *)qs.p, (uint16_t *)u.p)) return rc;
         hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, (u16 *)v,
                            (const u16 *)u.p, (long)(n * N), (u32)q);
       }
