@@ -19,6 +19,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned u32;
 
 struct Geo { int N, NT, tpitch; };
+#ifndef ABL
+#define ABL 0   // timing-only variants: 1 no matrix loop, 2 reversed array built for the first item only, 4 no result stores, 8 no 3-period staging
+#endif
 constexpr int PAD_CH = 32;       // zero chunks on either side of the chunk matrix (tile distances reach +-(NT-1), rows 0..31)
 
 static __host__ __device__ size_t fa_bytes(const Geo &g) { return (size_t)32 * (g.NT + 2 * PAD_CH); }
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_num_vgpr(128))) v
       *(v4i *)(fa0 + 32 * PAD_CH + 16 * lane) = d0.v;
       *(v4i *)(fa1 + 32 * PAD_CH + 16 * lane) = d1.v;
       // three periods (+64 bytes) of s in natural order; period k starts at byte k N (any alignment): unaligned LDS stores
+      if (!(ABL & 8) || item < (long)gridDim.x * WAVES)
       for (int k = 0; k < 3; k++)
         if (16 * lane + 16 <= N) *(v4i *)(nat + k * N + 16 * lane) = sv.v;
         else for (int j = 0; j < 16; j++) if (16 * lane + j < N) nat[k * N + 16 * lane + j] = (unsigned char)sv.c[j];
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_num_vgpr(128))) v
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- reversed cyclic array of s, 4 byte-shifted copies: T[c][w] = bytes rev[4w+c+j], rev[y] = s[(Y0 - y) mod N]
+    if (!(ABL & 2) || item < (long)gridDim.x * WAVES)
     for (int x = lane; x < 4 * g.tpitch; x += 64) {
       const int c = x / g.tpitch, w = x - c * g.tpitch;
       int P = Y0 + 2 * N - (4 * w + c);
@@ -87,6 +92,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_num_vgpr(128))) v
     v16i L0, L1, H0, H1;
     for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
     const unsigned char *pa0 = fa0 + 32 * PAD_CH + 32 * r + 16 * h, *pa1 = fa1 + 32 * PAD_CH + 32 * r + 16 * h;
+    if (!(ABL & 1)) {
     for (int d = -(NT - 1); d < 0; d++) {
       const u32 *p = tb - 8 * d;
       const v4i w = {(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
@@ -109,11 +115,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_num_vgpr(128))) v
       L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa0 - 32 * d), w, L0, 0, 0, 0);
       L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const v4i *)(pa1 - 32 * d), w, L1, 0, 0, 0);
     }
+    }
     // ---- split by 1 - x^N and store: register i is output tile (i & 3) + 8 (i >> 2) + 4 h, column r
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int kb = (i & 3) + 8 * (i >> 2) + 4 * h, k = 32 * kb + r;
-      if (kb < NT && k < N) {
+      if (kb < NT && k < N && (!(ABL & 4) || L0[i] == 0x7fffffff)) {
         const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
         rem[row + k] = (uint16_t)((u32)(lo + hi) & (q - 1));
         quot[row + k] = (uint16_t)((u32)(0 - hi) & (q - 1));

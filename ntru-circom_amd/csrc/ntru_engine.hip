@@ -2473,13 +2473,26 @@ static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T
     if (lane < 4) *(v4i *)(nat + 3 * N + 16 * lane) = sv;                 // N >= 64
   }
   wave_lds_fence();
+  // Word w of copy c holds bytes nat[A .. A+3] reversed, A = E - c, E = Y0 + 2N - 3 - 4w.  E & 3 is the same for every
+  // lane, so the four copies of a word come from three ALIGNED dwords around E >> 2 with one byte permute each
+  // (an unaligned LDS dword read costs several aligned ones: the build was 28 % of a product in the probe).
+  const u32 *D = (const u32 *)nat;
+  const int e = __builtin_amdgcn_readfirstlane((Y0 + 2 * N - 3) & 3);
+  u32 sel[4]; int dk[4];
 #pragma unroll
-  for (int c = 0; c < 4; c++)
-    for (int w = lane; w < g.tpitch; w += 64) {
-      int P = Y0 + 2 * N - (4 * w + c);
-      P = P < 3 ? 3 : P;                                                  // pad words of a copy are never read
-      T[c * g.tpitch + w] = __builtin_bswap32(*(const u32 *)(nat + P - 3));
-    }
+  for (int c = 0; c < 4; c++) {
+    const int al = c <= e ? e - c : e - c + 4;                            // byte offset of A inside its dword
+    dk[c] = c <= e ? 0 : -1;                                              // ... which is dword K or K - 1
+    sel[c] = 0x00010203u + 0x01010101u * (u32)al;                         // bytes al+3, al+2, al+1, al of the pair (reversed)
+  }
+  for (int w = lane; w < g.tpitch; w += 64) {
+    int K = (Y0 + 2 * N - 3 - 4 * w) >> 2;
+    K = K < 1 ? 1 : K;                                                    // pad words of a copy are never read
+    const u32 dm = D[K - 1], d0 = D[K], dp = D[K + 1];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      T[c * g.tpitch + w] = dk[c] == 0 ? __builtin_amdgcn_perm(dp, d0, sel[c]) : __builtin_amdgcn_perm(d0, dm, sel[c]);
+  }
   wave_lds_fence();
 }
 
