@@ -2773,6 +2773,103 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
   }
 }
 
+// Generic per-item product on the matrix cores: both operands < q <= 8192 (multiplyPolynomials + dividePolynomials by I,
+// index.js:319-401, with q a power of two; the v * v product of polyInv's Newton rounds).  With a = a0 + 128 a1 and
+// b = b0 + 128 b1 the product is a0 b0 + 128 (a0 b1 + a1 b0) + 16384 a1 b1, and 16384 = 0 mod q: three plane products, two
+// accumulator groups, two reversed arrays (the digit planes of b) per item.
+static __host__ __device__ inline size_t pi_wave_bytes2(const PGeom &g) { return pi_wave_bytes(g) + (size_t)16 * g.tpitch; }
+
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_polymul_m(
+    PGeom g, u32 q, const u16 *__restrict__ a, const u16 *__restrict__ b, long B, u16 *__restrict__ quot,
+    u16 *__restrict__ rem) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes2(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa1 + pi_fa_bytes(g);
+  u32 *T0 = (u32 *)(nat + pi_nat_bytes(g)), *T1 = T0 + 4 * g.tpitch;
+  const int N = g.N, NT = g.NT;
+  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  const int y0 = 32 * NT - 1 - r + 16 * hh;
+  const u32 *tb0 = T0 + (y0 & 3) * g.tpitch + (y0 >> 2), *tb1 = tb0 + 4 * g.tpitch;
+  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
+  u32 mlow[4];
+  diag_low_mask(lane, mlow);
+  const bool stager = 16 * lane < 32 * NT;
+  wave_lds_fence();
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
+    const long row = item * N, left = (B - item) * N;
+    {
+      auto fetch = [&](const u16 *base, u32 (&x)[8]) {
+        const AlignedSrc sr = aligned_src(base + row, 2 * left);
+        const RawChunks<2> rw = load_raw<2>(sr, sr.a0 + 32 * lane, 0);
+        v4i v[2];
+        shift_raw<2>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
+#pragma unroll
+        for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
+      };
+      u32 xa[8], xb[8];
+      fetch(a, xa); fetch(b, xb);
+      v4i a0, a1, b0, b1;
+      pi_digits(xa, q, 1u, 16 * lane, N, a0, a1);
+      pi_digits(xb, q, 1u, 16 * lane, N, b0, b1);
+      if (stager) {
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = a0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
+      }
+      pi_build_array(nat, T0, g, lane, b0);
+      pi_build_array(nat, T1, g, lane, b1);
+    }
+    v16i L0, L1, H0, H1;                                   // group 0: a0 b0; group 1: a0 b1 + a1 b0
+#pragma unroll
+    for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
+    auto ld = [&](int d, v4i &x0, v4i &x1, v4i &w0, v4i &w1) {
+      const u32 *p0 = tb0 - 8 * d, *p1 = tb1 - 8 * d;
+      w0 = (v4i){(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3]};
+      w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+      x0 = *(const v4i *)(pa0 - 32 * d);
+      x1 = *(const v4i *)(pa1 - 32 * d);
+    };
+    auto mm3 = [&](v16i &X0, v16i &X1, v4i x0, v4i x1, v4i w0, v4i w1) {
+      X0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w0, X0, 0, 0, 0);
+      X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w1, X1, 0, 0, 0);
+      X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1, w0, X1, 0, 0, 0);
+    };
+    v4i x0, x1, w0, w1;
+    ld(-(NT - 1), x0, x1, w0, w1);
+    for (int d = -(NT - 1); d < 0; d++) {
+      v4i n0, n1, m0, m1;
+      ld(d + 1, n0, n1, m0, m1);
+      mm3(H0, H1, x0, x1, w0, w1);
+      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+    }
+    {
+      v4i n0, n1, m0, m1;
+      ld(1, n0, n1, m0, m1);
+      u32 mhigh[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
+      mm3(L0, L1, x0, x1, and4(w0, mlow), and4(w1, mlow));
+      mm3(H0, H1, x0, x1, and4(w0, mhigh), and4(w1, mhigh));
+      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+    }
+    for (int d = 1; d < NT; d++) {
+      v4i n0, n1, m0, m1;
+      ld(d + 1, n0, n1, m0, m1);
+      mm3(L0, L1, x0, x1, w0, w1);
+      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
+      if (kb < NT && k < N) {
+        const u32 lo = (u32)L0[i] + 128u * (u32)L1[i], hi = (u32)H0[i] + 128u * (u32)H1[i];
+        rem[row + k] = (u16)((lo + hi) & (q - 1));
+        quot[row + k] = (u16)((0u - hi) & (q - 1));
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
@@ -3168,6 +3265,22 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
   if (B == 0) return NTRU_OK;
   if (!d_a || !d_b || !d_quot || !d_rem) return fail(NTRU_ERR_ARG, "ntru_polymul_split: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
+  // per-item product on the matrix cores: mod a power of two <= 8192, 64 <= N <= 1024 (automatic from N = 128)
+  if ((eng->path == 0 || eng->path == 4) && is_pow2(mod) && mod <= 8192 && N <= 1024 && N >= (eng->path == 4 ? 64 : 128)) {
+    PGeom pg;
+    pg.N = N; pg.NT = (N + 31) / 32; pg.tpitch = ((16 * pg.NT + 31) / 32) * 32 + 8;
+    const size_t lds = PI_WAVES * pi_wave_bytes2(pg);
+    if (int rc = allow_lds(k_polymul_m, lds)) return rc;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_polymul_m, 64 * PI_WAVES, lds));
+    long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
+    if (blocks > work) blocks = work;
+    snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
+    hipLaunchKernelGGL(k_polymul_m, dim3((unsigned)blocks), dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b,
+                       (long)B, d_quot, d_rem);
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  }
   Launch L;
   if (int rc = plan(eng, N, B, 0, true, &L)) return rc;
   DISPATCH_K(L.K, {

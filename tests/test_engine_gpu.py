@@ -478,6 +478,30 @@ def test_polymul_split_equals_oracle(eng, N, mod):
     assert np.array_equal(quot, quot_o) and np.array_equal(rem, rem_o)
 
 
+def test_polymul_split_matrix_core_kernel_sweep(eng):
+    """k_polymul_m (generic per-item product on the matrix cores, power-of-two moduli <= 8192): random (N, mod) with
+    unreduced operands and worst-case magnitudes, against the oracle and against the vector-ALU kernel."""
+    rng = np.random.default_rng(4242)
+    cases = [(64, 2), (64, 8192), (128, 4096), (1024, 8192), (1023, 2048), (821, 4096), (701, 8192), (257, 4), (640, 1024)]
+    cases += [(int(rng.integers(64, 1025)), 1 << int(rng.integers(1, 14))) for _ in range(8)]
+    for N, mod in cases:
+        B = int(rng.integers(1, 30))
+        a = rng.integers(0, 65536, (B, N)); b = rng.integers(0, 65536, (B, N))
+        a[0] = 65535; b[0] = 65535
+        if B > 2:
+            a[1] = mod - 1; b[1] = mod - 1; b[2] = 0; b[2, N - 1] = 1      # all (mod - 1); times x^(N-1)
+        eng.set_kernel_path(4)
+        quot, rem = eng.polymul_split(N, mod, a, b)
+        assert eng.last_kernel() == "k_polymul_m", (N, mod, eng.last_kernel())
+        eng.set_kernel_path(1)
+        quot1, rem1 = eng.polymul_split(N, mod, a, b)
+        assert eng.last_kernel() != "k_polymul_m"
+        eng.set_kernel_path(0)
+        quot_o, rem_o = orc.polymul_split_batch(N, mod, a % mod, b % mod)
+        assert np.array_equal(quot, quot_o) and np.array_equal(rem, rem_o), (N, mod)
+        assert np.array_equal(quot1, quot_o) and np.array_equal(rem1, rem_o), (N, mod, "vector-ALU kernel")
+
+
 @pytest.mark.parametrize("N,q,d", [(17, 32, 2), (167, 128, 18), (509, 2048, 169), (821, 4096, 273), (701, 8192, 233)])
 def test_verify_keys_batch_equals_oracle(eng, N, q, d, ):
     # synthetic per-item operands (SURVEY.md 8d config 5): outputs are fully defined, flags mostly "invalid"
