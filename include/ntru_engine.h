@@ -31,8 +31,9 @@
  *     accept arbitrary operand values for r and h, e, fq.
  *   - shared-key encrypt / decrypt with 64 <= N <= 1024 and q <= 8192 run on the int8 matrix cores (batch x Toeplitz
  *     matrix of the key, exact), and so does verify_keys with 128 <= N <= 1024, q <= 8192, p == 3 (each per-item product
- *     as a 32-row matrix product per tile distance); everything else on the vector-ALU kernel families.  Pointers may
- *     have any alignment.
+ *     as a 32-row matrix product per tile distance), polymul_split with a power-of-two modulus <= 8192, the public key
+ *     and the Newton rounds of the key inversion in the same N range; everything else on the vector-ALU kernel families.
+ *     Pointers may have any alignment.
  */
 #ifndef NTRU_ENGINE_H
 #define NTRU_ENGINE_H

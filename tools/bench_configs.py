@@ -121,7 +121,25 @@ def add_config(N, q, logB):
             "correct": ok}
 
 
+def polymul_config(N, q, logB):
+    """multiplyPolynomials + dividePolynomials by I (index.js:319-401) for B independent operand pairs, both < q."""
+    B = 1 << logB
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    a = torch.randint(0, q, (B, N), device=dev, generator=gen).to(torch.int16)
+    b = torch.randint(0, q, (B, N), device=dev, generator=gen).to(torch.int16)
+    quot = torch.empty((B, N), dtype=torch.int16, device=dev); rem = torch.empty((B, N), dtype=torch.int16, device=dev)
+    out = {}
+    for path, name in ((0, "auto"), (1, "vector ALU (packed MAC)")):
+        eng.set_kernel_path(path)
+        ms = timed(lambda: eng.polymul_split_dev(N, q, a.data_ptr(), b.data_ptr(), B, quot.data_ptr(), rem.data_ptr()))
+        out[name] = {"kernel": eng.last_kernel(), "ms": ms, "products_per_s": B / (ms * 1e-3)}
+    eng.set_kernel_path(0)
+    return {"config": "N=%d q=%d batch=2^%d multiplyPolynomials + split by I, per-item operands, 1 GPU" % (N, q, logB),
+            "kernel": out["auto"]["kernel"], "ms": out["auto"]["ms"], "products_per_s": out["auto"]["products_per_s"],
+            "vector_alu": out["vector ALU (packed MAC)"]}
+
+
 if __name__ == "__main__":
     for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
-                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), keygen_config("n821_q4096", 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20)):
+                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), keygen_config("n821_q4096", 18), polymul_config(821, 4096, 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20)):
         print(json.dumps(res), flush=True)
