@@ -2582,6 +2582,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
   diag_low_mask(lane, mlow);
   const bool stager = 16 * lane < 32 * NT;                                 // lanes that hold a 16-coefficient chunk of a row
   const v4i cmask = col_mask16(16 * lane, N);                              // bytes of this lane's chunk that are below N
+  const int kl = 128 * hh + r;                                             // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + kl
   wave_lds_fence();
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
     const long row = item * N, left = (B - item) * N;
@@ -2626,18 +2627,19 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     v16i L0, L1, H0, H1;
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
+      // stores through one-row descriptors: index k = 32 kb + r is a per-lane offset (128 hh + r) plus a compile-time
+      // one per register, indices >= N fall outside the descriptor and are dropped -- no address arithmetic per store
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fq + row, 2L * N), rs_q = rows_rsrc(quot_fq + row, 2L * N);
       bool nz_hi = false, first_not_one = false;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
-        if (kb < NT && k < N) {
-          const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
-          const u32 rv = (u32)(lo + hi) & (q - 1);
-          rem_fq[row + k] = (u16)rv;
-          quot_fq[row + k] = (u16)((u32)(0 - hi) & (q - 1));
-          nz_hi |= k >= 1 && rv != 0;
-          first_not_one |= k == 0 && rv != 1;
-        }
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        const u32 rv = (u32)(lo + hi) & (q - 1);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        nz_hi |= k >= 1 && k < N && rv != 0;
+        first_not_one |= k == 0 && rv != 1;
       }
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
     }
@@ -2653,19 +2655,18 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     wave_lds_fence();
     pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
       bool nz_hi = false, first_not_one = false;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
-        if (kb < NT && k < N) {
-          const int x = L0[i] + H0[i], y = 0 - H0[i];
-          const int xm = x % 3, ym = y % 3;
-          const u32 rv = (u32)(xm < 0 ? xm + 3 : xm), qv = (u32)(ym < 0 ? ym + 3 : ym);
-          rem_fp[row + k] = (uint8_t)rv;
-          quot_fp[row + k] = (uint8_t)qv;
-          nz_hi |= k >= 1 && rv != 0;
-          first_not_one |= k == 0 && rv != 1;
-        }
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        // |L + H|, |H| <= 127 N (f is an int8, fp < 3): a multiple of 3 above that keeps the dividend non-negative
+        const u32 x = (u32)(L0[i] + H0[i] + 3 * 131072), y = (u32)(3 * 131072 - H0[i]);
+        const u32 rv = x % 3u, qv = y % 3u;
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
+        nz_hi |= k >= 1 && k < N && rv != 0;
+        first_not_one |= k == 0 && rv != 1;
       }
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
     }
@@ -2685,28 +2686,29 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     }
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
+      const __amdgpu_buffer_rsrc_t rs_h = rows_rsrc(h + row, 2L * N);
+      u32 hv[16];                                                       // indices >= N read as zero
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        hv[i] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_h, 2 * kl, 64 * ((i & 3) + 8 * (i >> 2)), 0);
       int top = -1;
       u32 differs = 0;                                                  // bit i: h differs from the remainder at this lane's i-th index
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
-        if (kb < NT && k < N) {
-          const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
-          const u32 rv = (u32)(lo + hi) & (q - 1), hv = h[row + k];
-          rem_h[row + k] = (u16)rv;
-          quot_h[row + k] = (u16)((u32)(0 - hi) & (q - 1));
-          if (hv) top = k > top ? k : top;
-          differs |= hv != rv ? 1u << i : 0u;
-        }
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        const u32 rv = (u32)(lo + hi) & (q - 1);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        if (hv[i]) top = k > top ? k : top;
+        differs |= (k < N && hv[i] != rv) ? 1u << i : 0u;
       }
       const int wtop = wave_max(top);
       const int hl = wtop >= 0 ? wtop + 1 : 1;                          // trimmed length of h (1 for the zero polynomial)
       bool bad = false;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
-        bad |= ((differs >> i) & 1u) && k < hl;
-      }
+      for (int i = 0; i < 16; i++) bad |= ((differs >> i) & 1u) && 32 * ((i & 3) + 8 * (i >> 2)) + kl < hl;
       if (__ballot(bad) != 0) fl |= NTRU_FLAG_INVALID_H;
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
@@ -2760,13 +2762,16 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     }
     v16i L0, L1, H0, H1;
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
+      const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quot + row : nullptr, want_q ? 2L * N : 0L);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
-      if (kb < NT && k < N) {
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
-        rem[row + k] = (u16)((u32)(lo + hi) & (q - 1));
-        if (want_q) quot[row + k] = (u16)((u32)(0 - hi) & (q - 1));
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
       }
     }
     wave_lds_fence();
@@ -2857,13 +2862,15 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       mm3(L0, L1, x0, x1, w0, w1);
       x0 = n0; x1 = n1; w0 = m0; w1 = m1;
     }
+    {
+      const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N), rs_q = rows_rsrc(quot + row, 2L * N);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int kb = (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * kb + r;
-      if (kb < NT && k < N) {
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const u32 lo = (u32)L0[i] + 128u * (u32)L1[i], hi = (u32)H0[i] + 128u * (u32)H1[i];
-        rem[row + k] = (u16)((lo + hi) & (q - 1));
-        quot[row + k] = (u16)((0u - hi) & (q - 1));
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((0u - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
       }
     }
     wave_lds_fence();
