@@ -2454,9 +2454,9 @@ constexpr int PI_WAVES = 2;         // waves per workgroup (LDS, not registers, 
 struct PGeom { int N, NT, tpitch; };
 static __host__ __device__ inline size_t pi_fa_bytes(const PGeom &g) { return (size_t)32 * (g.NT + 2 * PI_PAD); }
 static __host__ __device__ inline size_t pi_nat_bytes(const PGeom &g) { return ((size_t)3 * g.N + 64 + 15) & ~(size_t)15; }
-static __host__ __device__ inline size_t pi_wave_bytes(const PGeom &g) {
-  return 2 * pi_fa_bytes(g) + pi_nat_bytes(g) + (size_t)16 * g.tpitch;
-}
+// per wave: the two chunk matrices, then the reversed array.  The three natural-order periods the array is built from
+// are staged OVER the chunk matrices (2 fa >= nat for every N <= 1024) and wiped again before the digits go in.
+static __host__ __device__ inline size_t pi_wave_bytes(const PGeom &g) { return 2 * pi_fa_bytes(g) + (size_t)16 * g.tpitch; }
 
 // Reversed cyclic array (4 byte-shifted copies) of the 16 bytes per lane in sv (coefficients 16 lane .. 16 lane + 15 of a
 // ternary operand, zero at and beyond N): three periods in natural order (period k starts at byte k N, any alignment:
@@ -2494,6 +2494,8 @@ static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T
       T[c * g.tpitch + w] = dk[c] == 0 ? __builtin_amdgcn_perm(dp, d0, sel[c]) : __builtin_amdgcn_perm(d0, dm, sel[c]);
   }
   wave_lds_fence();
+  for (int i = 16 * lane; i < (int)pi_nat_bytes(g); i += 16 * 64) *(v4i *)(nat + i) = (v4i){0, 0, 0, 0};   // nat lies over the
+  wave_lds_fence();                                                       // chunk matrices: their pads are zero again
 }
 
 // Digit planes of 16 values < q (u16 pairs in x[8]) -> natural-order int8 bytes; hs = d0 + 128 d1 is the signed
@@ -2571,8 +2573,8 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa1 + pi_fa_bytes(g);
-  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T = (u32 *)(fa1 + pi_fa_bytes(g));
   const int N = g.N, NT = g.NT;
   for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
   const int y0 = 32 * NT - 1 - r + 16 * hh;
@@ -2616,13 +2618,14 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       u32 xq[8];
       fetch_fq(xq);
       const v4i tf = ternary(fetch8(f + row));
+      pi_build_array(nat, T, g, lane, tf);
       if (stager) {
         v4i o0, o1;
         pi_digits(xq, q, 1u, 16 * lane, N, o0, o1);
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
       }
-      pi_build_array(nat, T, g, lane, tf);
+      wave_lds_fence();
     }
     v16i L0, L1, H0, H1;
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
@@ -2676,13 +2679,14 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       u32 xq[8];
       fetch_fq(xq);
       const v4i tg = ternary(fetch8(gg + row));
+      pi_build_array(nat, T, g, lane, tg);
       if (stager) {
         v4i o0, o1;
         pi_digits(xq, q, 3u, 16 * lane, N, o0, o1);
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
       }
-      pi_build_array(nat, T, g, lane, tg);
+      wave_lds_fence();
     }
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
@@ -2724,8 +2728,8 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa1 + pi_fa_bytes(g);
-  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T = (u32 *)(fa1 + pi_fa_bytes(g));
   const int N = g.N, NT = g.NT;
   for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
   const int y0 = 32 * NT - 1 - r + 16 * hh;
@@ -2752,13 +2756,14 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       union { v4i v; signed char c[16]; } u; u.v = vs[0] & cmask;        // any negative byte is -1 (ValTernary)
 #pragma unroll
       for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
+      pi_build_array(nat, T, g, lane, u.v);
       if (stager) {
         v4i o0, o1;
         pi_digits(xa, q, mul, 16 * lane, N, o0, o1);
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
       }
-      pi_build_array(nat, T, g, lane, u.v);
+      wave_lds_fence();
     }
     v16i L0, L1, H0, H1;
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
@@ -2789,8 +2794,8 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes2(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa1 + pi_fa_bytes(g);
-  u32 *T0 = (u32 *)(nat + pi_nat_bytes(g)), *T1 = T0 + 4 * g.tpitch;
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes2(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T0 = (u32 *)(fa1 + pi_fa_bytes(g)), *T1 = T0 + 4 * g.tpitch;
   const int N = g.N, NT = g.NT;
   for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
   const int y0 = 32 * NT - 1 - r + 16 * hh;
@@ -2816,12 +2821,13 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       v4i a0, a1, b0, b1;
       pi_digits(xa, q, 1u, 16 * lane, N, a0, a1);
       pi_digits(xb, q, 1u, 16 * lane, N, b0, b1);
+      pi_build_array(nat, T0, g, lane, b0);
+      pi_build_array(nat, T1, g, lane, b1);
       if (stager) {
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = a0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
       }
-      pi_build_array(nat, T0, g, lane, b0);
-      pi_build_array(nat, T1, g, lane, b1);
+      wave_lds_fence();
     }
     v16i L0, L1, H0, H1;                                   // group 0: a0 b0; group 1: a0 b1 + a1 b0
 #pragma unroll
