@@ -321,6 +321,33 @@ def main():
                                     "note": "ntru_engine_set_kernel_path(2): one ciphertext per wavefront, no MFMA; kernel "
                                             "times only, 3 steps"}
             eng.set_kernel_path(0)
+        if world == 1 and args.kernel_path == "auto" and not ablation:
+            # The other function of the path with per-item operands, verifyKeysInputs (index.js:141-197, BASELINE config 5),
+            # outside the timed region: 2^16 synthetic key pairs, kernel time of 3 launches (tools/bench_configs.py is the
+            # full secondary table).
+            Bk = 1 << 16
+            gk = torch.Generator(device=dev); gk.manual_seed(5)
+            tern = lambda: (torch.randint(0, 3, (Bk, N), device=dev, generator=gk) - 1).to(torch.int8)
+            kf, kg = tern(), tern()
+            kfq = torch.randint(0, q, (Bk, N), device=dev, generator=gk).to(torch.int16)
+            kh = torch.randint(0, q, (Bk, N), device=dev, generator=gk).to(torch.int16)
+            kfp = torch.randint(0, p, (Bk, N), device=dev, generator=gk).to(torch.uint8)
+            k16 = lambda: torch.empty((Bk, N), dtype=torch.int16, device=dev)
+            k8 = lambda: torch.empty((Bk, N), dtype=torch.uint8, device=dev)
+            kouts = [k16(), k16(), k8(), k8(), k16(), k16()]
+            kflags = torch.empty(Bk, dtype=torch.uint8, device=dev)
+            vk = lambda: eng.verify_keys_batch_dev(N, q, p, kf.data_ptr(), kg.data_ptr(), kfq.data_ptr(), kfp.data_ptr(),
+                                                   kh.data_ptr(), Bk, *[t.data_ptr() for t in kouts], kflags.data_ptr())
+            vk(); torch.cuda.synchronize()
+            kev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            kev[0].record(stream)
+            for i in range(3):
+                vk(); kev[i + 1].record(stream)
+            torch.cuda.synchronize()
+            vms = float(np.mean([kev[i].elapsed_time(kev[i + 1]) for i in range(3)]))
+            out["verify_keys"] = {"value": Bk / (vms * 1e-3), "unit": "key_pairs/s", "kernel": eng.last_kernel(), "ms": vms,
+                                  "batch": Bk, "hbm_gbs": 17.0 * N * Bk / (vms * 1e-3) / 1e9,
+                                  "note": "verifyKeysInputs with per-item keys (synthetic operands), kernel time only"}
         if ablation:       # timing-only build of the engine (tools/ablate.sh): results are NOT checked, not a benchmark line
             out = {"ABLATION_NOT_A_RESULT": os.environ["NTRU_ENGINE_LIB"], "results_match_oracle": bool(ok),
                    "kernels_ms": out["kernels_ms"], "ms_per_step": out["ms_per_step"]}
