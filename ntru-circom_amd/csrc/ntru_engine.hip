@@ -1645,9 +1645,6 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
     }
     int delta = 1;
     // GF(3) helpers on (is-one, is-two) plane pairs
-    auto mul3 = [](u32 a0, u32 a1, u32 m1, u32 m2, u32 &r0, u32 &r1) {   // by a scalar given as masks (==1, ==2)
-      r0 = (a0 & m1) | (a1 & m2); r1 = (a1 & m1) | (a0 & m2);
-    };
     auto add3 = [](u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
       const u32 az = ~(a0 | a1), bz = ~(b0 | b1);
       r0 = (a0 & bz) | (az & b0) | (a1 & b1);
@@ -1662,7 +1659,11 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       delta = (swap ? -delta : delta) + 1;
       const int c1 = swap ? gc : fc;                      // new f(0): multiplies g and w
       const int c2 = (P - (swap ? fc : gc)) % P;           // -(new g(0)): multiplies f and v
-      const u32 c1m1 = c1 == 1 ? ~0u : 0u, c1m2 = c1 == 2 ? ~0u : 0u, c2m1 = c2 == 1 ? ~0u : 0u, c2m2 = c2 == 2 ? ~0u : 0u;
+      const u32 c2m1 = c2 == 1 ? ~0u : 0u;
+      // GF(3): g and w are scaled by the unit 1 / f(0) every step (they stay consistent with each other, and the inverse
+      // is unique), so ONE scalar multiplies f and v: new g = (g - (g(0) / f(0)) f) / x, and 1 / f(0) = f(0) in GF(3)
+      const int cm = P == 3 ? (9 - (swap ? fc : gc) * c1) % 3 : 0;
+      const bool k1 = cm == 1, k2 = cm == 2;
       u32 vcar[PL], gprev[PL];
 #pragma unroll
       for (int pl = 0; pl < PL; pl++) { vcar[pl] = 0; gprev[pl] = 0; }
@@ -1675,17 +1676,24 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
           const u32 v = at(AV, pl, w);
           V[pl] = (v << 1) | vcar[pl];                    // v = x v
           vcar[pl] = v >> 31;
-          u32 t = sm & (F[pl] ^ G[pl]); F[pl] ^= t; G[pl] ^= t;      // conditional swaps
-          t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
+          if (P == 2) {
+            u32 t = sm & (F[pl] ^ G[pl]); F[pl] ^= t; G[pl] ^= t;    // conditional swaps
+            t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
+          } else {                                                    // ... as selects: the condition is per lane, not per bit
+            const u32 f_ = F[pl], v_ = V[pl];
+            F[pl] = swap ? G[pl] : f_; G[pl] = swap ? f_ : G[pl];
+            V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
+          }
         }
         u32 NG[PL], NWW[PL];
         if (P == 2) {                                     // c1 = 1; c2 = g(0)
           NG[0] = G[0] ^ (c2m1 & F[0]);
           NWW[0] = W[0] ^ (c2m1 & V[0]);
         } else {
-          u32 a0, a1, b0, b1;
-          mul3(G[0], G[1], c1m1, c1m2, a0, a1); mul3(F[0], F[1], c2m1, c2m2, b0, b1); add3(a0, a1, b0, b1, NG[0], NG[1]);
-          mul3(W[0], W[1], c1m1, c1m2, a0, a1); mul3(V[0], V[1], c2m1, c2m2, b0, b1); add3(a0, a1, b0, b1, NWW[0], NWW[1]);
+          const u32 b0 = k1 ? F[0] : (k2 ? F[1] : 0u), b1 = k1 ? F[1] : (k2 ? F[0] : 0u);      // cm * f
+          add3(G[0], G[1], b0, b1, NG[0], NG[1]);
+          const u32 d0 = k1 ? V[0] : (k2 ? V[1] : 0u), d1 = k1 ? V[1] : (k2 ? V[0] : 0u);      // cm * v
+          add3(W[0], W[1], d0, d1, NWW[0], NWW[1]);
         }
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
