@@ -2508,15 +2508,16 @@ static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T
 
 // Digit planes of 16 values < q (u16 pairs in x[8]) -> natural-order int8 bytes; hs = d0 + 128 d1 is the signed
 // representative used by k_encrypt_m.  mul: the operand is (mul v) mod q (p fq of index.js:155; 1 otherwise).
+// q <= 256: the centred representative fits ONE int8 plane (d1 = 0; the callers skip that plane's matrix instructions).
 static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 mul, int i0, int N, v4i &o0, v4i &o1) {
   union { v4i v; signed char c[16]; } d0, d1;
-  const int hthr = (int)(q >> 1) - 65;
+  const int hthr = q <= 256 ? (int)(q >> 1) - 1 : (int)(q >> 1) - 65;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
     const u32 v = ((x[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) * mul;
     int hs = i0 + j < N ? (int)(v & (q - 1)) : 0;
     hs = hs > hthr ? hs - (int)q : hs;
-    const int lo = ((hs + 64) & 127) - 64;
+    const int lo = q <= 256 ? hs : ((hs + 64) & 127) - 64;
     d0.c[j] = (signed char)lo;
     d1.c[j] = (signed char)((hs - lo) >> 7);
   }
@@ -2774,7 +2775,8 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       wave_lds_fence();
     }
     v16i L0, L1, H0, H1;
-    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    if (q <= 256) pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);   // one digit plane (early Newton rounds, small q)
+    else pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
       const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
@@ -2812,6 +2814,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
   u32 mlow[4];
   diag_low_mask(lane, mlow);
   const bool stager = 16 * lane < 32 * NT;
+  const bool one = q <= 256;                               // single int8 plane per operand (pi_digits)
   wave_lds_fence();
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
     const long row = item * N, left = (B - item) * N;
@@ -2830,7 +2833,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       pi_digits(xa, q, 1u, 16 * lane, N, a0, a1);
       pi_digits(xb, q, 1u, 16 * lane, N, b0, b1);
       pi_build_array(nat, T0, g, lane, b0);
-      pi_build_array(nat, T1, g, lane, b1);
+      if (!one) pi_build_array(nat, T1, g, lane, b1);
       if (stager) {
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = a0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
@@ -2849,8 +2852,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     };
     auto mm3 = [&](v16i &X0, v16i &X1, v4i x0, v4i x1, v4i w0, v4i w1) {
       X0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w0, X0, 0, 0, 0);
-      X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w1, X1, 0, 0, 0);
-      X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1, w0, X1, 0, 0, 0);
+      if (!one) {                                          // q <= 256: both operands are single planes
+        X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w1, X1, 0, 0, 0);
+        X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1, w0, X1, 0, 0, 0);
+      }
     };
     v4i x0, x1, w0, w1;
     ld(-(NT - 1), x0, x1, w0, w1);
@@ -3622,13 +3627,16 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
       hipLaunchKernelGGL(k_signed_to_u16, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, d_f + o * N, (long)(n * N),
                          (u32)q, (u16 *)f16.p);
       for (int r = 0; r < rounds; r++) {
-        if (int rc = ntru_polymul_split_dev(eng, N, q, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p)) return rc;
-        if (product_tern_m_applies(eng, N, q)) {          // f * t with f ternary: per-item product on the matrix cores
-          if (int rc = launch_product_tern_m(eng, N, q, 1u, (const u16 *)t.p, d_f + o * N, (long)n, nullptr, (u16 *)u.p)) return rc;
-        } else if (int rc = ntru_polymul_split_dev(eng, N, q, (const uint16_t *)f16.p, (const uint16_t *)t.p, n,
+        // Hensel lifting: round r only has to be right modulo 2^(2^(r+1)); the early rounds therefore run modulo 4, 16,
+        // 256 (single int8 digit planes on the matrix cores), the last one modulo q.  The inverse modulo q is unique.
+        const int mr = (2 << r) >= k ? q : 1 << (2 << r);
+        if (int rc = ntru_polymul_split_dev(eng, N, mr, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p)) return rc;
+        if (product_tern_m_applies(eng, N, mr)) {         // f * t with f ternary: per-item product on the matrix cores
+          if (int rc = launch_product_tern_m(eng, N, mr, 1u, (const u16 *)t.p, d_f + o * N, (long)n, nullptr, (u16 *)u.p)) return rc;
+        } else if (int rc = ntru_polymul_split_dev(eng, N, mr, (const uint16_t *)f16.p, (const uint16_t *)t.p, n,
                                                    (uint16_t *)qs.p, (uint16_t *)u.p)) return rc;
         hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, (u16 *)v,
-                           (const u16 *)u.p, (long)(n * N), (u32)q);
+                           (const u16 *)u.p, (long)(n * N), (u32)mr);
       }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(eng->stream));          // the temporaries are reused by the next chunk / freed on return
