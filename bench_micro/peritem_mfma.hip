@@ -1,4 +1,4 @@
-// Feasibility probe for round 2 (tools/peritem_mfma_model.py): ONE product with per-item
+// The probe that preceded k_verify_keys_m / k_product_tern_m / k_polymul_m (tools/peritem_mfma_model.py): ONE product with per-item
 // operands on the int8 matrix cores, one item per wavefront, no shared key.
 //   c = a * s in Z[x], a < q (two int8 digit planes), s ternary; rem = low + high, quot = -high (split by 1 - x^N).
 // For a tile distance d = kb - ib one v_mfma_i32_32x32x32_i8 adds the contribution of every tile pair at that distance:
