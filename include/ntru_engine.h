@@ -21,8 +21,10 @@
  *   - every function returns 0 on success or one of the NTRU_ERR_* codes; ntru_last_error() then
  *     returns a message for the calling thread.
  *   - *_dev entry points take DEVICE pointers and enqueue work on the engine's stream without
- *     synchronising; the same names without _dev take HOST pointers, copy in/out and return when
- *     the results are in the caller's buffers.
+ *     synchronising; the same names without _dev take HOST pointers and return when the results are in
+ *     the caller's buffers: the batch is cut into chunks that flow through two engine-owned streams
+ *     (H2D, kernel and D2H of neighbouring chunks overlap), through pinned staging arenas that only grow
+ *     -- or with no staging at all for buffers from ntru_host_alloc.  An engine is used by one thread at a time.
  *   - there is no CPU fallback: without a usable HIP device ntru_engine_create fails.
  *   - symbol preconditions (what the reference itself always produces): r in {0,1,2}; f, g in {-1,0,1}; fp and the
  *     plaintext-side values below p.  The fast kernels rely on them (the ternary add path steps over these operands by
@@ -165,8 +167,9 @@ int ntru_decrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, int p, int 
  * unique, so for units the result equals the reference's Euclidean algorithm bit for bit.  For f that is not a unit the
  * matching flag is set and the row is zero; the reference throws 'invalid_gcd' / 'invalid fq' for most such f but its
  * `&&` checks (index.js:41-45, :451) accept some and return meaningless polynomials -- that artefact is not reproduced.
- * The _dev form allocates its Newton temporaries itself (4 x 2N bytes per key, at most 65536 keys at a time) and waits
- * for the stream once per such chunk.  [§8(f) #1] */
+ * Either of fq / fp may be NULL when only the other inverse is wanted (polyInv(f, I, 3) / polyInv(f, I, q)).
+ * The Newton temporaries (4 x 2N bytes per key, at most 65536 keys at a time) live in an engine-owned buffer that only
+ * grows; nothing is allocated per call and the _dev form does not synchronise.  [§8(f) #1] */
 int ntru_invert_key_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, int64_t B, uint16_t *fq, uint8_t *fp,
                           uint8_t *flags);
 int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, int64_t B, uint16_t *d_fq,
@@ -194,6 +197,41 @@ int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int p, const in
                                const uint16_t *d_fq, const uint8_t *d_fp, const uint16_t *d_h, int64_t B,
                                uint16_t *d_quot_fq, uint16_t *d_rem_fq, uint8_t *d_quot_fp, uint8_t *d_rem_fp,
                                uint16_t *d_quot_h, uint16_t *d_rem_h, uint8_t *d_flags);
+
+/* ---- pinned host memory.  Buffers from ntru_host_alloc are page-locked: the host-pointer entry points below DMA
+ *      straight from / to them (any other host memory is staged through the engine's own pinned arenas, which costs a
+ *      CPU copy per byte).  The N-API addon hands them to JavaScript as TypedArrays (allocUint8 / allocUint16). */
+void *ntru_host_alloc(size_t bytes);
+void ntru_host_free(void *p);
+
+/* ---- generic, reference-faithful family (ntru_generic.hip): the reference's own algorithms on int64 coefficients, for
+ *      what the fast kernels do not cover -- moduli above 65536 (multiplyPolynomials(a, b, 2^20), test/circuits.test.js:72),
+ *      arbitrary divisors (dividePolynomials, index.js:358-401, e.g. test/circuits.test.js:165-170), and the stand-alone
+ *      extendedEuclideanAlgorithm (index.js:425-459) / polyInv (index.js:491-514) incl. their behaviour on non-units.
+ *      a: [B][la], b: [B][lb] signed, possibly unreduced coefficients, |x| <= 2^26; 1 <= mod <= 2^26 (every product the
+ *      reference forms then stays exact in a JS double).  Every item of a batch has the same operand lengths la, lb --
+ *      lengths matter to the reference (a.length, `r0.length !== 1`), so callers must not pad.  Result rows have a pitch of
+ *      ntru_generic_capacity(la, lb) elements; *_len[b] is the length of the (trimmed) result array the reference returns.
+ *      status[b]: 0, or the NTRU_GENERIC_* code of the error the reference throws for item b (its results are then empty).
+ *      Host pointers; one item per wavefront; a latency path, not a throughput path. */
+#define NTRU_GENERIC_DIV_BY_ZERO 1  /* "Cannot divide by zero polynomial."  (index.js:360) */
+#define NTRU_GENERIC_NO_INVERSE 2   /* "No inverse exists for division."    (index.js:378) */
+#define NTRU_GENERIC_INVALID_GCD 3  /* "invalid_gcd"                        (index.js:452) */
+#define NTRU_GENERIC_CAPACITY 4     /* internal: a result outgrew the work area (never expected) */
+int ntru_generic_capacity(int la, int lb);
+/* multiplyPolynomials(a, b, mod): out[b] = the linear product, coefficients in [0, mod), trimmed ([0] when la or lb is 0). */
+int ntru_generic_multiply(ntru_engine_t *eng, int la, int lb, int64_t mod, const int64_t *a, const int64_t *b, int64_t B,
+                          int64_t *out, int32_t *out_len);
+/* dividePolynomials(a, b, mod) -> { quotient, remainder } exactly as index.js:358-401 computes them. */
+int ntru_generic_divide(ntru_engine_t *eng, int la, int lb, int64_t mod, const int64_t *a, const int64_t *b, int64_t B,
+                        int64_t *quot, int32_t *quot_len, int64_t *rem, int32_t *rem_len, uint8_t *status);
+/* extendedEuclideanAlgorithm(a, b, mod) -> { gcd, inverse } (index.js:425-459). */
+int ntru_generic_eea(ntru_engine_t *eng, int la, int lb, int64_t mod, const int64_t *a, const int64_t *b, int64_t B,
+                     int64_t *gcd, int32_t *gcd_len, int64_t *inverse, int32_t *inverse_len, uint8_t *status);
+/* polyInv(a, polyI, mod) (index.js:491-514): EEA modulo 2 + log2(mod) - 1 Newton rounds when mod is a power of two,
+ * plain EEA otherwise. */
+int ntru_generic_poly_inv(ntru_engine_t *eng, int la, int lb, int64_t mod, const int64_t *a, const int64_t *poly_i,
+                          int64_t B, int64_t *inverse, int32_t *inverse_len, uint8_t *status);
 
 /* ---- BN254 field-element packing: packOutput / unpackInput (index.js:572-620), the wire format of the circuits'
  *      CombineArray / UnpackArray (circuits/ntru.circom:258-306).  bits = floor(log2(max_val)+1) per value,

@@ -1,7 +1,9 @@
 """MI355X-native NTRU polynomial-ring engine: host-side mirror of the reference's hot-path interface.
 
 Layout
-  csrc/ntru_engine.hip   HIP kernels (gfx950) + the C ABI declared in include/ntru_engine.h
+  csrc/ntru_engine.hip   HIP kernels (gfx950) + the *_dev entry points of the C ABI declared in include/ntru_engine.h
+  csrc/ntru_host.hip     host-pointer entry points: pinned staging, two streams, chunked H2D / kernel / D2H pipeline
+  csrc/ntru_generic.hip  reference-faithful generic family (arbitrary divisors, moduli up to 2^26, EEA, polyInv)
   lib/libntru_engine.so  built artefact (make -C csrc, or __graft_entry__.build())
   engine.py              ctypes binding of the C ABI (numpy host buffers or raw device pointers)
   ntru.py                `NTRU` class + pure functions with the reference's names and semantics (index.js)
@@ -12,5 +14,7 @@ raises `EngineError` when it (or a GPU) is missing.
 """
 from .engine import Engine, EngineError, library_path, load_library  # noqa: F401
 from . import sharding  # noqa: F401
-from .ntru import (NTRU, addCiphertexts, addPolynomials, degree, dividePolynomials, expandArray, generateCustomArray,  # noqa: F401
-                   multiplyPolynomials, packOutput, unpackInput, stringToBits, bitsToString, trimPolynomial)
+from .ntru import (NTRU, addCiphertexts, addPolynomials, bigintToBits, bitsToBigInt, bitsToString, degree,  # noqa: F401
+                   dividePolynomials, expandArray, extendedEuclideanAlgorithm, generateCustomArray, modInverse,
+                   multiplyPolynomials, multiplyPolynomialsByScalar, packOutput, polyInv, stringToBits,
+                   subtractPolynomials, trimPolynomial, unpackInput)

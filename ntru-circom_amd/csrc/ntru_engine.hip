@@ -29,7 +29,7 @@
 #include <string>
 #include <type_traits>
 
-#include "ntru_engine.h"
+#include "engine_internal.h"
 
 typedef unsigned short u16;
 typedef unsigned int u32;
@@ -2899,22 +2899,42 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
 // ---- host side ----------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+int ntru_fail(int code, const std::string &msg) { g_err = msg; return code; }
+static inline int fail(int code, const std::string &msg) { return ntru_fail(code, msg); }
 
-struct ntru_engine {
-  int device;
-  hipStream_t stream;
-  int cus;
-  int path;     // 0 auto, 1 MAC kernels, 2 add path, 3 add path without dot8, 4 matrix-core path (where applicable)
-  char last_kernel[64];   // name of the kernel the last *_dev call launched (reporting only)
-};
+int ntru_grow_dev(GrowBuf *b, size_t bytes) {
+  if (bytes <= b->cap) return NTRU_OK;
+  if (b->p) (void)hipFree(b->p);          // waits for the device: nothing in flight still reads the old buffer
+  b->p = nullptr; b->cap = 0;
+  const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  if (hipMalloc(&b->p, want) != hipSuccess) { b->p = nullptr; return fail(NTRU_ERR_HIP, "hipMalloc failed"); }
+  b->cap = want;
+  return NTRU_OK;
+}
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess)                                                                          \
-      return fail(NTRU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
-  } while (0)
+int ntru_grow_pinned(GrowBuf *b, size_t bytes) {
+  if (bytes <= b->cap) return NTRU_OK;
+  if (b->p) (void)hipHostFree(b->p);
+  b->p = nullptr; b->cap = 0;
+  const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  if (hipHostMalloc(&b->p, want, hipHostMallocDefault) != hipSuccess) { b->p = nullptr; return fail(NTRU_ERR_HIP, "hipHostMalloc failed"); }
+  b->cap = want;
+  return NTRU_OK;
+}
+
+// Occupancy of (kernel, block size, LDS bytes), asked once per engine; the first use of a kernel with more than 64 KiB
+// of dynamic LDS also raises its limit.
+int ntru_blocks_per_cu(ntru_engine *eng, const void *fn, int threads, size_t lds, int *per_cu) {
+  for (int i = 0; i < eng->n_occ; i++)
+    if (eng->occ[i].fn == fn && eng->occ[i].lds == lds && eng->occ[i].threads == threads) { *per_cu = eng->occ[i].per_cu; return NTRU_OK; }
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int n = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds));
+  if (n < 1) n = 1;
+  if (eng->n_occ < (int)(sizeof eng->occ / sizeof eng->occ[0])) eng->occ[eng->n_occ++] = {fn, lds, threads, n};
+  *per_cu = n;
+  return NTRU_OK;
+}
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -2961,17 +2981,36 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
   HIP_TRY(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
-  ntru_engine *eng = new ntru_engine;
+  ntru_engine *eng = new ntru_engine();
   eng->device = device;
   eng->stream = nullptr;
   eng->cus = prop.multiProcessorCount;
   eng->path = 0;
   eng->last_kernel[0] = 0;
+  eng->n_occ = 0;
+  eng->cur_scratch = &eng->scratch_dev;
+  eng->max_blocks_per_cu = 0;
+  if (const char *cap = getenv("NTRU_MAX_BLOCKS_PER_CU")) {      // tuning experiments only; read once
+    const int c = atoi(cap);
+    if (c >= 1) eng->max_blocks_per_cu = c;
+  }
   *out = eng;
   return NTRU_OK;
 }
 
-extern "C" void ntru_engine_destroy(ntru_engine_t *eng) { delete eng; }
+extern "C" void ntru_engine_destroy(ntru_engine_t *eng) {
+  if (!eng) return;
+  (void)hipSetDevice(eng->device);
+  for (HostSlot &s : eng->slot) {
+    if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+    if (s.pinned.p) (void)hipHostFree(s.pinned.p);
+    if (s.dev.p) (void)hipFree(s.dev.p);
+    if (s.scratch.p) (void)hipFree(s.scratch.p);
+  }
+  if (eng->shared_dev.p) (void)hipFree(eng->shared_dev.p);
+  if (eng->scratch_dev.p) (void)hipFree(eng->scratch_dev.p);
+  delete eng;
+}
 
 extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
@@ -3099,25 +3138,19 @@ static bool make_mgeom(const ntru_engine *eng, int N, int q, int ld, MGeom *g) {
 // Persistent grid: as many workgroups as are co-resident (occupancy query for this kernel and LDS size) x CUs, capped
 // by the work available.  A grid larger than residency would run its tail at a fraction of the chip.
 template <class Kern>
-static int resident_grid(const ntru_engine *eng, Kern kern, size_t lds, long work_blocks, dim3 *grid) {
+static int resident_grid(const ntru_engine *eng, Kern kern, size_t lds, long work_blocks, dim3 *grid, int threads = BLOCK_THREADS) {
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK_THREADS, lds));
-  if (per_cu < 1) per_cu = 1;
-  if (const char *cap = getenv("NTRU_MAX_BLOCKS_PER_CU")) {      // tuning experiments only
-    const int c = atoi(cap);
-    if (c >= 1 && c < per_cu) per_cu = c;
-  }
+  if (int rc = ntru_blocks_per_cu(const_cast<ntru_engine *>(eng), (const void *)kern, threads, lds, &per_cu)) return rc;
+  if (eng->max_blocks_per_cu && eng->max_blocks_per_cu < per_cu) per_cu = eng->max_blocks_per_cu;
   long blocks = (long)eng->cus * per_cu;
   if (blocks > work_blocks) blocks = work_blocks;
   *grid = dim3((unsigned)(blocks < 1 ? 1 : blocks));
   return NTRU_OK;
 }
 
+// The dynamic-LDS limit of a kernel is raised at its first use, inside ntru_blocks_per_cu (resident_grid).
 template <class Kern>
-static int allow_lds(Kern kern, size_t bytes) {
-  if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return NTRU_OK;
-}
+static int allow_lds(Kern, size_t) { return NTRU_OK; }
 
 #define DISPATCH_K(Kv, ...)                                                                       \
   switch (Kv) {                                                                                     \
@@ -3298,7 +3331,7 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
     const size_t lds = PI_WAVES * pi_wave_bytes2(pg);
     if (int rc = allow_lds(k_polymul_m, lds)) return rc;
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_polymul_m, 64 * PI_WAVES, lds));
+    if (int rc = ntru_blocks_per_cu(eng, (const void *)k_polymul_m, 64 * PI_WAVES, lds, &per_cu)) return rc;
     long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
     if (blocks > work) blocks = work;
     snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
@@ -3332,7 +3365,7 @@ static int launch_product_tern_m(ntru_engine *eng, int N, int q, u32 mul, const 
   const size_t lds = PI_WAVES * pi_wave_bytes(pg);
   if (int rc = allow_lds(k_product_tern_m, lds)) return rc;
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_product_tern_m, 64 * PI_WAVES, lds));
+  if (int rc = ntru_blocks_per_cu(eng, (const void *)k_product_tern_m, 64 * PI_WAVES, lds, &per_cu)) return rc;
   long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
   if (blocks > work) blocks = work;
   hipLaunchKernelGGL(k_product_tern_m, dim3((unsigned)blocks), dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, mul, d_a,
@@ -3387,7 +3420,7 @@ extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int 
     const size_t lds = PI_WAVES * pi_wave_bytes(pg);
     if (int rc = allow_lds(k_verify_keys_m, lds)) return rc;
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_verify_keys_m, 64 * PI_WAVES, lds));
+    if (int rc = ntru_blocks_per_cu(eng, (const void *)k_verify_keys_m, 64 * PI_WAVES, lds, &per_cu)) return rc;
     long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
     if (blocks > work) blocks = work;
     snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_verify_keys_m");
@@ -3473,114 +3506,17 @@ extern "C" int ntru_add_batch_dev(ntru_engine_t *eng, int N, int mod, const uint
   return NTRU_OK;
 }
 
-// ---- host-pointer convenience entry points: stage through device buffers in bounded chunks -------------------
+// ---- key inversion, sampler, field packing: *_dev entry points (the host-pointer forms are in ntru_host.hip) --------
 
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) {
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { p = nullptr; return fail(NTRU_ERR_HIP, "hipMalloc failed"); }
-    return NTRU_OK;
-  }
-};
-
-static const int64_t HOST_CHUNK = 1 << 16;   // items per staged chunk
-
-#define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst).p, (src), (bytes), hipMemcpyHostToDevice, eng->stream))
-#define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src).p, (bytes), hipMemcpyDeviceToHost, eng->stream))
-
-extern "C" int ntru_encrypt_batch(ntru_engine_t *eng, int N, int q, const uint16_t *h, const uint8_t *r,
-                                  const uint8_t *m, int64_t B, uint16_t *e, uint16_t *quotE) {
-  if (int rc = check_common(eng, N, q, B)) return rc;
-  if (B == 0) return NTRU_OK;
-  if (!h || !r || !m || !e) return fail(NTRU_ERR_ARG, "ntru_encrypt_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
-  DevBuf dh, dr, dm, de, dq;
-  if (dh.alloc((size_t)N * 2) || dr.alloc((size_t)C * N) || dm.alloc((size_t)C * N) || de.alloc((size_t)C * N * 2) ||
-      (quotE && dq.alloc((size_t)C * N * 2)))
-    return NTRU_ERR_HIP;
-  H2D(dh, h, (size_t)N * 2);
-  for (int64_t o = 0; o < B; o += C) {
-    const int64_t n = B - o < C ? B - o : C;
-    H2D(dr, r + o * N, (size_t)n * N);
-    H2D(dm, m + o * N, (size_t)n * N);
-    if (int rc = ntru_encrypt_batch_dev(eng, N, q, (const uint16_t *)dh.p, (const uint8_t *)dr.p, (const uint8_t *)dm.p,
-                                        n, (uint16_t *)de.p, quotE ? (uint16_t *)dq.p : nullptr))
-      return rc;
-    D2H(e + o * N, de, (size_t)n * N * 2);
-    if (quotE) D2H(quotE + o * N, dq, (size_t)n * N * 2);
-    HIP_TRY(hipStreamSynchronize(eng->stream));
-  }
-  return NTRU_OK;
-}
-
-extern "C" int ntru_decrypt_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, const uint8_t *fp,
-                                  const uint16_t *e, int64_t B, uint8_t *value, uint16_t *quot1, uint16_t *rem1,
-                                  uint8_t *quot2) {
-  if (int rc = check_common(eng, N, q, B)) return rc;
-  if (B == 0) return NTRU_OK;
-  if (!f || !fp || !e || !value) return fail(NTRU_ERR_ARG, "ntru_decrypt_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
-  DevBuf df, dfp, de, dv, dq1, dr1, dq2;
-  if (df.alloc(N) || dfp.alloc(N) || de.alloc((size_t)C * N * 2) || dv.alloc((size_t)C * N) ||
-      (quot1 && dq1.alloc((size_t)C * N * 2)) || (rem1 && dr1.alloc((size_t)C * N * 2)) ||
-      (quot2 && dq2.alloc((size_t)C * N)))
-    return NTRU_ERR_HIP;
-  H2D(df, f, (size_t)N);
-  H2D(dfp, fp, (size_t)N);
-  for (int64_t o = 0; o < B; o += C) {
-    const int64_t n = B - o < C ? B - o : C;
-    H2D(de, e + o * N, (size_t)n * N * 2);
-    if (int rc = ntru_decrypt_batch_dev(eng, N, q, p, (const int8_t *)df.p, (const uint8_t *)dfp.p,
-                                        (const uint16_t *)de.p, n, (uint8_t *)dv.p, quot1 ? (uint16_t *)dq1.p : nullptr,
-                                        rem1 ? (uint16_t *)dr1.p : nullptr, quot2 ? (uint8_t *)dq2.p : nullptr))
-      return rc;
-    D2H(value + o * N, dv, (size_t)n * N);
-    if (quot1) D2H(quot1 + o * N, dq1, (size_t)n * N * 2);
-    if (rem1) D2H(rem1 + o * N, dr1, (size_t)n * N * 2);
-    if (quot2) D2H(quot2 + o * N, dq2, (size_t)n * N);
-    HIP_TRY(hipStreamSynchronize(eng->stream));
-  }
-  return NTRU_OK;
-}
-
-extern "C" int ntru_polymul_split(ntru_engine_t *eng, int N, int mod, const uint16_t *a, const uint16_t *b,
-                                  int64_t B, uint16_t *quot, uint16_t *rem) {
-  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
-  if (!ntru_engine_supports(N, mod))
-    return fail(NTRU_ERR_UNSUPPORTED, "unsupported (N, mod): mod must be a power of two <= 65536 or satisfy N*(mod-1)^2 < 65536");
-  if (B == 0) return NTRU_OK;
-  if (!a || !b || !quot || !rem) return fail(NTRU_ERR_ARG, "ntru_polymul_split: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
-  DevBuf da, db, dq, dr;
-  const size_t row = (size_t)N * 2;
-  if (da.alloc(C * row) || db.alloc(C * row) || dq.alloc(C * row) || dr.alloc(C * row)) return NTRU_ERR_HIP;
-  for (int64_t o = 0; o < B; o += C) {
-    const int64_t n = B - o < C ? B - o : C;
-    H2D(da, a + o * N, n * row);
-    H2D(db, b + o * N, n * row);
-    if (int rc = ntru_polymul_split_dev(eng, N, mod, (const uint16_t *)da.p, (const uint16_t *)db.p, n,
-                                        (uint16_t *)dq.p, (uint16_t *)dr.p))
-      return rc;
-    D2H(quot + o * N, dq, n * row);
-    D2H(rem + o * N, dr, n * row);
-    HIP_TRY(hipStreamSynchronize(eng->stream));
-  }
-  return NTRU_OK;
-}
+static const int64_t INVERT_CHUNK = 1 << 16;   // keys per set of Newton temporaries
 
 template <int P, int NWC>
 static int launch_invert_nw(ntru_engine *eng, int N, const int8_t *d_f, long B, uint16_t *d16, uint8_t *d8, uint8_t *d_flags,
                             unsigned bit) {
   const size_t lds = NWC ? 0 : (size_t)(P == 2 ? 4 : 8) * ((N + 32) / 32) * 64 * 4;
   if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the inversion kernel's LDS planes");
-  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_invert_key<P, NWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_invert_key<P, NWC>, 64, lds));
+  if (int rc = ntru_blocks_per_cu(eng, (const void *)k_invert_key<P, NWC>, 64, lds, &per_cu)) return rc;
   long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL((k_invert_key<P, NWC>), dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, d_f, B, (u16 *)d16, d8,
@@ -3606,9 +3542,14 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   if (int rc = check_common(eng, N, q, B)) return rc;
   if (p != 3) return fail(NTRU_ERR_UNSUPPORTED, "key inversion implements p = 3 (and q a power of two)");
   if (B == 0) return NTRU_OK;
-  if (!d_f || !d_fq || !d_fp || !d_flags) return fail(NTRU_ERR_ARG, "ntru_invert_key_batch: NULL buffer");
+  if (!d_f || (!d_fq && !d_fp) || !d_flags) return fail(NTRU_ERR_ARG, "ntru_invert_key_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   HIP_TRY(hipMemsetAsync(d_flags, 0, (size_t)B, eng->stream));
+  if (!d_fq) {                                     // only the inverse modulo p was asked for (polyInv(f, I, 3))
+    if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
+    snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");
+    return NTRU_OK;
+  }
   // mod 2 inverse straight into d_fq (as 0/1 coefficients), then Newton rounds v <- 2v - f v^2 mod q (index.js:499-506;
   // the reference runs log2(q) - 1 of them, the unique inverse mod q is reached once 2^rounds >= log2(q))
   if (int rc = launch_invert<2>(eng, N, d_f, (long)B, d_fq, nullptr, d_flags, NTRU_FLAG_NOT_UNIT_MOD2)) return rc;
@@ -3617,10 +3558,11 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   int rounds = 0;
   while ((1 << rounds) < k) rounds++;
   if (rounds > 0) {
-    const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;     // temporaries for C keys at a time
-    const size_t row = (size_t)N * 2;
-    DevBuf f16, t, u, qs;
-    if (f16.alloc(C * row) || t.alloc(C * row) || u.alloc(C * row) || qs.alloc(C * row)) return NTRU_ERR_HIP;
+    const int64_t C = B < INVERT_CHUNK ? B : INVERT_CHUNK;     // temporaries for C keys at a time
+    const size_t row = (size_t)N * 2, part = ((size_t)C * row + 255) & ~(size_t)255;
+    if (int rc = ntru_grow_dev(eng->cur_scratch, 4 * part)) return rc;      // engine-owned, grown on demand, never per call
+    char *const sc = (char *)eng->cur_scratch->p;
+    struct { void *p; } f16{sc}, t{sc + part}, u{sc + 2 * part}, qs{sc + 3 * part};
     for (int64_t o = 0; o < B; o += C) {
       const int64_t n = B - o < C ? B - o : C;
       uint16_t *v = d_fq + o * N;
@@ -3638,127 +3580,11 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
         hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, (u16 *)v,
                            (const u16 *)u.p, (long)(n * N), (u32)mr);
       }
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipStreamSynchronize(eng->stream));          // the temporaries are reused by the next chunk / freed on return
+      HIP_TRY(hipGetLastError());                          // the next chunk reuses the temporaries in stream order
     }
   }
-  if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
+  if (d_fp) if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");
-  return NTRU_OK;
-}
-
-extern "C" int ntru_invert_key_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, int64_t B, uint16_t *fq,
-                                     uint8_t *fp, uint8_t *flags) {
-  if (int rc = check_common(eng, N, q, B)) return rc;
-  if (B == 0) return NTRU_OK;
-  if (!f || !fq || !fp || !flags) return fail(NTRU_ERR_ARG, "ntru_invert_key_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  DevBuf df, dfq, dfp, dfl;
-  if (df.alloc((size_t)B * N) || dfq.alloc((size_t)B * N * 2) || dfp.alloc((size_t)B * N) || dfl.alloc((size_t)B)) return NTRU_ERR_HIP;
-  H2D(df, f, (size_t)B * N);
-  if (int rc = ntru_invert_key_batch_dev(eng, N, q, p, (const int8_t *)df.p, B, (uint16_t *)dfq.p, (uint8_t *)dfp.p, (uint8_t *)dfl.p))
-    return rc;
-  D2H(fq, dfq, (size_t)B * N * 2);
-  D2H(fp, dfp, (size_t)B * N);
-  D2H(flags, dfl, (size_t)B);
-  HIP_TRY(hipStreamSynchronize(eng->stream));
-  return NTRU_OK;
-}
-
-extern "C" int ntru_public_key_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *fq, const int8_t *g,
-                                     int64_t B, uint16_t *h) {
-  if (int rc = check_common(eng, N, q, B)) return rc;
-  if (B == 0) return NTRU_OK;
-  if (!fq || !g || !h) return fail(NTRU_ERR_ARG, "ntru_public_key_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
-  DevBuf dfq, dg, dh;
-  if (dfq.alloc(C * (size_t)N * 2) || dg.alloc(C * (size_t)N) || dh.alloc(C * (size_t)N * 2)) return NTRU_ERR_HIP;
-  for (int64_t o = 0; o < B; o += C) {
-    const int64_t n = B - o < C ? B - o : C;
-    H2D(dfq, fq + o * N, n * (size_t)N * 2);
-    H2D(dg, g + o * N, n * (size_t)N);
-    if (int rc = ntru_public_key_batch_dev(eng, N, q, p, (const uint16_t *)dfq.p, (const int8_t *)dg.p, n, (uint16_t *)dh.p))
-      return rc;
-    D2H(h + o * N, dh, n * (size_t)N * 2);
-    HIP_TRY(hipStreamSynchronize(eng->stream));
-  }
-  return NTRU_OK;
-}
-
-extern "C" int ntru_verify_keys_batch(ntru_engine_t *eng, int N, int q, int p, const int8_t *f, const int8_t *g,
-                                      const uint16_t *fq, const uint8_t *fp, const uint16_t *h, int64_t B,
-                                      uint16_t *quot_fq, uint16_t *rem_fq, uint8_t *quot_fp, uint8_t *rem_fp,
-                                      uint16_t *quot_h, uint16_t *rem_h, uint8_t *flags) {
-  if (int rc = check_common(eng, N, q, B)) return rc;
-  if (B == 0) return NTRU_OK;
-  if (!f || !g || !fq || !fp || !h || !quot_fq || !rem_fq || !quot_fp || !rem_fp || !quot_h || !rem_h || !flags)
-    return fail(NTRU_ERR_ARG, "ntru_verify_keys_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
-  const size_t r8 = (size_t)N, r16 = (size_t)N * 2;
-  DevBuf df, dg, dfq, dfp, dh, o1, o2, o3, o4, o5, o6, dfl;
-  if (df.alloc(C * r8) || dg.alloc(C * r8) || dfq.alloc(C * r16) || dfp.alloc(C * r8) || dh.alloc(C * r16) ||
-      o1.alloc(C * r16) || o2.alloc(C * r16) || o3.alloc(C * r8) || o4.alloc(C * r8) || o5.alloc(C * r16) ||
-      o6.alloc(C * r16) || dfl.alloc((size_t)C))
-    return NTRU_ERR_HIP;
-  for (int64_t o = 0; o < B; o += C) {
-    const int64_t n = B - o < C ? B - o : C;
-    H2D(df, f + o * N, n * r8); H2D(dg, g + o * N, n * r8); H2D(dfq, fq + o * N, n * r16);
-    H2D(dfp, fp + o * N, n * r8); H2D(dh, h + o * N, n * r16);
-    if (int rc = ntru_verify_keys_batch_dev(eng, N, q, p, (const int8_t *)df.p, (const int8_t *)dg.p,
-                                            (const uint16_t *)dfq.p, (const uint8_t *)dfp.p, (const uint16_t *)dh.p, n,
-                                            (uint16_t *)o1.p, (uint16_t *)o2.p, (uint8_t *)o3.p, (uint8_t *)o4.p,
-                                            (uint16_t *)o5.p, (uint16_t *)o6.p, (uint8_t *)dfl.p))
-      return rc;
-    D2H(quot_fq + o * N, o1, n * r16); D2H(rem_fq + o * N, o2, n * r16);
-    D2H(quot_fp + o * N, o3, n * r8); D2H(rem_fp + o * N, o4, n * r8);
-    D2H(quot_h + o * N, o5, n * r16); D2H(rem_h + o * N, o6, n * r16);
-    D2H(flags + o, dfl, (size_t)n);
-    HIP_TRY(hipStreamSynchronize(eng->stream));
-  }
-  return NTRU_OK;
-}
-
-extern "C" int ntru_split_by_I(ntru_engine_t *eng, int N, int mod, const uint16_t *a, int64_t B, uint16_t *quot,
-                               uint16_t *rem) {
-  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
-  if (B == 0) return NTRU_OK;
-  if (!a || !quot || !rem) return fail(NTRU_ERR_ARG, "ntru_split_by_I: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
-  const size_t row = (size_t)N * 2;
-  DevBuf da, dq, dr;
-  if (da.alloc(C * row * 2) || dq.alloc(C * row) || dr.alloc(C * row)) return NTRU_ERR_HIP;
-  for (int64_t o = 0; o < B; o += C) {
-    const int64_t n = B - o < C ? B - o : C;
-    H2D(da, a + o * 2 * N, n * row * 2);
-    if (int rc = ntru_split_by_I_dev(eng, N, mod, (const uint16_t *)da.p, n, (uint16_t *)dq.p, (uint16_t *)dr.p)) return rc;
-    D2H(quot + o * N, dq, n * row);
-    D2H(rem + o * N, dr, n * row);
-    HIP_TRY(hipStreamSynchronize(eng->stream));
-  }
-  return NTRU_OK;
-}
-
-extern "C" int ntru_add_batch(ntru_engine_t *eng, int N, int mod, const uint16_t *a, const uint16_t *b, int64_t B,
-                              uint16_t *out) {
-  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
-  if (B == 0) return NTRU_OK;
-  if (!a || !b || !out) return fail(NTRU_ERR_ARG, "ntru_add_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  const int64_t C = B < HOST_CHUNK ? B : HOST_CHUNK;
-  const size_t row = (size_t)N * 2;
-  DevBuf da, db, dout;
-  if (da.alloc(C * row) || db.alloc(C * row) || dout.alloc(C * row)) return NTRU_ERR_HIP;
-  for (int64_t o = 0; o < B; o += C) {
-    const int64_t n = B - o < C ? B - o : C;
-    H2D(da, a + o * N, n * row);
-    H2D(db, b + o * N, n * row);
-    if (int rc = ntru_add_batch_dev(eng, N, mod, (const uint16_t *)da.p, (const uint16_t *)db.p, n, (uint16_t *)dout.p)) return rc;
-    D2H(out + o * N, dout, n * row);
-    HIP_TRY(hipStreamSynchronize(eng->stream));
-  }
   return NTRU_OK;
 }
 
@@ -3779,29 +3605,14 @@ extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2
   HIP_TRY(hipSetDevice(eng->device));
   ChaChaKey ck;
   memcpy(ck.k, key, 32);
-  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_sample_ternary, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample_ternary, 64, lds));
+  if (int rc = ntru_blocks_per_cu(eng, (const void *)k_sample_ternary, 64, lds, &per_cu)) return rc;
   long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
   if (blocks > cap) blocks = cap;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_sample_ternary");
   hipLaunchKernelGGL(k_sample_ternary, dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, n1, n2, (u32)other, ck,
                      (unsigned long long)first_item, (long)B, d_out, pitch);
   HIP_TRY(hipGetLastError());
-  return NTRU_OK;
-}
-
-extern "C" int ntru_sample_ternary(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
-                                   uint64_t first_item, int64_t B, uint8_t *out) {
-  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (B > 0 && !out) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: NULL buffer");
-  if (B <= 0) return ntru_sample_ternary_dev(eng, N, n1, n2, other, key, first_item, B, nullptr);
-  HIP_TRY(hipSetDevice(eng->device));
-  DevBuf d;
-  if (d.alloc((size_t)B * N)) return NTRU_ERR_HIP;
-  if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, other, key, first_item, B, (uint8_t *)d.p)) return rc;
-  D2H(out, d, (size_t)B * N);
-  HIP_TRY(hipStreamSynchronize(eng->stream));
   return NTRU_OK;
 }
 
@@ -3849,43 +3660,5 @@ extern "C" int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed
   hipLaunchKernelGGL(k_unpack, elementwise_grid(eng, B * packed_size * per), dim3(256), 0, eng->stream, bits, per,
                      packed_size, (const unsigned long long *)d_in, (long)B, d_out);
   HIP_TRY(hipGetLastError());
-  return NTRU_OK;
-}
-
-extern "C" int ntru_pack_batch(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *data, int64_t B,
-                               uint64_t *out) {
-  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  int bits, per, al, os;
-  if (int rc = ntru_pack_params(max_val, data_len, &bits, &per, &al, &os)) return rc;
-  if (B <= 0) return B == 0 ? NTRU_OK : fail(NTRU_ERR_ARG, "negative batch size");
-  if ((!data && data_len) || !out) return fail(NTRU_ERR_ARG, "ntru_pack_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  DevBuf din, dout;
-  if (din.alloc((size_t)B * data_len * 2) || dout.alloc((size_t)B * os * 32)) return NTRU_ERR_HIP;
-  if (data_len) H2D(din, data, (size_t)B * data_len * 2);
-  if (int rc = ntru_pack_batch_dev(eng, max_val, data_len, (const uint16_t *)din.p, B, (uint64_t *)dout.p)) return rc;
-  D2H(out, dout, (size_t)B * os * 32);
-  HIP_TRY(hipStreamSynchronize(eng->stream));
-  return NTRU_OK;
-}
-
-extern "C" int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *in, int packed_size,
-                                 int64_t B, uint16_t *out) {
-  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (B < 0 || packed_size < 0) return fail(NTRU_ERR_ARG, "negative size");
-  if (max_val < 1 || max_val > 65535) return fail(NTRU_ERR_ARG, "need 1 <= max_val <= 65535");
-  int bits = 0;
-  while ((max_val >> bits) != 0) bits++;
-  const int per = packed_bits / bits;
-  if (per < 1 || per * bits > 256) return fail(NTRU_ERR_ARG, "packed_bits does not hold a whole number of values within 256 bits");
-  if (B == 0 || packed_size == 0) return NTRU_OK;
-  if (!in || !out) return fail(NTRU_ERR_ARG, "ntru_unpack_batch: NULL buffer");
-  HIP_TRY(hipSetDevice(eng->device));
-  DevBuf din, dout;
-  if (din.alloc((size_t)B * packed_size * 32) || dout.alloc((size_t)B * packed_size * per * 2)) return NTRU_ERR_HIP;
-  H2D(din, in, (size_t)B * packed_size * 32);
-  if (int rc = ntru_unpack_batch_dev(eng, max_val, packed_bits, (const uint64_t *)din.p, packed_size, B, (uint16_t *)dout.p)) return rc;
-  D2H(out, dout, (size_t)B * packed_size * per * 2);
-  HIP_TRY(hipStreamSynchronize(eng->stream));
   return NTRU_OK;
 }

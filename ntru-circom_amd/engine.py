@@ -10,6 +10,9 @@ _LIB = None
 ERR_NAMES = {1: "NTRU_ERR_NO_DEVICE", 2: "NTRU_ERR_ARG", 3: "NTRU_ERR_UNSUPPORTED", 4: "NTRU_ERR_HIP"}
 FLAG_INVALID_FQ, FLAG_INVALID_FP, FLAG_INVALID_H = 1, 2, 4
 FLAG_NOT_UNIT_MOD2, FLAG_NOT_UNIT_MODP = 8, 16
+# status codes of the generic family = the errors the reference throws (include/ntru_engine.h NTRU_GENERIC_*)
+GENERIC_ERRORS = {1: "Cannot divide by zero polynomial.", 2: "No inverse exists for division.", 3: "invalid_gcd",
+                  4: "ntru engine: generic work area exhausted"}
 
 
 class EngineError(RuntimeError):
@@ -52,6 +55,13 @@ for _sfx in ("", "_dev"):
     _SIGS["ntru_encrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
     _SIGS["ntru_decrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
     _SIGS["ntru_verify_keys_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i] + [_vp] * 5 + [_i64] + [_vp] * 7)
+_SIGS["ntru_host_alloc"] = (C.c_void_p, [C.c_size_t])
+_SIGS["ntru_host_free"] = (None, [_vp])
+_SIGS["ntru_generic_capacity"] = (C.c_int, [_i, _i])
+_SIGS["ntru_generic_multiply"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _vp])
+_SIGS["ntru_generic_divide"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp])
+_SIGS["ntru_generic_eea"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp])
+_SIGS["ntru_generic_poly_inv"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _vp, _vp])
 _SIGS["ntru_encrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
 _SIGS["ntru_decrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
 
@@ -243,13 +253,73 @@ class Engine:
         self._chk(self._lib.ntru_public_key_batch(self._h, N, q, p, _ptr(fq), _ptr(g), B, _ptr(h)))
         return h
 
-    def invert_key_batch(self, N, q, p, f):
-        """loadPrivateKeyF / polyInv for B keys: (fq [B][N] u16, fp [B][N] u8, flags [B]); a set flag = not a unit."""
+    def invert_key_batch(self, N, q, p, f, want_fq=True, want_fp=True):
+        """loadPrivateKeyF / polyInv for B keys: (fq [B][N] u16, fp [B][N] u8, flags [B]); a set flag = not a unit.
+        want_fq / want_fp = False skips that half (its array comes back as None)."""
         f = _np(f, np.int8).reshape(-1, N)
         B = f.shape[0]
-        fq, fp, flags = np.empty((B, N), np.uint16), np.empty((B, N), np.uint8), np.empty(B, np.uint8)
+        fq = np.empty((B, N), np.uint16) if want_fq else None
+        fp = np.empty((B, N), np.uint8) if want_fp else None
+        flags = np.empty(B, np.uint8)
         self._chk(self._lib.ntru_invert_key_batch(self._h, N, q, p, _ptr(f), B, _ptr(fq), _ptr(fp), _ptr(flags)))
         return fq, fp, flags
+
+    # ---- pinned host memory ---------------------------------------------------------------------------------
+    def pinned_empty(self, shape, dtype):
+        """numpy array over page-locked memory (ntru_host_alloc): the batch entry points DMA it in place.  The memory is
+        released when the array (and every view of it) is gone."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = self._lib.ntru_host_alloc(n)
+        if not p:
+            raise EngineError(4, self._lib.ntru_last_error().decode())
+        lib = self._lib
+
+        class _Owner:
+            def __init__(self, ptr): self.ptr = ptr
+            def __del__(self): lib.ntru_host_free(self.ptr)
+        buf = (C.c_char * max(n, 1)).from_address(p)
+        buf._owner = _Owner(p)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    # ---- generic family (ntru_generic_*): int64 coefficients, uniform operand lengths per batch ---------------
+    def _generic(self, op, a, b, mod, two):
+        a, b = np.ascontiguousarray(a, dtype=np.int64), np.ascontiguousarray(b, dtype=np.int64)
+        if a.ndim == 1: a = a[None]
+        if b.ndim == 1: b = b[None]
+        B, la, lb = a.shape[0], a.shape[1], b.shape[1]
+        cap = self._lib.ntru_generic_capacity(la, lb)
+        o0, l0 = np.zeros((B, cap), np.int64), np.zeros(B, np.int32)
+        o1, l1 = (np.zeros((B, cap), np.int64), np.zeros(B, np.int32)) if two else (None, None)
+        st = np.zeros(B, np.uint8)
+        fn = [self._lib.ntru_generic_multiply, self._lib.ntru_generic_divide, self._lib.ntru_generic_eea,
+              self._lib.ntru_generic_poly_inv][op]
+        if op == 0:
+            rc = fn(self._h, la, lb, int(mod), _ptr(a), _ptr(b), B, _ptr(o0), _ptr(l0))
+        elif op == 3:
+            rc = fn(self._h, la, lb, int(mod), _ptr(a), _ptr(b), B, _ptr(o0), _ptr(l0), _ptr(st))
+        else:
+            rc = fn(self._h, la, lb, int(mod), _ptr(a), _ptr(b), B, _ptr(o0), _ptr(l0), _ptr(o1), _ptr(l1), _ptr(st))
+        self._chk(rc)
+        rows = lambda o, l: [o[i, :l[i]].tolist() for i in range(B)]
+        return rows(o0, l0), (rows(o1, l1) if two else None), st
+
+    def generic_multiply(self, a, b, mod):
+        """multiplyPolynomials per row (index.js:319-355), any modulus up to 2^26 -> list of trimmed lists."""
+        return self._generic(0, a, b, mod, False)[0]
+
+    def generic_divide(self, a, b, mod):
+        """dividePolynomials per row (index.js:358-401) -> (quotients, remainders, status[B])."""
+        return self._generic(1, a, b, mod, True)
+
+    def generic_eea(self, a, b, mod):
+        """extendedEuclideanAlgorithm per row (index.js:425-459) -> (gcds, inverses, status[B])."""
+        return self._generic(2, a, b, mod, True)
+
+    def generic_poly_inv(self, a, poly_i, mod):
+        """polyInv per row (index.js:491-514) -> (inverses, status[B])."""
+        r = self._generic(3, a, poly_i, mod, False)
+        return r[0], r[2]
 
     def invert_key_batch_dev(self, N, q, p, d_f, B, d_fq, d_fp, d_flags):
         dp = self._dp

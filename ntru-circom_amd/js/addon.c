@@ -9,6 +9,7 @@
 #include <node_api.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ntru_engine.h"
@@ -131,15 +132,15 @@ static napi_value AddBatch(napi_env env, napi_callback_info info) {
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
-/* invertKeyBatch(N, q, p, f:Int8Array[B*N], B, fq:Uint16Array[B*N], fp:Uint8Array[B*N], flags:Uint8Array[B]) */
+/* invertKeyBatch(N, q, p, f:Int8Array[B*N], B, fq:Uint16Array[B*N]|null, fp:Uint8Array[B*N]|null, flags:Uint8Array[B]) */
 static napi_value InvertKeyBatch(napi_env env, napi_callback_info info) {
   ARGS(8)
   int32_t N, q, p, B; void *f, *fq, *fp, *flags;
   if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) || !get_i32(env, argv[4], &B) ||
       N < 1 || B < 0) BAD_ARGS();
   size_t n = (size_t)N * (size_t)B;
-  if (!get_buf(env, argv[3], napi_int8_array, n, 0, &f) || !get_buf(env, argv[5], napi_uint16_array, n, 0, &fq) ||
-      !get_buf(env, argv[6], napi_uint8_array, n, 0, &fp) || !get_buf(env, argv[7], napi_uint8_array, (size_t)B, 0, &flags)) BAD_ARGS();
+  if (!get_buf(env, argv[3], napi_int8_array, n, 0, &f) || !get_buf(env, argv[5], napi_uint16_array, n, 1, &fq) ||
+      !get_buf(env, argv[6], napi_uint8_array, n, 1, &fp) || !get_buf(env, argv[7], napi_uint8_array, (size_t)B, 0, &flags)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
   int rc = ntru_invert_key_batch(g_engine, N, q, p, f, B, fq, fp, flags);
   return rc ? throw_engine(env, rc) : undefined(env);
@@ -265,6 +266,83 @@ static napi_value UnpackBatch(napi_env env, napi_callback_info info) {
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
+/* allocPinned(bytes) -> ArrayBuffer over page-locked memory (ntru_host_alloc): TypedArrays built on it are DMA'd in place
+ * by the batch entry points instead of being staged.  Released when the ArrayBuffer is garbage collected. */
+static void free_pinned(napi_env env, void *data, void *hint) { (void)env; (void)hint; ntru_host_free(data); }
+
+static napi_value AllocPinned(napi_env env, napi_callback_info info) {
+  ARGS(1)
+  double bytes;
+  if (napi_get_value_double(env, argv[0], &bytes) != napi_ok || bytes < 0 || bytes > 1e12) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  void *p = ntru_host_alloc((size_t)bytes);
+  if (!p) return throw_engine(env, NTRU_ERR_HIP);
+  napi_value ab;
+  if (napi_create_external_arraybuffer(env, p, (size_t)bytes, free_pinned, NULL, &ab) != napi_ok) {
+    ntru_host_free(p);
+    napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed");
+    return NULL;
+  }
+  return ab;
+}
+
+/* genericOp(op, a:Float64Array, b:Float64Array, mod, out0:Float64Array, out1:Float64Array|null) -> [status, len0, len1]
+ * op: 0 multiplyPolynomials, 1 dividePolynomials, 2 extendedEuclideanAlgorithm, 3 polyInv (one item; the generic family of
+ * include/ntru_engine.h).  JS Numbers cross as doubles and are converted to the int64 the C ABI takes; out0 / out1 need
+ * ntru_generic_capacity(a.length, b.length) elements (genericCapacity). */
+static napi_value GenericCapacity(napi_env env, napi_callback_info info) {
+  ARGS(2)
+  int32_t la, lb;
+  if (!get_i32(env, argv[0], &la) || !get_i32(env, argv[1], &lb)) BAD_ARGS();
+  napi_value r; NAPI_OK(napi_create_int32(env, ntru_generic_capacity(la, lb), &r)); return r;
+}
+
+static napi_value GenericOp(napi_env env, napi_callback_info info) {
+  ARGS(6)
+  int32_t op; double mod; void *a = NULL, *b = NULL, *o0 = NULL, *o1 = NULL;
+  size_t la = 0, lb = 0;
+  napi_typedarray_type t; bool is_ta = false;
+  if (!get_i32(env, argv[0], &op) || op < 0 || op > 3 || napi_get_value_double(env, argv[3], &mod) != napi_ok ||
+      mod != (double)(int64_t)mod) BAD_ARGS();
+  if (napi_is_typedarray(env, argv[1], &is_ta) != napi_ok || !is_ta ||
+      napi_get_typedarray_info(env, argv[1], &t, &la, &a, NULL, NULL) != napi_ok || t != napi_float64_array) BAD_ARGS();
+  if (napi_is_typedarray(env, argv[2], &is_ta) != napi_ok || !is_ta ||
+      napi_get_typedarray_info(env, argv[2], &t, &lb, &b, NULL, NULL) != napi_ok || t != napi_float64_array) BAD_ARGS();
+  const size_t cap = (size_t)ntru_generic_capacity((int)la, (int)lb);
+  if (!get_buf(env, argv[4], napi_float64_array, cap, 0, &o0) || !get_buf(env, argv[5], napi_float64_array, cap, 1, &o1)) BAD_ARGS();
+  if ((op == 1 || op == 2) && !o1) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int64_t *buf = (int64_t *)malloc((la + lb + 2 * cap + 2) * sizeof(int64_t));
+  if (!buf) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  int64_t *ia = buf, *ib = ia + la + 1, *r0 = ib + lb + 1, *r1 = r0 + cap;
+  for (size_t i = 0; i < la; i++) {
+    const double v = ((double *)a)[i];
+    if (v != (double)(int64_t)v) { free(buf); napi_throw_type_error(env, NULL, "coefficients must be integers"); return NULL; }
+    ia[i] = (int64_t)v;
+  }
+  for (size_t i = 0; i < lb; i++) {
+    const double v = ((double *)b)[i];
+    if (v != (double)(int64_t)v) { free(buf); napi_throw_type_error(env, NULL, "coefficients must be integers"); return NULL; }
+    ib[i] = (int64_t)v;
+  }
+  int32_t len0 = 0, len1 = 0; uint8_t st = 0;
+  int rc;
+  if (op == 0) rc = ntru_generic_multiply(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0);
+  else if (op == 1) rc = ntru_generic_divide(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, r1, &len1, &st);
+  else if (op == 2) rc = ntru_generic_eea(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, r1, &len1, &st);
+  else rc = ntru_generic_poly_inv(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, &st);
+  if (!rc) {
+    for (int32_t i = 0; i < len0; i++) ((double *)o0)[i] = (double)r0[i];
+    if (o1) for (int32_t i = 0; i < len1; i++) ((double *)o1)[i] = (double)r1[i];
+  }
+  free(buf);
+  if (rc) return throw_engine(env, rc);
+  napi_value arr; NAPI_OK(napi_create_array_with_length(env, 3, &arr));
+  const int32_t v[3] = {st, len0, len1};
+  for (int i = 0; i < 3; i++) { napi_value n; NAPI_OK(napi_create_int32(env, v[i], &n)); NAPI_OK(napi_set_element(env, arr, i, n)); }
+  return arr;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
     {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
@@ -283,6 +361,9 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"packParams", NULL, PackParams, NULL, NULL, NULL, napi_default, NULL},
     {"packBatch", NULL, PackBatch, NULL, NULL, NULL, napi_default, NULL},
     {"unpackBatch", NULL, UnpackBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"allocPinned", NULL, AllocPinned, NULL, NULL, NULL, napi_default, NULL},
+    {"genericCapacity", NULL, GenericCapacity, NULL, NULL, NULL, napi_default, NULL},
+    {"genericOp", NULL, GenericOp, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof props / sizeof props[0], props) != napi_ok) return NULL;
   return exports;

@@ -12,8 +12,10 @@
 // There is no JavaScript arithmetic fallback: without the addon or a GPU the first call throws.
 //
 // Key generation runs on the device too (loadPrivateKeyF, generatePrivateKeyF, generateNewPublicKeyGH,
-// generatePublicKeyH); the stand-alone helpers polyInv / extendedEuclideanAlgorithm / generic long division are not exported.
-// Keys are supplied through the options object, as README.md:81 of the reference already allows.
+// generatePublicKeyH).  The whole export list of the reference is here (default NTRU + its 19 named functions):
+// polyInv / extendedEuclideanAlgorithm / dividePolynomials by an arbitrary divisor / products modulo more than 65536 run
+// on the engine's generic family (ntru_generic_*: the reference's own algorithms, one item per wavefront), which also
+// serves the f that are not units, so that loadPrivateKeyF behaves like the reference there too.
 import { createRequire } from 'module';
 import { randomFillSync } from 'crypto';
 
@@ -99,11 +101,92 @@ export function generateCustomArray(length, numOnes, numNegOnes) {
 
 const mod = (x, p) => ((x % p) + p) % p;
 
+// ---- the reference's remaining O(N) helpers (host glue, like addPolynomials) ------------------------------------
+
+export function modInverse(a, p) {                               // index.js:224-232
+  a = ((a % p) + p) % p;
+  for (let x = 1; x < p; x++) if ((a * x) % p === 1) return x;
+  return null;
+}
+
+export function subtractPolynomials(a, b, p) {                   // index.js:247-256
+  const n = Math.max(a.length, b.length), out = [];
+  for (let i = 0; i < n; i++) out[i] = (((i < a.length ? a[i] : 0) - (i < b.length ? b[i] : 0)) % p + p) % p;
+  return trimPolynomial(out);
+}
+
+export function multiplyPolynomialsByScalar(poly, scalar, p) {   // index.js:404-406
+  return poly.map(coeff => (coeff * scalar) % p);
+}
+
+export function bigintToBits(bigint) {                           // index.js:558-566
+  const bits = [];
+  while (bigint > 0n) { bits.push(Number(bigint & 1n)); bigint >>= 1n; }
+  return bits;
+}
+
+export function bitsToBigInt(bits) { return BigInt(`0b${bits.join('')}`); }   // index.js:568-570
+
+// ---- generic family of the engine (include/ntru_engine.h, ntru_generic_*): one item, JS Numbers in and out --------
+const GENERIC_ERRORS = [null, 'Cannot divide by zero polynomial.', 'No inverse exists for division.', 'invalid_gcd',
+  'ntru engine: generic work area exhausted'];
+const REFERENCE_KEYGEN_ERRORS = new Set(['invalid_gcd', 'invalid fq', 'invalid fp', GENERIC_ERRORS[1], GENERIC_ERRORS[2]]);
+
+function genericOp(op, a, b, mod) {
+  const A = Float64Array.from(a), Bv = Float64Array.from(b);
+  const cap = engine().genericCapacity(A.length, Bv.length);
+  const o0 = new Float64Array(cap), o1 = op === 1 || op === 2 ? new Float64Array(cap) : null;
+  const [status, len0, len1] = engine().genericOp(op, A, Bv, mod, o0, o1);
+  if (status) throw new Error(GENERIC_ERRORS[status]);
+  return [Array.from(o0.subarray(0, len0)), o1 ? Array.from(o1.subarray(0, len1)) : null];
+}
+
+const isI = (b, p) => {                                           // b = [1, 0, ..., 0, -1] (or p-1) of length N+1 >= 2
+  const N = b.length - 1;
+  if (N < 1 || mod(b[0], p) !== 1 || mod(b[N], p) !== p - 1) return false;
+  for (let i = 1; i < N; i++) if (mod(b[i], p) !== 0) return false;
+  return true;
+};
+const fastModulus = (N, p) => Number.isInteger(p) && p >= 2 &&
+  ((p & (p - 1)) === 0 ? p <= 65536 : N * (p - 1) * (p - 1) < 65536);
+
+// index.js:425-459 -> { gcd, inverse }
+export function extendedEuclideanAlgorithm(a, b, p) {
+  const [gcd, inverse] = genericOp(2, a, b, p);
+  return { gcd, inverse };
+}
+
+// index.js:491-514.  The key-generation case -- ternary f, polyI = 1 - x^N, modulus 3 or a power of two -- runs on the
+// batched inversion kernels (k_invert_key + Newton rounds on the matrix cores); the inverse of a unit is unique, so that
+// is the reference's result.  Everything else, and every f those kernels flag as a non-unit, goes through the generic
+// family, which follows the reference step by step (and throws what it throws).
+export function polyInv(polyIn, polyI, polyMod) {
+  const N = polyI.length - 1;
+  const ternary = polyIn.length <= N && polyIn.every(x => x === 0 || x === 1 || x === -1);
+  const pow2 = Number.isInteger(polyMod) && polyMod >= 2 && polyMod <= 65536 && (polyMod & (polyMod - 1)) === 0;
+  if (ternary && N >= 2 && N <= 1920 && (polyMod === 3 || pow2) && polyI[0] === 1 && polyI[N] === -1 &&
+      polyI.every((x, i) => i === 0 || i === N || x === 0)) {
+    const f = Int8Array.from(expandArray(polyIn, N, 0)), flags = new Uint8Array(1);
+    if (polyMod === 3) {
+      const fp = new Uint8Array(N);
+      engine().invertKeyBatch(N, 2, 3, f, 1, null, fp, flags);
+      if (!(flags[0] & 16)) return trimPolynomial(Array.from(fp));
+    } else {
+      const fq = new Uint16Array(N);
+      engine().invertKeyBatch(N, polyMod, 3, f, 1, fq, null, flags);
+      if (!(flags[0] & 8)) return trimPolynomial(Array.from(fq));
+    }
+  }
+  return genericOp(3, polyIn, polyI, polyMod)[0];
+}
+
 // index.js:319-355: linear product, coefficients into [0,p), trimmed.  One GPU polymul-split in a ring that
-// holds both operands; c[N+k] = -quot[k], c[k] = rem[k] - c[N+k].
+// holds both operands; c[N+k] = -quot[k], c[k] = rem[k] - c[N+k].  Moduli the packed kernels do not take (above 65536,
+// e.g. the 2^20 of test/circuits.test.js:72) run on the generic family.
 export function multiplyPolynomials(a, b, p) {
   if (a.length === 0 || b.length === 0) return [0];
   const N = Math.max(a.length, b.length, 2);
+  if (!fastModulus(N, p)) return genericOp(0, a, b, p)[0];
   const A = new Uint16Array(N), Bv = new Uint16Array(N), quot = new Uint16Array(N), rem = new Uint16Array(N);
   for (let i = 0; i < a.length; i++) A[i] = mod(a[i], p);
   for (let i = 0; i < b.length; i++) Bv[i] = mod(b[i], p);
@@ -117,14 +200,16 @@ export function multiplyPolynomials(a, b, p) {
   return trimPolynomial(out);
 }
 
-// index.js:358-401 for the hot path's divisor b = I = 1 - x^N; generic long division is key-generation code.
+// index.js:358-401.  The hot path's divisor b = I = 1 - x^N with a reduced dividend is the closed-form split kernel;
+// any other divisor (or an unreduced dividend) is long division on the generic family.
 export function dividePolynomials(a, b, p) {
   if (degree(b) === -1) throw new Error('Cannot divide by zero polynomial.');
   const N = b.length - 1;
-  let isI = N >= 1 && mod(b[0], p) === 1 && mod(b[N], p) === p - 1;
-  for (let i = 1; isI && i < N; i++) isI = mod(b[i], p) === 0;
-  if (!isI || a.length > 2 * N || a.some(x => x < 0 || x >= p))
-    throw new Error('ntru engine: dividePolynomials only supports b = 1 - x^N with a reduced dividend of length <= 2N');
+  if (!(Number.isInteger(p) && p >= 2 && p <= 65536 && isI(b, p) && a.length <= 2 * N &&
+        a.every(x => Number.isInteger(x) && x >= 0 && x < p))) {
+    const [quotient, remainder] = genericOp(1, a, b, p);
+    return { quotient, remainder };
+  }
   const A = new Uint16Array(2 * N), quot = new Uint16Array(N), rem = new Uint16Array(N);
   A.set(a);
   engine().splitByI(N, p, A, 1, quot, rem);
@@ -192,12 +277,29 @@ export default class NTRU {
     const { N, p, q } = this;
     const r = generateCustomArray(N, this.dr, this.dr).map(x => x === -1 ? p - 1 : x);
     const mPad = expandArray(m, N, 0), hPad = expandArray(this.h, N, 0);
-    if (mPad.some(x => !(x >= 0 && x <= 255))) throw new Error('ntru engine: plaintext coefficients must be in 0..255');
+    // addPolynomials(m, rhq, q) reduces any integer m[i] modulo q (index.js:91, :241); the device adds a byte, and
+    // (m mod q) mod 256 is the same residue modulo q whenever q divides 256 -- otherwise m mod q must fit the byte.
+    const mDev = Uint8Array.from(mPad, x => { const v = mod(x, q); return q <= 256 ? v : v & 255; });
+    if (q > 256 && mPad.some(x => mod(x, q) > 255)) return this.encryptBitsWide(m, r, mPad, hPad);
     const e = new Uint16Array(N), quot = new Uint16Array(N);
-    engine().encryptBatch(N, q, Uint16Array.from(hPad), Uint8Array.from(r), Uint8Array.from(mPad), 1, e, quot);
+    engine().encryptBatch(N, q, Uint16Array.from(hPad), Uint8Array.from(r), mDev, 1, e, quot);
     return {
       value: trimPolynomial(Array.from(e)),
       inputs: { r, m: mPad, h: hPad, quotientE: withZero(quot), remainderE: withZero(e) },
+      params: [q, this.calculateNq(), N],
+    };
+  }
+
+  // Plaintext coefficients that do not fit the kernel's byte operand (the reference accepts any integer): the same
+  // three steps as index.js:90-92 as separate engine calls.
+  encryptBitsWide(m, r, mPad, hPad) {
+    const { N, q } = this;
+    const rhqm = addPolynomials(m, multiplyPolynomials(r, this.h, q), q);
+    const { quotient, remainder } = dividePolynomials(rhqm, this.I, q);
+    return {
+      value: trimPolynomial(remainder),
+      inputs: { r, m: mPad, h: hPad, quotientE: expandArray(quotient.map(x => x % q), N + 1, 0),
+        remainderE: expandArray(remainder, N + 1, 0) },
       params: [q, this.calculateNq(), N],
     };
   }
@@ -219,23 +321,47 @@ export default class NTRU {
     };
   }
 
-  loadPrivateKeyF(fArr) {                                        // index.js:30-49: fq, fp by inversion on the device
+  // index.js:30-49.  Units (every f a key generator ends up with) take the batched inversion kernels: fq and fp are
+  // unique, so they are the reference's, and its validity checks pass by construction.  For an f those kernels flag,
+  // the reference's own sequence runs on the generic family: same assignments in the same order, same throws, same
+  // acceptance of the non-units its `&&` checks let through (index.js:41-45, :451).
+  loadPrivateKeyF(fArr) {
     const { N, p, q } = this;
-    const fq = new Uint16Array(N), fp = new Uint8Array(N), flags = new Uint8Array(1);
-    addon.invertKeyBatch(N, q, p, Int8Array.from(expandArray(fArr, N, 0)), 1, fq, fp, flags);
-    // not a unit: the reference throws 'invalid_gcd' / 'invalid fq' for most such f (and accepts a few by accident)
-    if (flags[0] & 24) throw new Error('invalid_gcd');
+    const ternary = fArr.length <= N && fArr.every(x => x === 0 || x === 1 || x === -1);
+    if (ternary && p === 3 && fastModulus(N, q) && (q & (q - 1)) === 0) {
+      const fq = new Uint16Array(N), fp = new Uint8Array(N), flags = new Uint8Array(1);
+      engine().invertKeyBatch(N, q, p, Int8Array.from(expandArray(fArr, N, 0)), 1, fq, fp, flags);
+      if (!(flags[0] & 24)) {
+        this.f = fArr;
+        this.fq = trimPolynomial(Array.from(fq));
+        this.fp = trimPolynomial(Array.from(fp));
+        return true;
+      }
+    }
     this.f = fArr;
-    this.fq = trimPolynomial(Array.from(fq));
-    this.fp = trimPolynomial(Array.from(fp));
+    this.fq = polyInv(this.f, this.I, q);
+    this.fp = polyInv(this.f, this.I, p);
+    const fmodq = this.f.map(x => x === -1 ? q - 1 : x), fmodp = this.f.map(x => x === -1 ? p - 1 : x);
+    const fqDiv = dividePolynomials(multiplyPolynomials(this.fq, fmodq, q), this.I, q);
+    if (fqDiv.remainder.length !== 1 && fqDiv.remainder[0] !== 1) throw new Error('invalid fq');
+    const fpDiv = dividePolynomials(multiplyPolynomials(this.fp, fmodp, p), this.I, p);
+    if (fpDiv.remainder.length !== 1 && fpDiv.remainder[0] !== 1) throw new Error('invalid fp');
     return true;
   }
 
   generatePrivateKeyF() {                                        // index.js:51-65
-    for (let i = 0; i < 100; i++) {
-      try { return this.loadPrivateKeyF(generateCustomArray(this.N, this.df, this.df - 1)); } catch (error) { /* next f */ }
+    const maxTries = 100;
+    let i = 0, retval;
+    while ((!retval || !(this.fq && this.fp)) && i++ < maxTries) {
+      try {
+        retval = this.loadPrivateKeyF(generateCustomArray(this.N, this.df, this.df - 1));
+      } catch (error) {
+        // the reference swallows everything here; only what IT can throw means "try the next f" -- an engine, addon
+        // or GPU failure must surface instead of ending as 'Could not find invertible f'
+        if (!REFERENCE_KEYGEN_ERRORS.has(error.message)) throw error;
+      }
     }
-    throw new Error('Could not find invertible f');
+    if (!this.fq || !this.fp) throw new Error('Could not find invertible f');
   }
 
   generateNewPublicKeyGH() {                                     // index.js:67-70
@@ -248,7 +374,7 @@ export default class NTRU {
     if (!this.g) throw new Error('missing private key G');
     const { N, p, q } = this;
     const h = new Uint16Array(N);
-    addon.publicKeyBatch(N, q, p, Uint16Array.from(expandArray(this.fq, N, 0)), Int8Array.from(expandArray(this.g, N, 0)), 1, h);
+    engine().publicKeyBatch(N, q, p, Uint16Array.from(expandArray(this.fq, N, 0)), Int8Array.from(expandArray(this.g, N, 0)), 1, h);
     this.h = trimPolynomial(Array.from(h));
   }
 
@@ -283,10 +409,15 @@ export default class NTRU {
   }
 
   // ---- additive batch API (typed arrays, fixed stride N; see include/ntru_engine.h for the layout) -----------
+  // Page-locked typed arrays (ntru_host_alloc): the batch calls DMA straight from / to them, no staging copy.
+  static allocUint8(n) { return new Uint8Array(engine().allocPinned(n), 0, n); }
+  static allocUint16(n) { return new Uint16Array(engine().allocPinned(2 * n), 0, n); }
+
   // r: Uint8Array[B*N] in {0,1,2}, m: Uint8Array[B*N]  ->  { e, quotientE } as Uint16Array[B*N]
-  encryptBatch(r, m, B, wantWitness = true) {
+  // `out` may carry preallocated result arrays (e.g. from NTRU.allocUint16, which are page-locked and DMA'd in place).
+  encryptBatch(r, m, B, wantWitness = true, out = {}) {
     const { N, q } = this;
-    const e = new Uint16Array(B * N), quot = wantWitness ? new Uint16Array(B * N) : null;
+    const e = out.e || new Uint16Array(B * N), quot = wantWitness ? (out.quotientE || new Uint16Array(B * N)) : null;
     engine().encryptBatch(N, q, Uint16Array.from(expandArray(this.h, N, 0)), r, m, B, e, quot);
     return { e, quotientE: quot };
   }
@@ -300,11 +431,12 @@ export default class NTRU {
   }
 
   // e: Uint16Array[B*N] -> { value, quotient1, remainder1, quotient2 }
-  decryptBatch(e, B, wantWitness = true) {
+  decryptBatch(e, B, wantWitness = true, out = {}) {
     const { N, p, q } = this;
-    const value = new Uint8Array(B * N);
-    const q1 = wantWitness ? new Uint16Array(B * N) : null, r1 = wantWitness ? new Uint16Array(B * N) : null;
-    const q2 = wantWitness ? new Uint8Array(B * N) : null;
+    const value = out.value || new Uint8Array(B * N);
+    const q1 = wantWitness ? (out.quotient1 || new Uint16Array(B * N)) : null;
+    const r1 = wantWitness ? (out.remainder1 || new Uint16Array(B * N)) : null;
+    const q2 = wantWitness ? (out.quotient2 || new Uint8Array(B * N)) : null;
     engine().decryptBatch(N, q, p, Int8Array.from(expandArray(this.f, N, 0)), Uint8Array.from(expandArray(this.fp, N, 0)),
       e, B, value, q1, r1, q2);
     return { value, quotient1: q1, remainder1: r1, quotient2: q2 };

@@ -9,14 +9,16 @@ Same names, argument meaning, return shapes and error behaviour as the reference
 
 All polynomial products and the quotient/remainder split run on the GPU through the C ABI
 (include/ntru_engine.h); this file only reshapes data (padding, trimming, dict building), which is what
-SURVEY.md section 8 assigns to the shim.  Key generation (index.js:30-79, 425-514) is out of scope: set
-f, fp, fq, g, h through the constructor options or the public fields, exactly as the reference allows.
+SURVEY.md section 8 assigns to the shim.  Key generation (index.js:30-79) runs on the device as well; polyInv,
+extendedEuclideanAlgorithm, dividePolynomials by an arbitrary divisor and products modulo more than 65536 run on the
+engine's generic family (ntru_generic_*), which follows the reference step by step, non-units included.
 """
 import secrets
 
 import numpy as np
 
-from .engine import FLAG_INVALID_FP, FLAG_INVALID_FQ, FLAG_INVALID_H, Engine, EngineError
+from .engine import (FLAG_INVALID_FP, FLAG_INVALID_FQ, FLAG_INVALID_H, FLAG_NOT_UNIT_MOD2, FLAG_NOT_UNIT_MODP,
+                     GENERIC_ERRORS, Engine, EngineError)
 
 _DEFAULT_ENGINE = None
 
@@ -90,15 +92,75 @@ def bitsToString(bits):
     return "".join(out)
 
 
+class ReferenceError_(ValueError):
+    """An error the reference itself throws (`throw new Error(msg)`): str(e) is the reference's message."""
+
+
+def _js_mod(x, p):
+    """JS `%`: truncated remainder, sign of the dividend."""
+    return int(np.fmod(x, p))
+
+
+def _fast_modulus(N, p):
+    return p >= 2 and (p <= 65536 if p & (p - 1) == 0 else N * (p - 1) * (p - 1) < 65536)
+
+
+def _is_I(b, p):
+    N = len(b) - 1
+    return N >= 1 and b[0] % p == 1 and b[N] % p == p - 1 and all(x % p == 0 for x in b[1:N])
+
+
+def _raise_status(st):
+    if st:
+        raise ReferenceError_(GENERIC_ERRORS[int(st)])
+
+
+def modInverse(a, p):
+    """index.js:224-232 (brute force, like the reference; None when there is no inverse)"""
+    a = ((_js_mod(a, p)) + p) % p
+    for x in range(1, p):
+        if (a * x) % p == 1:
+            return x
+    return None
+
+
+def subtractPolynomials(a, b, p):
+    """index.js:247-256"""
+    n = max(len(a), len(b))
+    return trimPolynomial([((a[i] if i < len(a) else 0) - (b[i] if i < len(b) else 0)) % p for i in range(n)])
+
+
+def multiplyPolynomialsByScalar(poly, scalar, p):
+    """index.js:404-406: no normalisation (JS `%` keeps the sign), no trimming"""
+    return [_js_mod(c * scalar, p) for c in poly]
+
+
+def bigintToBits(value):
+    """index.js:558-566: least significant bit first, [] for 0"""
+    bits = []
+    while value > 0:
+        bits.append(value & 1)
+        value >>= 1
+    return bits
+
+
+def bitsToBigInt(bits):
+    """index.js:568-570: BigInt('0b' + bits.join(''))"""
+    return int("".join(str(b) for b in bits), 2)
+
+
 def multiplyPolynomials(a, b, p, engine=None):
     """index.js:319-355: linear product, each coefficient in [0,p), trailing zeros trimmed.
 
     Runs on the GPU as one polymul-split in a ring large enough to hold both operands; the linear
-    product is recovered from (quotient, remainder): c[N+k] = -quot[k], c[k] = rem[k] - c[N+k]."""
+    product is recovered from (quotient, remainder): c[N+k] = -quot[k], c[k] = rem[k] - c[N+k].  Moduli the packed
+    kernels do not take (above 65536: test/circuits.test.js:72 uses 2^20) run on the generic family."""
     if len(a) == 0 or len(b) == 0:
         return [0]
     eng = engine or default_engine()
     N = max(len(a), len(b), 2)
+    if not _fast_modulus(N, p):
+        return eng.generic_multiply(list(a), list(b), p)[0]
     ar = np.array([x % p for x in expandArray(a, N)], dtype=np.int64)
     br = np.array([x % p for x in expandArray(b, N)], dtype=np.int64)
     quot, rem = eng.polymul_split(N, p, ar.astype(np.uint16), br.astype(np.uint16))
@@ -108,23 +170,52 @@ def multiplyPolynomials(a, b, p, engine=None):
 
 
 def dividePolynomials(a, b, p, engine=None):
-    """index.js:358-401 for the hot path's only divisor, b = I = [1, 0, ..., 0, -1] (or mod-1 as the last entry).
-
-    Inside encrypt/decrypt/verify the split is fused into the product kernel; a stand-alone call runs the
-    elementwise split kernel (ntru_split_by_I).  Only trimming happens on the host."""
-    N = len(b) - 1
-    if N < 1 or b[0] % p != 1 or any(x % p != 0 for x in b[1:N]) or (b[N] % p) != p - 1:
-        raise NotImplementedError("the HIP engine only divides by I = 1 - x^N (generic long division is "
-                                  "key-generation code, out of scope: SURVEY.md section 8f)")
-    if len(a) > 2 * N:
-        raise NotImplementedError("dividend longer than 2N")
-    if any(x < 0 or x >= p for x in a):
-        raise NotImplementedError("dividend must already be reduced into [0, mod)")
+    """index.js:358-401.  The hot path's divisor b = I = [1, 0, ..., 0, -1] with a reduced dividend runs the elementwise
+    split kernel (ntru_split_by_I; inside encrypt/decrypt/verify the split is fused into the product kernel); any other
+    divisor is long division on the generic family, errors included."""
+    if degree(b) == -1:
+        raise ReferenceError_("Cannot divide by zero polynomial.")
     eng = engine or default_engine()
+    N = len(b) - 1
+    if not (2 <= p <= 65536 and _is_I(b, p) and len(a) <= 2 * N and all(0 <= x < p for x in a)):
+        quot, rem, st = eng.generic_divide(list(a), list(b), p)
+        _raise_status(st[0])
+        return {"quotient": quot[0], "remainder": rem[0]}
     quot, rem = eng.split_by_I(N, p, [expandArray(a, 2 * N)])
     nq = max(len(a) - N, 0)
     quotient = trimPolynomial(quot[0].tolist()[:nq]) if nq else [0]
     return {"quotient": quotient, "remainder": trimPolynomial(rem[0].tolist())}
+
+
+def extendedEuclideanAlgorithm(a, b, p, engine=None):
+    """index.js:425-459 -> {'gcd', 'inverse'}"""
+    eng = engine or default_engine()
+    gcd, inv, st = eng.generic_eea(list(a), list(b), p)
+    _raise_status(st[0])
+    return {"gcd": gcd[0], "inverse": inv[0]}
+
+
+def polyInv(polyIn, polyI, polyMod, engine=None):
+    """index.js:491-514.  Ternary f, polyI = 1 - x^N and modulus 3 or a power of two take the batched inversion kernels
+    (the inverse of a unit is unique); everything else, and every f those kernels flag, runs the reference's own sequence
+    on the generic family."""
+    eng = engine or default_engine()
+    N = len(polyI) - 1
+    pow2 = 2 <= polyMod <= 65536 and polyMod & (polyMod - 1) == 0
+    if (len(polyIn) <= N and all(x in (-1, 0, 1) for x in polyIn) and 2 <= N and eng.supports(N, 2) and
+            (polyMod == 3 or pow2) and polyI[0] == 1 and polyI[N] == -1 and all(x == 0 for x in polyI[1:N])):
+        f = [expandArray(list(polyIn), N)]
+        if polyMod == 3:
+            _, fp, flags = eng.invert_key_batch(N, 2, 3, f, want_fq=False)
+            if not int(flags[0]) & FLAG_NOT_UNIT_MODP:
+                return trimPolynomial(fp[0].tolist())
+        else:
+            fq, _, flags = eng.invert_key_batch(N, polyMod, 3, f, want_fp=False)
+            if not int(flags[0]) & FLAG_NOT_UNIT_MOD2:
+                return trimPolynomial(fq[0].tolist())
+    inv, st = eng.generic_poly_inv(list(polyIn), list(polyI), polyMod)
+    _raise_status(st[0])
+    return inv[0]
 
 
 def addCiphertexts(e1, e2, q, engine=None):
@@ -193,9 +284,16 @@ class NTRU:
             r = generateCustomArray(N, self.dr, self.dr)
         r = [p - 1 if x == -1 else x for x in r]                                     # :89
         m_pad, h_pad = expandArray(m, N), expandArray(self.h, N)
-        if any((not 0 <= x <= 255) for x in m_pad):
-            raise ValueError("plaintext coefficients must be in 0..255")
-        e, quot = self.engine.encrypt_batch(N, q, h_pad, [r], [m_pad], want_quot=True)
+        # addPolynomials(m, rhq, q) reduces any integer m[i] modulo q (index.js:91, :241); the device adds a byte
+        m_dev = [x % q for x in m_pad]
+        if q > 256 and any(x > 255 for x in m_dev):       # does not fit the byte operand: the three steps separately
+            rhqm = addPolynomials(m, multiplyPolynomials(r, self.h, q, self.engine), q)
+            d = dividePolynomials(rhqm, self.I, q, self.engine)
+            return {"value": trimPolynomial(d["remainder"]),
+                    "inputs": {"r": r, "m": m_pad, "h": h_pad, "quotientE": expandArray(d["quotient"], N + 1),
+                               "remainderE": expandArray(d["remainder"], N + 1)},
+                    "params": [q, self.calculateNq(), N]}
+        e, quot = self.engine.encrypt_batch(N, q, h_pad, [r], [m_dev], want_quot=True)
         e, quot = e[0].tolist(), quot[0].tolist()
         return {
             "value": trimPolynomial(e),
@@ -228,24 +326,44 @@ class NTRU:
 
     # -- loadPrivateKeyF, index.js:30-49 -------------------------------------------------------------------
     def loadPrivateKeyF(self, fArr):
-        """fq = f^-1 mod q, fp = f^-1 mod p on the device.  For f that is not a unit this raises 'invalid_gcd' (the
-        reference throws that or 'invalid fq' for most such f and accepts a few through its `&&` checks)."""
-        from .engine import FLAG_NOT_UNIT_MOD2, FLAG_NOT_UNIT_MODP
-        fq, fp, flags = self.engine.invert_key_batch(self.N, self.q, self.p, [expandArray(list(fArr), self.N)])
-        if int(flags[0]) & (FLAG_NOT_UNIT_MOD2 | FLAG_NOT_UNIT_MODP):
-            raise ValueError("invalid_gcd")
-        self.f = list(fArr)
-        self.fq, self.fp = trimPolynomial(fq[0].tolist()), trimPolynomial(fp[0].tolist())
+        """fq = f^-1 mod q, fp = f^-1 mod p.  Units take the batched inversion kernels (unique inverses = the reference's,
+        its validity checks pass by construction); an f those kernels flag runs the reference's own sequence on the
+        generic family: same assignments in the same order, same errors, same acceptance of the non-units its `&&`
+        checks let through (index.js:41-45, :451)."""
+        N, q, p = self.N, self.q, self.p
+        fArr = list(fArr)
+        if (len(fArr) <= N and all(x in (-1, 0, 1) for x in fArr) and p == 3 and q & (q - 1) == 0 and
+                self.engine.supports(N, q)):
+            fq, fp, flags = self.engine.invert_key_batch(N, q, p, [expandArray(fArr, N)])
+            if not int(flags[0]) & (FLAG_NOT_UNIT_MOD2 | FLAG_NOT_UNIT_MODP):
+                self.f = fArr
+                self.fq, self.fp = trimPolynomial(fq[0].tolist()), trimPolynomial(fp[0].tolist())
+                return True
+        self.f = fArr
+        self.fq = polyInv(self.f, self.I, q, self.engine)
+        self.fp = polyInv(self.f, self.I, p, self.engine)
+        fmodq = [q - 1 if x == -1 else x for x in self.f]
+        fmodp = [p - 1 if x == -1 else x for x in self.f]
+        rem = dividePolynomials(multiplyPolynomials(self.fq, fmodq, q, self.engine), self.I, q, self.engine)["remainder"]
+        if len(rem) != 1 and rem[0] != 1:
+            raise ReferenceError_("invalid fq")
+        rem = dividePolynomials(multiplyPolynomials(self.fp, fmodp, p, self.engine), self.I, p, self.engine)["remainder"]
+        if len(rem) != 1 and rem[0] != 1:
+            raise ReferenceError_("invalid fp")
         return True
 
     def generatePrivateKeyF(self, max_tries=100):
-        """index.js:51-65: draw f with df ones and df - 1 minus ones until it is invertible."""
-        for _ in range(max_tries):
+        """index.js:51-65: draw f with df ones and df - 1 minus ones until it is invertible.  Only the reference's own
+        errors mean "next f"; an engine or GPU failure propagates."""
+        i, retval = 0, None
+        while (not retval or not (self.fq and self.fp)) and i < max_tries:
+            i += 1
             try:
-                return self.loadPrivateKeyF(generateCustomArray(self.N, self.df, self.df - 1))
-            except ValueError:
-                continue
-        raise ValueError("Could not find invertible f")
+                retval = self.loadPrivateKeyF(generateCustomArray(self.N, self.df, self.df - 1))
+            except ReferenceError_:
+                pass
+        if not self.fq or not self.fp:
+            raise ValueError("Could not find invertible f")
 
     def generateNewPublicKeyGH(self):                                       # index.js:67-70
         self.g = generateCustomArray(self.N, self.dg, self.dg)

@@ -2,6 +2,9 @@
 SURVEY.md 8(f) #1.  Nothing under ntru-circom_amd/ may import this.
 
 Follows index.js:
+  modInverse / subtractPolynomials / multiplyPolynomialsByScalar / multiplyPolynomials (exact) / dividePolynomials
+                              :224-232, :247-256, :404-406, :319-355, :358-401  -- pinned one by one by
+                              tests/test_oracle_golden.py against tests/golden/generic_functions.json
   extendedEuclideanAlgorithm  :425-459   (with dividePolynomials :358-401, subtractPolynomials :247-257)
   polyInv                     :491-514   (EEA mod 2 + `exponent - 1` rounds of v <- 2v - f v^2 for a power of two,
                                           plain EEA for a prime)
@@ -27,12 +30,17 @@ def _trim(a):
 
 
 def _mod_inverse(a, p):
-    """index.js:224-232: brute force over 1..p-1 on the normalised residue; None if there is none."""
+    """index.js:224-232: the smallest x in 1..p-1 with (a * x) % p == 1 on the normalised residue, None if there is
+    none.  The reference searches x upwards; an inverse modulo p is unique in that range, so for large p (2^20) the
+    search is replaced by the integer Euclidean algorithm -- same value, pinned by the modInverse vectors."""
     a = ((int(a) % p) + p) % p
-    for x in range(1, p):
-        if (a * x) % p == 1:
-            return x
-    return None
+    if p <= 4096:
+        for x in range(1, p):
+            if (a * x) % p == 1:
+                return x
+        return None
+    import math
+    return pow(a, -1, p) if a and math.gcd(a, p) == 1 else None
 
 
 def _divide(a, b, p):
@@ -71,28 +79,34 @@ def _subtract(a, b, p):
     return _trim((np.fmod(x - y, p) + p) % p)
 
 
-def extended_euclid(a, b, p):
-    """extendedEuclideanAlgorithm(a, b, p) -> inverse of a modulo b (index.js:425-459), quirks included."""
+def extended_euclid(a, b, p, want_gcd=False):
+    """extendedEuclideanAlgorithm(a, b, p) -> inverse of a modulo b (index.js:425-459), quirks included;
+    (gcd, inverse) with want_gcd."""
     r0, r1 = np.array(a, dtype=np.int64), np.array(b, dtype=np.int64)
     s0, s1 = np.array([1], np.int64), np.array([0], np.int64)
     while _deg(r1) >= 0:
         quotient, remainder = _divide(r0, r1, p)
         r0, r1 = r1, remainder
         s0, s1 = s1, _subtract(s0, _multiply(quotient, s1, p), p)
-    lead = r0[_deg(r0)]
-    inv_lead = _mod_inverse(lead, p)
+    inv_lead = _mod_inverse(r0[_deg(r0)], p) if _deg(r0) >= 0 else None      # modInverse(undefined) is null
+
     if inv_lead is not None and inv_lead != 1:
         r0 = np.fmod(r0 * inv_lead, p)
         s0 = np.fmod(s0 * inv_lead, p)
-    if len(r0) != 1 and r0[0] != 1:                              # the reference's `&&` (index.js:451)
+    if len(r0) != 1 and (len(r0) == 0 or r0[0] != 1):            # the reference's `&&` (index.js:451)
         raise InvalidGcd("invalid_gcd")
-    return s0
+    return (r0, s0) if want_gcd else s0
 
 
-def poly_inv(f, N, mod):
-    """polyInv(f, I, mod) with I = 1 - x^N as the reference builds it (index.js:25-27): [1, 0, ..., 0, -1]."""
+def scale(poly, s, p):
+    """multiplyPolynomialsByScalar (index.js:404-406): JS `%`, no normalisation, no trimming."""
+    return np.fmod(np.asarray(poly, np.int64) * s, p)
+
+
+def poly_inv_generic(f, poly_i, mod):
+    """polyInv(f, polyI, mod) for ANY modulus polynomial (index.js:491-514)."""
     f = np.asarray(f, np.int64)
-    I = np.zeros(N + 1, np.int64); I[0] = 1; I[N] = -1
+    I = np.asarray(poly_i, np.int64)
     e = np.log2(mod)
     if round(e) == e:
         inverse = extended_euclid(f, I, 2)
@@ -104,6 +118,12 @@ def poly_inv(f, N, mod):
             inverse = _trim(rem)
         return inverse
     return extended_euclid(f, I, mod)
+
+
+def poly_inv(f, N, mod):
+    """polyInv(f, I, mod) with I = 1 - x^N as the reference builds it (index.js:25-27): [1, 0, ..., 0, -1]."""
+    I = np.zeros(N + 1, np.int64); I[0] = 1; I[N] = -1
+    return poly_inv_generic(f, I, mod)
 
 
 def load_private_key(f, N, q, p):

@@ -70,16 +70,12 @@ def test_string_round_trip_like_reference_test(eng, scheme_golden):
 
 
 def test_pure_functions_equal_reference(eng, pure_golden):
-    n_dev = 0
-    for v in pure_golden["multiply"]:
-        N = max(len(v["a"]), len(v["b"]), 2)
-        if len(v["a"]) and len(v["b"]) and not eng.supports(N, v["p"]):
-            with pytest.raises(pkg.EngineError):
-                pkg.multiplyPolynomials(v["a"], v["b"], v["p"], engine=eng)
-            continue
+    n_dev = n_big = 0
+    for v in pure_golden["multiply"]:                    # incl. the 2^20 products of test/circuits.test.js:60-72
         assert pkg.multiplyPolynomials(v["a"], v["b"], v["p"], engine=eng) == v["out"]
         n_dev += 1
-    assert n_dev >= 25
+        n_big += v["p"] > 65536
+    assert n_dev >= 31 and n_big >= 6
     n_div = 0
     for v in pure_golden["divide"]:
         if "N" not in v:
@@ -87,8 +83,96 @@ def test_pure_functions_equal_reference(eng, pure_golden):
         assert pkg.dividePolynomials(v["a"], v["b"], v["p"], engine=eng) == v["out"]
         n_div += 1
     assert n_div >= 60
-    with pytest.raises(NotImplementedError):
-        pkg.dividePolynomials([81, 2, 96], [48, 2, 31], 128, engine=eng)
+    for v in pure_golden["divide"]:                      # the generic divisors of test/circuits.test.js:165-170
+        if "N" in v:
+            continue
+        if v.get("error"):
+            with pytest.raises(ValueError, match=v["error"].replace(".", r"\.")):
+                pkg.dividePolynomials(v["a"], v["b"], v["p"], engine=eng)
+        else:
+            assert pkg.dividePolynomials(v["a"], v["b"], v["p"], engine=eng) == v["out"]
+
+
+# ---- the generic family (ntru_generic_*): the reference's own algorithms, quirks and errors included -----------------
+
+def _outcome(fn):
+    try:
+        return {"out": fn()}
+    except ValueError as e:                                # ntru.ReferenceError_: str(e) is the reference's message
+        return {"error": str(e)}
+
+
+def _want(c):
+    return {k: c[k] for k in ("out", "error") if k in c}
+
+
+def test_generic_exports_equal_reference(eng):
+    from ntru_circom_amd import ntru as host
+    with open(os.path.join(ge.ROOT, "tests", "golden", "generic_functions.json")) as fh:
+        g = json.load(fh)
+    for c in g["modInverse"]:
+        assert host.modInverse(c["a"], c["p"]) == c["out"]
+    for c in g["subtract"]:
+        assert host.subtractPolynomials(c["a"], c["b"], c["p"]) == c["out"]
+    for c in g["scalar"]:
+        assert host.multiplyPolynomialsByScalar(c["a"], c["s"], c["p"]) == c["out"]
+    for c in g["bigintToBits"]:
+        assert host.bigintToBits(int(c["v"])) == c["out"]
+    for c in g["bitsToBigInt"]:
+        assert str(host.bitsToBigInt(c["bits"])) == c["out"]
+    for c in g["multiply"]:
+        assert host.multiplyPolynomials(c["a"], c["b"], c["p"], engine=eng) == c["out"]
+    for c in g["divide"]:
+        assert _outcome(lambda: host.dividePolynomials(c["a"], c["b"], c["p"], engine=eng)) == _want(c), c
+    assert g["eea"][0]["out"] == {"gcd": [1], "inverse": [5, 8]}           # index.js:411-423
+    for c in g["eea"]:
+        assert _outcome(lambda: host.extendedEuclideanAlgorithm(c["a"], c["b"], c["p"], engine=eng)) == _want(c), c
+    for c in g["polyInv"]:
+        assert _outcome(lambda: host.polyInv(c["f"], c["I"], c["mod"], engine=eng)) == _want(c), c
+
+
+def test_generic_family_batches_equal_oracle(eng):
+    """Whole batches per launch (uniform lengths), against the Python restatement: long division and EEA with signed,
+    unreduced operands; polyInv at a real key size; a 2^20-modulus product at N = 701."""
+    from oracle import ntru_keygen as kg
+    rng = np.random.default_rng(99)
+    for p, la, lb, B in ((7, 30, 11, 70), (4096, 50, 20, 33), (2, 40, 41, 65), (1048576, 12, 5, 9)):
+        a = rng.integers(-p, 2 * p, (B, la)); b = rng.integers(0, p, (B, lb))
+        b[:, -1] = rng.integers(0, 2, B)                   # some leading coefficients vanish, some lack an inverse
+        quot, rem, st = eng.generic_divide(a, b, p)
+        gcd, inv, st2 = eng.generic_eea(a, b, p)
+        for i in range(B):
+            try:
+                qo, ro = kg._divide(a[i], b[i], p)
+                assert st[i] == 0 and quot[i] == qo.tolist() and rem[i] == ro.tolist()
+            except ZeroDivisionError:
+                assert st[i] == 1
+            except ArithmeticError:
+                assert st[i] == 2
+            try:
+                go, io = kg.extended_euclid(a[i], b[i], p, True)
+                assert st2[i] == 0 and gcd[i] == go.tolist() and inv[i] == io.tolist()
+            except kg.InvalidGcd:
+                assert st2[i] == 3
+            except ZeroDivisionError:
+                assert st2[i] == 1
+            except ArithmeticError:
+                assert st2[i] == 2
+    a = rng.integers(0, 1 << 20, (3, 701)); b = rng.integers(0, 1 << 20, (3, 701))
+    prod = eng.generic_multiply(a, b, 1 << 20)
+    for i in range(3):
+        assert prod[i] == kg._multiply(a[i], b[i], 1 << 20).tolist()
+    N = 167
+    I = [1] + [0] * (N - 1) + [-1]
+    f = rng.integers(-1, 2, (4, N))
+    for mod in (3, 128):
+        inv, st = eng.generic_poly_inv(f, np.tile(I, (4, 1)), mod)
+        for i in range(4):
+            try:
+                want = kg.poly_inv_generic(f[i], I, mod).tolist()
+                assert st[i] == 0 and inv[i] == want
+            except kg.InvalidGcd:
+                assert st[i] == 3
 
 
 # ---- random batches against the oracle, fixed-stride layout ----------------------------------------------------
@@ -404,7 +488,7 @@ def test_fresh_key_round_trip_like_reference_test(eng):
 
 def test_key_inversion_captured_cases_and_random_keys(eng):
     """tests/golden/keygen_cases.json: for every f that IS a unit mod 2 and mod 3 the device equals the reference; for the
-    others the matching flag is set (the reference throws for most of them and accepts some: documented deviation).
+    others the matching flag is set (the host mirrors then run the reference's own sequence on the generic family).
     Random keys at BASELINE sizes: f * fq = 1 mod q and f * fp = 1 mod p through the product entry point."""
     from oracle import ntru_keygen as kg
     with open(os.path.join(os.path.dirname(__file__), "golden", "keygen_cases.json")) as fh:
@@ -442,6 +526,27 @@ def test_key_inversion_captured_cases_and_random_keys(eng):
         assert all(np.array_equal(rem[i], one) for i in range(B) if ok[i])
         _, rem3 = orc.polymul_split_batch(N, 3, f % 3, fp)
         assert all(np.array_equal(rem3[i], one) for i in range(B) if ok[i])
+
+
+def test_load_private_key_equals_reference_on_every_captured_f(eng):
+    """loadPrivateKeyF through the host mirror on all 123 captured f (tests/golden/keygen_cases.json): the reference's fq
+    and fp where it returns, its message where it throws -- including the non-units its `&&` checks accept, which the
+    inversion kernels flag and the generic family then reproduces step by step."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "keygen_cases.json")) as fh:
+        cases = json.load(fh)["cases"]
+    n_ok = n_err = 0
+    for c in cases:
+        n = pkg.NTRU(dict(N=c["N"], q=c["q"], p=c["p"]), engine=eng)
+        if "error" in c:
+            with pytest.raises(ValueError) as ei:
+                n.loadPrivateKeyF(c["f"])
+            assert str(ei.value) == c["error"] and n.f == c["f"]       # index.js:33 assigns f before anything can throw
+            n_err += 1
+        else:
+            assert n.loadPrivateKeyF(c["f"]) is True
+            assert n.fq == c["fq"] and n.fp == c["fp"], c["f"]
+            n_ok += 1
+    assert n_ok >= 60 and n_err >= 40
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 6, 7, 8, 13, 29, 257])

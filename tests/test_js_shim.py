@@ -20,8 +20,10 @@ def test_addon_builds_loads_and_fails_loudly_without_gpu():
     ge.build()
     assert os.path.exists(os.path.join(JS, "ntru_addon.node"))
     code = ("import NTRU, * as lib from '../../ntru-circom_amd/js/index.mjs';"
-            "const names=['degree','trimPolynomial','addPolynomials','multiplyPolynomials','dividePolynomials',"
-            "'expandArray','expandArrayToMultiple','generateCustomArray','stringToBits','bitsToString'];"
+            "const names=['degree','trimPolynomial','modInverse','addPolynomials','subtractPolynomials','multiplyPolynomials',"
+            "'dividePolynomials','multiplyPolynomialsByScalar','extendedEuclideanAlgorithm','generateCustomArray','polyInv',"
+            "'expandArrayToMultiple','expandArray','stringToBits','bitsToString','bigintToBits','bitsToBigInt','packOutput',"
+            "'unpackInput'];"     # the reference's 19 named exports (index.js:210-598)
             "for (const n of names) if (typeof lib[n] !== 'function') throw new Error('missing export '+n);"
             "const n = new NTRU({N:17,q:32,dr:2,h:[1,2,3]});"
             "if (n.I.length !== 18 || n.I[17] !== -1 || n.calculateNq() !== 15) throw new Error('ctor');"
@@ -46,3 +48,26 @@ def test_shim_reproduces_reference_witnesses():
     r = _node([os.path.join(ge.ROOT, "tests", "js", "shim_golden.mjs")])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "shim_golden:" in r.stdout
+
+
+# test/reference.test.js:6-61: each scenario in a FRESH node process, key generation as its first engine call
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+@pytest.mark.parametrize("scenario", ["roundtrip", "wrongkey", "large", "homomorphic", "firstcall-loadPrivateKeyF",
+                                      "firstcall-generatePublicKeyH", "firstcall-polyInv", "firstcall-allocUint16"])
+def test_reference_scenarios_in_fresh_processes(scenario):
+    ge.build()
+    r = _node([os.path.join(ge.ROOT, "tests", "js", "ref_scenarios.mjs"), scenario])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ref_scenarios: %s OK" % scenario in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_generic_exports_reproduce_reference():
+    """polyInv, extendedEuclideanAlgorithm, generic dividePolynomials, products modulo 2^20, the O(N) helpers and
+    loadPrivateKeyF on non-units against vectors captured from the reference (generic_functions.json, keygen_cases.json)."""
+    ge.build()
+    r = _node([os.path.join(ge.ROOT, "tests", "js", "shim_generic.mjs")])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "shim_generic:" in r.stdout

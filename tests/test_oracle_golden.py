@@ -246,3 +246,57 @@ def test_key_inversion_failing_and_quirky_cases():
             assert got == (pad(c["fq"]), pad(c["fp"]))
             n_quirk += not (kg.is_unit(f, N, 2) and kg.is_unit(f, N, 3))
     assert n_err >= 40 and n_quirk >= 30
+
+
+# ---- the reference's generic helpers (modInverse, subtract, scalar, long division, EEA, polyInv, products with large
+#      moduli): oracle/ntru_keygen.py against tests/golden/generic_functions.json (gen_generic_cases.mjs) --------------
+
+def _generic_golden():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "generic_functions.json")) as fh:
+        return json.load(fh)
+
+
+def _oracle_outcome(fn):
+    from oracle import ntru_keygen as kg
+    try:
+        return {"out": fn()}
+    except kg.InvalidGcd:
+        return {"error": "invalid_gcd"}
+    except ZeroDivisionError as e:
+        return {"error": str(e)}
+    except ArithmeticError as e:
+        return {"error": str(e)}
+
+
+def test_generic_helpers_equal_reference():
+    from oracle import ntru_keygen as kg
+    g = _generic_golden()
+    for c in g["modInverse"]:
+        assert kg._mod_inverse(c["a"], c["p"]) == c["out"]
+    for c in g["subtract"]:
+        assert kg._subtract(c["a"], c["b"], c["p"]).tolist() == c["out"]
+    for c in g["scalar"]:
+        assert kg.scale(c["a"], c["s"], c["p"]).tolist() == c["out"]
+    for c in g["multiply"]:
+        assert kg._multiply(c["a"], c["b"], c["p"]).tolist() == c["out"]
+    n_err = 0
+    for c in g["divide"]:
+        got = _oracle_outcome(lambda: dict(zip(("quotient", "remainder"), (x.tolist() for x in kg._divide(c["a"], c["b"], c["p"])))))
+        assert got == {k: c[k] for k in ("out", "error") if k in c}
+        n_err += "error" in c
+    assert n_err >= 5
+
+
+def test_generic_eea_and_polyinv_equal_reference():
+    from oracle import ntru_keygen as kg
+    g = _generic_golden()
+    assert g["eea"][0]["out"] == {"gcd": [1], "inverse": [5, 8]}           # the worked example of index.js:411-423
+    for c in g["eea"]:
+        got = _oracle_outcome(lambda: dict(zip(("gcd", "inverse"), (x.tolist() for x in kg.extended_euclid(c["a"], c["b"], c["p"], True)))))
+        assert got == {k: c[k] for k in ("out", "error") if k in c}
+    n_err = 0
+    for c in g["polyInv"]:
+        got = _oracle_outcome(lambda: kg.poly_inv_generic(c["f"], c["I"], c["mod"]).tolist())
+        assert got == {k: c[k] for k in ("out", "error") if k in c}, c
+        n_err += "error" in c
+    assert n_err >= 5
