@@ -52,6 +52,10 @@ def parse_args():
                     help="draw r with the engine's on-device sampler (generateCustomArray on a ChaCha20 stream) "
                          "instead of torch; the timed region is unchanged")
     ap.add_argument("--gather", action="store_true", help="after timing, all_gather the decrypted values (RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the timing all_reduce / barrier / gather even with ONE rank "
+                         "(RCCL refuses two ranks on one device, so this is how the RCCL code path is exercised on a 1-GPU box)")
+    ap.add_argument("--check-rows", type=int, default=1 << 14, help="rows of the batch verified against the CPU oracle")
     return ap.parse_args()
 
 
@@ -86,16 +90,35 @@ def make_inputs(torch, dev, B, N, d, seed, ld=None):
     return r, m
 
 
+def engine_source_hash():
+    """sha256 over the engine's sources: ties a PMC summary to the build it was measured on (tools/pmc_summary.py stamps
+    the same value; .git does not travel to the GPU box, the sources do)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ntru-circom_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, mode, batch_log2):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_hbm_latest.json:
-    2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950), or None if not collected for it."""
+    """(HBM bytes per launch of `kernel`, note) from the committed rocprofv3 PMC passes (profiles/pmc_hbm_latest.json:
+    2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  Counters need their own rocprofv3 passes, so
+    they cannot be collected inside this run; the summary carries the hash of the sources it was measured on and is only
+    served when that is the build being benchmarked -- otherwise traffic is null."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")) as fh:
             d = json.load(fh)
         k = d["kernels"].get(kernel)
-        return k["hbm_bytes_per_launch"] if k and d.get("mode") == mode and d.get("batch_log2") == batch_log2 else None
+        if not k or d.get("mode") != mode or d.get("batch_log2") != batch_log2:
+            return None, "no PMC pass on record for this kernel / mode / batch"
+        if d.get("engine_source_sha256") != engine_source_hash():
+            return None, "profiles/pmc_hbm_latest.json (%s) was measured on other engine sources: stale, not served" % d.get("tag")
+        return k["hbm_bytes_per_launch"], "rocprofv3 PMC passes %s on these sources (git %s)" % (d.get("tag"), d.get("git_sha"))
     except (OSError, ValueError, KeyError):
-        return None
+        return None, "profiles/pmc_hbm_latest.json missing or unreadable"
 
 
 def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
@@ -114,7 +137,21 @@ def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
     faithful = {"value": n / dt, "unit": "round_trips/s", "cores": 1, "kind": "port",
                 "sample": "%d round trips of the same workload, oracle in reference-equivalent mode (double FFT "
                           "product + long division with per-step brute-force inverse), %.1f s" % (n, dt)}
-    threads = max(1, min(16, os.cpu_count() or 1))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))                          # the GPU box's CPU share for one GPU is 16
+    # the same reference-equivalent algorithm on every core we may use ("single thread and all cores")
+    per_thread = int(max(4, min(len(r) // threads, (seconds / 2) * faithful["value"])))
+    ths = [threading.Thread(target=rt, args=(slice(i * per_thread, (i + 1) * per_thread), orc.FAITHFUL))
+           for i in range(threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]; [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    faithful_all = {"value": threads * per_thread / dt, "unit": "round_trips/s", "cores": threads, "kind": "port",
+                    "sample": "%d round trips, oracle in reference-equivalent mode, %d threads (host has %d usable), %.1f s"
+                              % (threads * per_thread, threads, avail, dt)}
     t0 = time.perf_counter(); rt(slice(0, 8), orc.EXACT); per = (time.perf_counter() - t0) / 8
     per_thread = int(max(8, min(len(r) // threads, (seconds / 3) / max(per, 1e-9))))
     ths = [threading.Thread(target=rt, args=(slice(i * per_thread, (i + 1) * per_thread), orc.EXACT))
@@ -125,7 +162,7 @@ def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
     optimized = {"value": threads * per_thread / dt, "unit": "round_trips/s", "cores": threads, "kind": "port",
                  "sample": "%d round trips, oracle in exact-integer mode (schoolbook + closed-form split), "
                            "%d threads, %.1f s" % (threads * per_thread, threads, dt)}
-    return faithful, optimized
+    return faithful, faithful_all, optimized
 
 
 def main():
@@ -143,8 +180,11 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -202,20 +242,37 @@ def main():
         for k in range(args.steps):
             step(events[k])
 
-    elapsed = sh.timed_region(run_steps, torch.cuda.synchronize, dist, red_dev)
+    elapsed = sh.timed_region(run_steps, torch.cuda.synchronize, dist, red_dev, always=args.force_dist)
     enc_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events]))
     dec_ms = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in events]))
 
-    # ---- bit-exact check of a sample against the CPU oracle (outside the timed region) --------------------
+    # ---- bit-exact check of a strided sample against the CPU oracle (outside the timed region): every output array ---
     from oracle import ntru_oracle as orc
-    rows = torch.tensor(sorted(set(list(range(0, B, max(1, B // 48))) + [B - 1])), device=dev)
+    n_chk = max(1, min(B, args.check_rows))
+    rows = torch.tensor(sorted(set(list(range(0, B, max(1, B // n_chk))) + [B - 1])), device=dev)
     host = lambda t: (lambda a: a.view(np.uint16) if a.dtype == np.int16 else a)(t[rows][:, :N].contiguous().cpu().numpy())
-    e_o, qe_o = orc.encrypt_batch(N, q, h_np, host(r), host(m))
-    v_o, q1_o, r1_o, q2_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)
-    ok = np.array_equal(host(e), e_o) and np.array_equal(host(value), v_o)
+    r_h, m_h = host(r), host(m)
+    got = {"e": host(e), "value": host(value)}
     if witness:
-        ok = ok and np.array_equal(host(quotE), qe_o) and np.array_equal(host(quot1), q1_o) \
-            and np.array_equal(host(rem1), r1_o) and np.array_equal(host(quot2), q2_o)
+        got.update(quotE=host(quotE), quot1=host(quot1), rem1=host(rem1), quot2=host(quot2))
+    try:
+        n_thr = max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        n_thr = max(1, min(16, os.cpu_count() or 1))
+    bad = []
+
+    def check(lo, hi):
+        e_o, qe_o = orc.encrypt_batch(N, q, h_np, r_h[lo:hi], m_h[lo:hi])
+        v_o, q1_o, r1_o, q2_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)
+        want = {"e": e_o, "value": v_o, "quotE": qe_o, "quot1": q1_o, "rem1": r1_o, "quot2": q2_o}
+        for k, a in got.items():
+            if not np.array_equal(a[lo:hi], want[k]):
+                bad.append(k)
+
+    cuts = np.linspace(0, len(r_h), n_thr + 1).astype(int)
+    ths = [threading.Thread(target=check, args=(int(cuts[i]), int(cuts[i + 1]))) for i in range(n_thr) if cuts[i] < cuts[i + 1]]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    ok = not bad
     ablation = bool(os.environ.get("NTRU_ENGINE_LIB")) and os.environ.get("NTRU_BENCH_ABLATION") == "1"
     if not ok and not ablation:
         raise SystemExit("bench: GPU results differ from the oracle -- refusing to report a number")
@@ -223,9 +280,11 @@ def main():
     gathered = None
     if args.gather and dist:
         torch.cuda.synchronize(); tg = time.perf_counter()
-        allv = sh.gather_rows(value if args.dist_backend == "nccl" else value.cpu(), dist)
+        allv = sh.gather_rows(value if args.dist_backend == "nccl" else value.cpu(), dist, always=args.force_dist)
         torch.cuda.synchronize()
-        gathered = {"rows": int(allv.shape[0]), "bytes_per_rank": int(value.numel()), "seconds": time.perf_counter() - tg}
+        gathered = {"rows": int(allv.shape[0]), "bytes_per_rank": int(value.numel()), "seconds": time.perf_counter() - tg,
+                    "backend": args.dist_backend, "ranks": world,
+                    "rows_equal_local_shard": bool(torch.equal(allv[rank * B:(rank + 1) * B].to(value.device), value))}
 
     if rank == 0:
         total = world * B * args.steps
@@ -235,6 +294,7 @@ def main():
         dec_gbs = dec_bytes * B / (dec_ms * 1e-3) / 1e9
         dec_s = dec_ms * 1e-3
         dname = names.get("decrypt", "k_decrypt")
+        traffic, traffic_note = pmc_traffic(dname, args.mode, args.batch_log2)
         add_path = dname.startswith(("k_decrypt_s", "k_decrypt_t"))
         mfma = None
         if dname == "k_decrypt_m":
@@ -287,9 +347,10 @@ def main():
                        "arithmetic": "int8 digit planes on the matrix cores, int32 accumulation (exact)" if mfma else "exact u16 vector ALU", "seed": 20240, "r_source": "device sampler" if args.sample_r else "torch",
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "verified_bit_exact_rows": int(rows.numel()),
+            "verified_arrays": sorted(got.keys()),
             "kernels_ms": {names.get("encrypt", "k_encrypt"): enc_ms, dname: dec_ms},
             "roofline": {"bound": "hbm", "kernel": dname, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(dname, args.mode, args.batch_log2),
+                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_item": dec_bytes, "algorithmic_bytes_per_launch": dec_bytes * B,
                          "note": ("matrix-core path: HBM traffic and int8 MFMA issue are within a factor of two of each "
                                   "other; the MFMA side is reported in `mfma`") if mfma else
@@ -301,14 +362,17 @@ def main():
         if world == 1 and args.kernel_path == "auto" and names.get("decrypt", "").endswith("_m"):
             # The wavefront-per-ciphertext VALU families (BASELINE north_star's design), same buffers, outside the timed
             # region: a few steps, and their outputs must equal the ones just verified.
-            ref_out = [t[:, :N].clone() for t in (e, value)]
+            cmp_names = ("e", "quotientE", "value", "quotient1", "remainder1", "quotient2") if witness else ("e", "value")
+            cmp_idx = (2, 3, 4, 5, 6, 7) if witness else (2, 4)
+            ref_out = [bufs[i][:, :N].clone() for i in cmp_idx]
             alt = bufs
             if pitched:      # those families read and write dense rows: give them dense copies of the same inputs
                 dense = lambda t: None if t is None else torch.empty((B, N), dtype=t.dtype, device=dev)
                 alt = (r[:, :N].contiguous(), m[:, :N].contiguous()) + tuple(dense(t) for t in bufs[2:])
             eng.set_kernel_path(2)
             step(None, alt, None); torch.cuda.synchronize()
-            same = all(bool(torch.equal(a, b)) for a, b in zip(ref_out, (alt[2], alt[4])))
+            differ = [n for n, a, i in zip(cmp_names, ref_out, cmp_idx) if not bool(torch.equal(a, alt[i][:, :N]))]
+            same = not differ
             alt_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(3)]
             for ev in alt_ev:
                 step(ev, alt, None)
@@ -317,7 +381,8 @@ def main():
             a_dec = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in alt_ev]))
             out["valu_families"] = {"value": B / ((a_enc + a_dec) * 1e-3), "unit": "round_trips/s",
                                     "kernels_ms": {names["encrypt"]: a_enc, names["decrypt"]: a_dec},
-                                    "outputs_equal_matrix_path": same,
+                                    "outputs_equal_matrix_path": same, "arrays_compared_on_whole_batch": list(cmp_names),
+                                    "rows_compared": B,
                                     "note": "ntru_engine_set_kernel_path(2): one ciphertext per wavefront, no MFMA; kernel "
                                             "times only, 3 steps"}
             eng.set_kernel_path(0)
@@ -356,8 +421,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = 4096
             rr, mm = r[:n_cpu, :N].contiguous().cpu().numpy(), m[:n_cpu, :N].contiguous().cpu().numpy()
-            faithful, optimized = cpu_baseline(N, q, p, h_np, f_np, fp_np, rr, mm, args.cpu_seconds)
+            faithful, faithful_all, optimized = cpu_baseline(N, q, p, h_np, f_np, fp_np, rr, mm, args.cpu_seconds)
             out["cpu_baseline"] = faithful
+            out["cpu_baseline_all_cores"] = faithful_all
             out["cpu_baseline_optimized"] = optimized
         print(json.dumps(out), flush=True)
     if dist:

@@ -16,9 +16,15 @@ def shard_seed(base_seed, rank):
     return int(base_seed) + 7919 * int(rank)
 
 
-def max_over_ranks(seconds, dist=None, device=None):
+def _active(dist, always):
+    """Collectives run when there is more than one rank -- or when the caller insists (a one-rank process group still
+    goes through the backend: the only way to execute RCCL on a box with a single GPU)."""
+    return dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or always)
+
+
+def max_over_ranks(seconds, dist=None, device=None, always=False):
     """The slowest rank's elapsed time (the job is done when the last shard is)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(dist, always):
         return float(seconds)
     import torch
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
@@ -26,9 +32,9 @@ def max_over_ranks(seconds, dist=None, device=None):
     return float(t.item())
 
 
-def timed_region(run_steps, sync, dist=None, device=None):
+def timed_region(run_steps, sync, dist=None, device=None, always=False):
     """barrier + sync, run, sync + barrier; returns max-over-ranks seconds (bench.py contract)."""
-    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    multi = _active(dist, always)
     sync()
     if multi:
         dist.barrier()
@@ -39,13 +45,13 @@ def timed_region(run_steps, sync, dist=None, device=None):
     if multi:
         dist.barrier()
     sync()
-    return max_over_ranks(time.perf_counter() - t0, dist, device)
+    return max_over_ranks(time.perf_counter() - t0, dist, device, always)
 
 
-def gather_rows(local, dist):
+def gather_rows(local, dist, always=False):
     """Final gather of per-rank output rows ([b_rank, N] each, equal b_rank) onto every rank, in rank order."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(dist, always):
         return local
     outs = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, local.contiguous())

@@ -867,8 +867,8 @@ def test_full_size_batch_properties(eng, profile, logB):
         assert int(val.max()) <= 2 and int(q2.max()) <= 2 and int(u(r1).max()) < q and int(u(q1).max()) < q
         if q % 3 == 2:   # the reference's lift only round-trips for q = 2 mod 3
             assert torch.equal(val, m1)
-        # a strided sample of rows, all outputs, against the oracle (incl. the last row)
-        rows = torch.tensor(sorted(set(list(range(0, B, B // 61)) + [B - 1])), device=dev)
+        # a strided sample of 4097 rows, all outputs, against the oracle (incl. the last row)
+        rows = torch.tensor(sorted(set(list(range(0, B, B // 4096)) + [B - 1])), device=dev)
         host = lambda t: (lambda a: a.view(np.uint16) if a.dtype == np.int16 else a)(t[rows].cpu().numpy())
         e_o, qe_o = orc.encrypt_batch(N, q, h.cpu().numpy().view(np.uint16), host(r), host(m1))
         assert np.array_equal(host(e1), e_o) and np.array_equal(host(qe1), qe_o)

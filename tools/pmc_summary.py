@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--mode", default="witness")
     ap.add_argument("--N", type=int, default=821)
     ap.add_argument("--logB", type=int, default=20)
+    ap.add_argument("--items", type=int, default=0, help="items per launch when it is not 2^logB (per-item kernels)")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     sdir = os.path.join(ROOT, "gpurun_out", "prof_stats")
@@ -79,7 +80,9 @@ def main():
         for k, v in acc.items():
             kern.setdefault(k, {})[cname + "_KiB_per_launch"] = sum(v) / len(v)
     B = 1 << a.logB
-    per_item = {"k_encrypt": (6, 4), "k_decrypt": (8, 3)}
+    per_item = {"k_encrypt": (6, 4), "k_decrypt": (8, 3), "k_verify_keys": (17, 17), "k_polymul": (8, 8), "k_public_key": (5, 5)}
+    if a.items:
+        B = a.items
     for k, v in kern.items():
         if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
             v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024
@@ -87,7 +90,19 @@ def main():
                 if k.startswith(fam):
                     v["algorithmic_bytes_per_launch"] = (wit if a.mode == "witness" else val) * a.N * B
                     v["ratio_to_algorithmic"] = v["hbm_bytes_per_launch"] / v["algorithmic_bytes_per_launch"]
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    from bench import engine_source_hash
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "ntru-circom_amd/csrc"], capture_output=True,
+                                    text=True).stdout.strip())
+    except OSError:
+        sha, dirty = None, None
     doc = {"tag": a.tag, "mode": a.mode, "N": a.N, "batch_log2": a.logB,
+           "git_sha": (sha + ("+uncommitted csrc changes" if dirty else "")) if sha else None,
+           "engine_source_sha256": engine_source_hash(),
            "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py",
            "kernels": kern}
     for name in (a.tag + "_pmc_hbm.json", "pmc_hbm_latest.json"):
