@@ -40,7 +40,7 @@ def parse_args():
                     help="witness: every array the reference returns; value: ciphertext / plaintext only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix"], default="auto",
+    ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix", "matrix2"], default="auto",
                     help="kernel family: packed-u16 MAC, ternary add path, or the engine's choice (same results)")
     ap.add_argument("--row-pitch", type=int, default=0,
                     help="row pitch of the batch arrays in elements (0 = dense rows of N elements; -1 = N rounded up to "
@@ -218,7 +218,7 @@ def main():
             raise SystemExit("bench: --sample-r writes dense rows; use it with --row-pitch 0")
         eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
         torch.cuda.synchronize()
-    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4}[args.kernel_path])
+    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4, "matrix2": 5}[args.kernel_path])
 
     names = {}
 
@@ -297,7 +297,7 @@ def main():
         traffic, traffic_note = pmc_traffic(dname, args.mode, args.batch_log2)
         add_path = dname.startswith(("k_decrypt_s", "k_decrypt_t"))
         mfma = None
-        if dname == "k_decrypt_m":
+        if dname.startswith("k_decrypt_m"):
             # int8 matrix path: decrypt = 3 plane-products (e_lo, e_hi against f; lifted against fp), each 27 tile
             # products per 32x32 output tile on a 32-padded grid (26 x 26 tiles at N = 821)
             NT = (N + 31) // 32
@@ -359,7 +359,7 @@ def main():
             "mfma": mfma,
             "hbm_gbs_round_trip": (dec_bytes + enc_bytes) * B / ((dec_ms + enc_ms) * 1e-3) / 1e9,
         }
-        if world == 1 and args.kernel_path == "auto" and names.get("decrypt", "").endswith("_m"):
+        if world == 1 and args.kernel_path == "auto" and names.get("decrypt", "").startswith("k_decrypt_m"):
             # The wavefront-per-ciphertext VALU families (BASELINE north_star's design), same buffers, outside the timed
             # region: a few steps, and their outputs must equal the ones just verified.
             cmp_names = ("e", "quotientE", "value", "quotient1", "remainder1", "quotient2") if witness else ("e", "value")

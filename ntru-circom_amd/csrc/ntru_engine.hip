@@ -1868,22 +1868,25 @@ static __device__ __forceinline__ v4i and4(v4i a, const u32 (&m)[4]) {
 
 // One strip of NT_S column tiles starting at tile kb0, all 32 rows of the staged row block.  st0 / st1: this lane's
 // row of the operand stage(s) (+ 16 bytes for the upper half-wave); tb0 / tb1: this lane's fragment bases.
-template <int MODE, int NT_S, class Epi>
+struct NoPause { __device__ __forceinline__ void operator()() const {} };
+// pause / pause_ib: pause() is called exactly once, before the first contraction step ib >= pause_ib is touched (at a
+// block boundary, so possibly a few steps early; after the loops when no such step exists).  The role-split decrypt
+// kernel waits there for the operand columns that are still being produced.
+template <int MODE, int NT_S, class Epi, class Pause = NoPause>
 static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__restrict__ st0,
                                                       const unsigned char *__restrict__ st1,
                                                       const u32 *__restrict__ tb0, const u32 *__restrict__ tb1,
                                                       const MGeom &g, int kb0, const u32 (&mlow)[4], Epi epi,
-                                                      int stamp_iter = 0, int stamp_base = 0) {
+                                                      int stamp_iter = 0, int stamp_base = 0, int pause_ib = 0x7fffffff,
+                                                      Pause pause = Pause()) {
 #ifndef NTRU_ABLATE
 #define NTRU_ABLATE 0
 #endif
   constexpr bool TWO = MODE != M_DEC2;
+  // The accumulators are never zeroed: the first matrix instruction of each takes the inline constant 0 as its C operand
+  // (accL: contraction step 0, peeled below; accH: its own diagonal sub-step) -- 2 x 16 x NT_S moves per strip less.
   v16i accL[NT_S], accH[NT_S];
   v4i W0[NT_S], W1[NT_S];
-#pragma unroll
-  for (int t = 0; t < NT_S; t++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) { accL[t][i] = 0; accH[t][i] = 0; }
   auto load_w = [&](int d, v4i &w0, v4i &w1) {
     const u32 *p = tb0 - 8 * d;
     w0 = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
@@ -1912,6 +1915,11 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w0, acc, 0, 0, 0);
     if (TWO) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w1, acc, 0, 0, 0);
   };
+  auto mm_first = [&](v16i &acc, v4i a0, v4i a1, v4i w0, v4i w1) {       // first touch of an accumulator
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w0, zero, 0, 0, 0);
+    if (TWO) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w1, acc, 0, 0, 0);
+  };
   // Fragment window: at a step boundary slot t holds the fragment of tile t ("canonical").  A block of NT_S steps
   // rotates through the slots with compile-time indices (no register moves) and ends canonical again: at sub-step u tile t
   // uses slot (t - u) mod NT_S, and the fragment needed next replaces the one tile NT_S-1 just used.  Left-over steps
@@ -1920,6 +1928,10 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   for (int t = 0; t < NT_S; t++) load_w(kb0 + t, W0[t], W1[t]);
 #if NTRU_ABLATE & 2
   const int kb0_ = kb0; kb0 = 0; const int NT_ = 0;
+#pragma unroll
+  for (int t = 0; t < NT_S; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) accH[t][i] = 0;
 #else
   const int NT_ = g.NT;
 #endif
@@ -1942,7 +1954,7 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
         else if (K == 1 || (K == 2 && t < u)) mm(accH[t], a0, a1, W0[sl], W1[sl]);
         else {
           mm(accL[t], a0, a1, and4(W0[sl], mlow), and4(W1[sl], mlow));
-          mm(accH[t], a0, a1, and4(W0[sl], mhigh), and4(W1[sl], mhigh));
+          mm_first(accH[t], a0, a1, and4(W0[sl], mhigh), and4(W1[sl], mhigh));   // t == u: the first term of `high`
         }
       }
       load_w(kb0 - (ib + u + 1), W0[(NT_S - 1 - u) % NT_S], W1[(NT_S - 1 - u) % NT_S]);
@@ -1960,13 +1972,42 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     a0 = n0; a1 = n1;
   };
   int ib = 0;
+  bool paused = false;
+  if (kb0 > 0 && NT_ > 0) {                              // contraction step 0: the first term of every `low`
+    if (!std::is_same<Pause, NoPause>::value && pause_ib <= 0) { pause(); paused = true; load_a(0, a0, a1); }
+    v4i n0, n1;
+    load_a(1, n0, n1);
+#pragma unroll
+    for (int t = 0; t < NT_S; t++) mm_first(accL[t], a0, a1, W0[t], W1[t]);
+#pragma unroll
+    for (int t = NT_S - 1; t > 0; t--) { W0[t] = W0[t - 1]; W1[t] = W1[t - 1]; }
+    load_w(kb0 - 1, W0[0], W1[0]);
+    a0 = n0; a1 = n1;
+    ib = 1;
+  } else {                                               // the diagonal block comes first (or a timing-only build)
+#pragma unroll
+    for (int t = 0; t < NT_S; t++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) accL[t][i] = 0;
+  }
+  auto maybe_pause = [&](int first, int last) {          // the steps first .. last are what the next block touches
+    if (!std::is_same<Pause, NoPause>::value && !paused && last >= pause_ib) {
+      __builtin_amdgcn_s_setprio(0);
+      pause();
+      __builtin_amdgcn_s_setprio(3);
+      paused = true;
+      load_a(first, a0, a1);                             // it was requested before the pause: read it again
+    }
+  };
   __builtin_amdgcn_s_setprio(3);       // the partner wave on this SIMD is usually in a VALU phase: decrypt -3 %
-  for (; ib + NT_S <= kb0; ib += NT_S) block(ib, std::integral_constant<int, 0>{});   // above the diagonal: low
-  for (; ib < kb0; ib++) single(ib, accL);
+  for (; ib + NT_S <= kb0; ib += NT_S) { maybe_pause(ib, ib + NT_S - 1); block(ib, std::integral_constant<int, 0>{}); }   // above the diagonal: low
+  for (; ib < kb0; ib++) { maybe_pause(ib, ib); single(ib, accL); }
+  maybe_pause(kb0, kb0 + NT_S - 1);
   block(kb0, std::integral_constant<int, 2>{});                                        // ib = kb0 .. kb0 + NT_S - 1
-  for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) block(ib, std::integral_constant<int, 1>{});   // below: high
-  for (; ib < NT_; ib++) single(ib, accH);
+  for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) { maybe_pause(ib, ib + NT_S - 1); block(ib, std::integral_constant<int, 1>{}); }   // below: high
+  for (; ib < NT_; ib++) { maybe_pause(ib, ib); single(ib, accH); }
   __builtin_amdgcn_s_setprio(0);
+  if (!std::is_same<Pause, NoPause>::value && !paused) pause();
   STAMP(stamp_base);
 #if NTRU_ABLATE & 128
   if (MODE == M_DEC1) { if (accL[0][0] == 0x7fffffff) epi(accL, accH); return; }
@@ -2236,8 +2277,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
   u32 *TF = (u32 *)(stLo + 32 * g.pitchA), *TP = TF + 4 * g.tpitch;
   unsigned char *blp = (unsigned char *)(TP + 4 * g.tpitch);   // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
   unsigned char *lift_lut = blp + 256 * g.NT;            // [q]: centred lift followed by mod p, index.js:117 verbatim
-  unsigned char *m3_lut = lds;                           // [(p-1)^2 N + 1][2], rebuilt per row block once the e stages are
-                                                         // dead: byte 2x = x mod p, byte 2x + 1 = (-x) mod p
+  // mod-p tables of product 2, rebuilt per row block once the e stages are dead: (-x) mod p at LDS address x, so that
+  // the quotient lookup's address IS the `high` accumulator; x mod p at M3V + x, the base folded into the low + high add
+  const int M3V = __builtin_amdgcn_readfirstlane(((int)((p - 1) * (p - 1)) * g.N + 4) & ~3);   // both tables inside the e_hi stage
+  unsigned char *m3_lut = lds;
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid0, BLOCK_THREADS);
   build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid0, BLOCK_THREADS);
@@ -2372,7 +2415,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
 #if !(NTRU_ABLATE & 64)
     for (int x = tid0; x <= (int)((p - 1) * (p - 1)) * N; x += BLOCK_THREADS) {
       const u32 rm = mod_small((u32)x, p);
-      *(u16 *)(m3_lut + 2 * x) = (u16)(rm | ((rm ? p - rm : 0u) << 8));
+      m3_lut[x] = (unsigned char)(rm ? p - rm : 0u);
+      m3_lut[M3V + x] = (unsigned char)rm;
     }
 #endif
 #if !(NTRU_ABLATE & 32)
@@ -2420,8 +2464,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
             for (int t = 0; t < NTS; t++)
 #pragma unroll
               for (int ii = 0; ii < 4; ii++) {
-                va[t][ii] = lds[(u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii]) << 1];
-                vb[t][ii] = decltype(wq)::value ? (u32)lds[((u32)hi[t][4 * j + ii] << 1) + 1] : 0u;
+                va[t][ii] = lds[(u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + M3V)];
+                vb[t][ii] = decltype(wq)::value ? (u32)lds[(u32)hi[t][4 * j + ii]] : 0u;
               }
 #pragma unroll
             for (int ii = 0; ii < 4; ii++) {
@@ -2447,6 +2491,266 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
       sidx++;
     });
   }
+}
+
+// ---- family 4, role-split variants ----------------------------------------------------------------------------------
+// k_encrypt_m / k_decrypt_m above give every wave the whole job of its column strips: stage, matrix loops, epilogue
+// arithmetic, table lookups and 2-byte result stores, phase after phase; the two co-resident workgroups of a CU overlap
+// almost none of it (the ablation times are additive).  The role-split kernels run ONE workgroup
+// of eight waves per CU, two per SIMD with complementary jobs at all times:
+//   waves 0-3, MATRIX waves: the strip loops of toeplitz_strip and nothing else -- their "epilogue" is one add and one
+//     ds_write_b32 per accumulator register: the raw pair (low + high | high << 16) goes into an LDS chunk;
+//   waves 4-7, IO waves: everything that touches global memory.  They stage the next row block's operand while the
+//     matrix waves compute, and they DRAIN the chunks: reduce modulo q / add m / negate with packed 16-bit arithmetic
+//     on 8 coefficients per lane and store them as 16-byte pieces that are ALIGNED IN GLOBAL MEMORY.  Rows of N odd
+//     elements start at every alignment, so a chunk row is laid out with the same misalignment as its row of the
+//     result array (a_row = byte address of the row start mod 16, which does not depend on the row block): aligned LDS
+//     reads then are aligned global pieces; the <= 7 elements on either side of a row segment go out one by one.
+// Per round (four adjacent strips): matrix loops || drain of the previous round's chunks, barrier, dump || staging,
+// barrier.  Preconditions checked by the host: every batch array 16-byte aligned, LDS fits; otherwise the kernels above.
+static __host__ __device__ inline int m2_rounds(int NT) { return (((NT + 3) >> 2) + 3) >> 2; }
+// Strip j of the 4 * rounds strips (sizes as even as possible, in column order): first tile and number of tiles.
+static __host__ __device__ inline void m2_strip(int NT, int j, int *kb0, int *nt) {
+  const int n_str = 4 * m2_rounds(NT), base = NT / n_str, rem = NT % n_str;
+  *nt = base + (j < rem ? 1 : 0);
+  *kb0 = j * base + (j < rem ? j : rem);
+}
+// Chunk row pitch of matrix wave w: 4 bytes per coefficient of its widest strip + room for twice the misalignment.
+static __host__ __device__ inline int m2_chunk_pitch(int NT, int w) {
+  int kb0, nt;
+  m2_strip(NT, w, &kb0, &nt);                            // the strips of round 0 are the widest ones of each wave
+  return 128 * nt + 32;
+}
+
+// Matrix wave: raw results of a strip into its chunk.  Register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5),
+// column lane & 31 (see k_encrypt_m); chunk element (row, c) lives at row * cp + 2 a_row + 4 c.
+template <class Acc>
+static __device__ __forceinline__ void m2_dump(unsigned char *chunk, int cp, int LD, int lane, const Acc &lo, const Acc &hi) {
+  constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+  u32 addr[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    addr[i] = (u32)(row * cp + 2 * ((2 * row * LD) & 15) + 4 * (lane & 31));
+  }
+#pragma unroll
+  for (int t = 0; t < NTS; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 pr = __builtin_amdgcn_perm((u32)hi[t][i], (u32)(lo[t][i] + hi[t][i]), 0x05040100u);   // (low + high) & 0xffff | high << 16
+      *(u32 *)(chunk + addr[i] + 128 * t) = pr;
+    }
+}
+
+// Geometry of a chunk drain (shared by every role-split kernel).  A row segment of `ncol` coefficients occupies the bytes
+// [a, a + L) of the row's "aligned space" (byte 0 = the 16-byte boundary at or below the segment's first element in a
+// uint16 result array; the same boundary is an 8-byte boundary of a byte array), L = 2 ncol.  Full 16-byte pieces k are
+// handled 16 lanes per row, 4 rows per pass, 8 passes; the elements before the first / after the last full piece 16
+// lanes per row as well (8 head slots, 8 tail slots).
+struct M2Piece { bool ok; int row, k, a; long at; };      // at: element index of the piece's first coefficient
+struct M2Edge { bool ok; int row, y, a; long at; };       // y: byte position in the aligned space
+static __device__ __forceinline__ M2Piece m2_piece(int it, int lane, int L, int LD, int kb0, long b0, long B) {
+  M2Piece p;
+  p.row = 4 * it + (lane >> 4);
+  p.a = (2 * p.row * LD) & 15;
+  const int kf0 = (p.a + 15) >> 4, kf1 = (p.a + L) >> 4;
+  p.k = kf0 + (lane & 15);
+  p.ok = b0 + p.row < B && p.k < kf1;
+  p.at = (b0 + p.row) * LD + 32 * kb0 + ((16 * p.k - p.a) >> 1);
+  return p;
+}
+static __device__ __forceinline__ M2Edge m2_edge(int it, int lane, int L, int LD, int kb0, long b0, long B) {
+  M2Edge g;
+  g.row = 4 * it + (lane >> 4);
+  g.a = (2 * g.row * LD) & 15;
+  const int j = lane & 15, kf0 = (g.a + 15) >> 4, kf1 = (g.a + L) >> 4;
+  const int head_end = 16 * kf0 < g.a + L ? 16 * kf0 : g.a + L;             // head = [a, head_end)
+  const int tail_beg = 16 * kf1 > head_end ? 16 * kf1 : head_end;           // tail = [tail_beg, a + L)
+  g.y = j < 8 ? g.a + 2 * j : tail_beg + 2 * (j - 8);
+  g.ok = b0 + g.row < B && (j < 8 ? g.y < head_end : g.y < g.a + L);
+  g.at = (b0 + g.row) * LD + 32 * kb0 + ((g.y - g.a) >> 1);
+  return g;
+}
+static __device__ __forceinline__ int m2_seg_bytes(int kb0, int nt, int N) {
+  const int ncol = 32 * nt < N - 32 * kb0 ? 32 * nt : N - 32 * kb0;
+  return 2 * (ncol > 0 ? ncol : 0);
+}
+
+// IO wave, encrypt: the plaintext bytes a chunk drain will add, requested a whole phase ahead (every load of the drain in
+// flight at once: as a load per pass the drain was one HBM round trip per pass, 3 ms per 2^20 instead of 1.5).
+struct M2EncPre { uint2 m8[8]; u32 mb[8]; };
+static __device__ __forceinline__ void m2_prefetch_encrypt(M2EncPre &pre, int kb0, int nt, long b0, long B, int N, int LD,
+                                                           const uint8_t *__restrict__ m, int lane) {
+  const int L = m2_seg_bytes(kb0, nt, N);
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const M2Piece p = m2_piece(it, lane, L, LD, kb0, b0, B);
+    pre.m8[it] = p.ok ? *(const uint2 *)(m + p.at) : make_uint2(0u, 0u);   // 8-byte aligned: 2 at is a multiple of 16
+    const M2Edge g = m2_edge(it, lane, L, LD, kb0, b0, B);
+    pre.mb[it] = g.ok ? (u32)m[g.at] : 0u;
+  }
+}
+
+// IO wave: one chunk of an encrypt strip -> e = (raw + m) mod q and quotientE = -high mod q.
+template <bool WQ>
+static __device__ __forceinline__ void m2_drain_encrypt(const unsigned char *chunk, int cp, int kb0, int nt, long b0, long B,
+                                                        int N, int LD, u32 q, const M2EncPre &pre,
+                                                        u16 *__restrict__ e, u16 *__restrict__ quotE, int lane) {
+  const int L = m2_seg_bytes(kb0, nt, N);
+  if (L <= 0) return;
+  const u32 qm2 = (q - 1) * 0x00010001u;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const M2Piece p = m2_piece(it, lane, L, LD, kb0, b0, B);
+    if (p.ok) {
+      const unsigned char *src = chunk + p.row * cp + 32 * p.k;
+      const v4i x0 = *(const v4i *)src, x1 = *(const v4i *)(src + 16);
+      const uint2 mv = pre.m8[it];
+      u32 rm[4], hv[4];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        rm[c] = __builtin_amdgcn_perm((u32)x0[2 * c + 1], (u32)x0[2 * c], 0x05040100u);
+        hv[c] = __builtin_amdgcn_perm((u32)x0[2 * c + 1], (u32)x0[2 * c], 0x07060302u);
+        rm[2 + c] = __builtin_amdgcn_perm((u32)x1[2 * c + 1], (u32)x1[2 * c], 0x05040100u);
+        hv[2 + c] = __builtin_amdgcn_perm((u32)x1[2 * c + 1], (u32)x1[2 * c], 0x07060302u);
+      }
+      const u32 mm[4] = {__builtin_amdgcn_perm(0u, mv.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, mv.x, 0x0c030c02u),
+                         __builtin_amdgcn_perm(0u, mv.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, mv.y, 0x0c030c02u)};
+      uint4 ev, qv;
+      u32 *evp = (u32 *)&ev, *qvp = (u32 *)&qv;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        evp[c] = as_u32(as_pair(rm[c]) + as_pair(mm[c])) & qm2;
+        qvp[c] = as_u32((u16x2){0, 0} - as_pair(hv[c])) & qm2;
+      }
+      *(uint4 *)(e + p.at) = ev;
+      if (WQ) *(uint4 *)(quotE + p.at) = qv;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const M2Edge g = m2_edge(it, lane, L, LD, kb0, b0, B);
+    if (g.ok) {
+      const u32 pr = *(const u32 *)(chunk + g.row * cp + 2 * g.y);
+      e[g.at] = (u16)((pr + pre.mb[it]) & (q - 1));
+      if (WQ) quotE[g.at] = (u16)((0u - (pr >> 16)) & (q - 1));
+    }
+  }
+}
+
+// encryptBits, role-split (see above).  Grid = one workgroup per CU; LDS: key arrays, TWO r stages, four chunks.
+__global__ __launch_bounds__(512, 1) void k_encrypt_m2(MGeom g, u32 q, const u16 *__restrict__ h,
+                                                         const uint8_t *__restrict__ r, const uint8_t *__restrict__ m,
+                                                         long B, u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;
+  unsigned char *stR = (unsigned char *)(T1 + 4 * g.tpitch);       // two stages of 32 rows
+  unsigned char *chunks = stR + 2 * 32 * g.pitchA;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave8 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const bool io = wave8 >= 4;
+  const int w4 = wave8 & 3;
+  int chunk_off = 0;
+  for (int w = 0; w < w4; w++) chunk_off += 32 * m2_chunk_pitch(g.NT, w);
+  unsigned char *chunk = chunks + chunk_off;                         // written by matrix wave w4, drained by io wave w4
+  const int cp = m2_chunk_pitch(g.NT, w4);
+  const int hthr = (int)(q >> 1) - 65;
+  auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
+  build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, tid0, 512);
+  build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid0, 512);
+  const bool want_q = quotE != nullptr;
+  const long nrb = (B + 31) >> 5;
+  const int rounds = m2_rounds(g.NT);
+  const int stamp_iter = 0;
+  (void)stamp_iter;
+
+  // io: rows w4, w4 + 4, ... of row block rb into stage `buf` (r in {0..3} bytes; columns >= N zero), in two halves so
+  // that the loads are in flight while the wave drains a chunk
+  constexpr int RPW = 8;
+  RawChunks<1> in_r[RPW];
+  auto stage_load = [&](long rb) {
+    int lane = lane0, LD = g.ld;
+    asm volatile("" : "+v"(lane), "+s"(LD));
+    const long b0 = rb << 5, left = (B - b0) * LD;
+    const AlignedSrc src_r = aligned_src(r + b0 * LD, left);
+#pragma unroll
+    for (int j = 0; j < RPW; j++) in_r[j] = load_raw<1>(src_r, src_r.a0 + (w4 + 4 * j) * LD + 16 * lane, 0);
+  };
+  auto stage_store = [&](long rb, int buf) {
+    int lane = lane0, N = g.N, LD = g.ld;
+    asm volatile("" : "+v"(lane), "+s"(N), "+s"(LD));
+    const int a0 = (int)((unsigned long long)(r + (rb << 5) * LD) & 15);
+    const v4i mk = col_mask16(16 * lane, N);
+    unsigned char *st = stR + buf * 32 * g.pitchA;
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int row = w4 + 4 * j;
+      v4i v[1];
+      shift_raw<1>(in_r[j], a0 + row * LD, v);
+      if (lane < 2 * g.NT) *(v4i *)(st + row * g.pitchA + 16 * lane) = v[0] & mk;
+    }
+  };
+
+  if (io && (long)blockIdx.x < nrb) { stage_load(blockIdx.x); stage_store(blockIdx.x, 0); }
+  __syncthreads();                                                   // key arrays and the first stage are in place
+  // The two roles run separate copies of the same (row block, round) loop -- same barrier sequence, but what one role
+  // keeps across iterations (prefetched operand rows, plaintext bytes) is not live in the other role's code.
+  if (!io) {
+    int it = 0;
+    for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x, it++) {
+      const int buf = it & 1;
+      for (int rho = 0; rho < rounds; rho++) {
+        int kb0, nt;
+        m2_strip(g.NT, 4 * rho + w4, &kb0, &nt);
+        int lane = lane0, LD = g.ld;
+        asm volatile("" : "+v"(lane), "+s"(LD));
+        const u32 *tb0 = frag_lane_base(T0, g, lane), *tb1 = frag_lane_base(T1, g, lane);
+        const unsigned char *st0 = stR + buf * 32 * g.pitchA + (lane & 31) * g.pitchA + 16 * (lane >> 5);
+        u32 mlow[4];
+        diag_low_mask(lane, mlow);
+        auto epi = [&](auto &lo, auto &hi) {
+          __syncthreads();                                           // the io wave has drained this chunk
+          m2_dump(chunk, cp, LD, lane, lo, hi);
+        };
+        switch (nt) {
+          case 0: __syncthreads(); break;
+          case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+          case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+          case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+          default: toeplitz_strip<M_ENC, 4>(st0, st0, tb0, tb1, g, kb0, mlow, epi); break;
+        }
+        __syncthreads();                                             // chunk full; (last round) next stage complete
+      }
+    }
+    return;
+  }
+  long drain_rb = -1; int drain_round = 0;                           // what the chunk holds
+  M2EncPre pre;                                                      // the plaintext bytes of that chunk's rows
+  auto drain = [&]() {
+#if !(NTRU_ABLATE & 1024)
+    if (drain_rb < 0) return;
+    int dk, dn;
+    m2_strip(g.NT, 4 * drain_round + w4, &dk, &dn);
+    if (want_q) m2_drain_encrypt<true>(chunk, cp, dk, dn, drain_rb << 5, B, g.N, g.ld, q, pre, e, quotE, lane0);
+    else m2_drain_encrypt<false>(chunk, cp, dk, dn, drain_rb << 5, B, g.N, g.ld, q, pre, e, quotE, lane0);
+#endif
+  };
+  int it = 0;
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x, it++) {
+    const int buf = it & 1;
+    for (int rho = 0; rho < rounds; rho++) {
+      int kb0, nt;
+      m2_strip(g.NT, 4 * rho + w4, &kb0, &nt);
+      const bool stage_next = rho == 0 && rb + gridDim.x < nrb;
+      if (stage_next) stage_load(rb + gridDim.x);                    // in flight during the drain
+      drain();
+      if (stage_next) stage_store(rb + gridDim.x, buf ^ 1);
+      __syncthreads();                                               // chunk free for the dump
+      drain_rb = rb; drain_round = rho;
+      m2_prefetch_encrypt(pre, kb0, nt, rb << 5, B, g.N, g.ld, m, lane0);   // in flight while the matrix wave dumps
+      __syncthreads();                                               // chunk full
+    }
+  }
+  drain();
 }
 
 // ---- family 4 for PER-ITEM operands: verifyKeysInputs (index.js:141-197) on the matrix cores ---------------------
@@ -3020,8 +3324,9 @@ extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
 
 extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (path < 0 || path > 4)
-    return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8) or 4 (matrix cores)");
+  if (path < 0 || path > 5)
+    return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8), 4 (matrix cores, one role per "
+                              "wave) or 5 (matrix cores, role-split workgroups)");
   eng->path = path;
   return NTRU_OK;
 }
@@ -3099,8 +3404,8 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
 
 // Matrix-core path (family 4): shared key, q a power of two <= 8192 (two int8 digit planes), LDS for a 32-row block.
 static bool make_mgeom(const ntru_engine *eng, int N, int q, int ld, MGeom *g) {
-  if (eng->path != 0 && eng->path != 4) return false;
-  if (q > 8192 || N > 1024 || ld > 1024 || N < (eng->path == 4 || ld != N ? 2 : 64)) return false;   // staging: lane = 16-byte chunk of a row
+  if (eng->path != 0 && eng->path != 4 && eng->path != 5) return false;
+  if (q > 8192 || N > 1024 || ld > 1024 || N < (eng->path >= 4 || ld != N ? 2 : 64)) return false;   // staging: lane = 16-byte chunk of a row
   g->N = N;
   g->ld = ld;
   g->NT = (N + 31) / 32;
@@ -3197,6 +3502,19 @@ extern "C" int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
     MGeom mg;
     const size_t lds = make_mgeom(eng, N, q, ld, &mg)
                            ? (size_t)32 * mg.tpitch + (size_t)32 * mg.pitchA + (((size_t)32 * ld + 15) & ~(size_t)15) + 16 : 0;
+    // role-split kernel (one workgroup of 8 waves per CU): needs 16-byte aligned batch arrays and its LDS to fit.  Only on
+    // request for now: 1.9 ms per 2^20 at N = 821 against 1.5 ms for k_encrypt_m (profiles/r02_*role_split*).
+    if (lds && eng->path == 5 && ((((uintptr_t)d_r | (uintptr_t)d_m | (uintptr_t)d_e | (uintptr_t)d_quotE) & 15) == 0)) {
+      size_t lds2 = (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA;
+      for (int w = 0; w < 4; w++) lds2 += (size_t)32 * m2_chunk_pitch(mg.NT, w);
+      if (lds2 <= 160 * 1024) {
+        if (int rc = resident_grid(eng, k_encrypt_m2, lds2, (long)((B + 31) / 32), &L.grid, 512)) return rc;
+        snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_encrypt_m2");
+        hipLaunchKernelGGL(k_encrypt_m2, L.grid, dim3(512), lds2, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B, d_e, d_quotE);
+        HIP_TRY(hipGetLastError());
+        return NTRU_OK;
+      }
+    }
     if (lds && lds <= 160 * 1024) {
       if (int rc = allow_lds(k_encrypt_m, lds)) return rc;
       if (int rc = resident_grid(eng, k_encrypt_m, lds, (long)((B + 31) / 32), &L.grid)) return rc;
@@ -3325,7 +3643,7 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
   if (!d_a || !d_b || !d_quot || !d_rem) return fail(NTRU_ERR_ARG, "ntru_polymul_split: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
   // per-item product on the matrix cores: mod a power of two <= 8192, 64 <= N <= 1024 (automatic from N = 128)
-  if ((eng->path == 0 || eng->path == 4) && is_pow2(mod) && mod <= 8192 && N <= 1024 && N >= (eng->path == 4 ? 64 : 128)) {
+  if ((eng->path == 0 || eng->path >= 4) && is_pow2(mod) && mod <= 8192 && N <= 1024 && N >= (eng->path >= 4 ? 64 : 128)) {
     PGeom pg;
     pg.N = N; pg.NT = (N + 31) / 32; pg.tpitch = ((16 * pg.NT + 31) / 32) * 32 + 8;
     const size_t lds = PI_WAVES * pi_wave_bytes2(pg);
@@ -3356,7 +3674,7 @@ extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const 
 // Per-item products with a ternary operand on the matrix cores: q a power of two <= 8192, 64 <= N <= 1024 (automatic
 // from N = 128).
 static bool product_tern_m_applies(const ntru_engine *eng, int N, int q) {
-  return (eng->path == 0 || eng->path == 4) && is_pow2(q) && q <= 8192 && N <= 1024 && N >= (eng->path == 4 ? 64 : 128);
+  return (eng->path == 0 || eng->path >= 4) && is_pow2(q) && q <= 8192 && N <= 1024 && N >= (eng->path >= 4 ? 64 : 128);
 }
 static int launch_product_tern_m(ntru_engine *eng, int N, int q, u32 mul, const u16 *d_a, const int8_t *d_s, long B,
                                  u16 *d_quot, u16 *d_rem) {
@@ -3414,7 +3732,7 @@ extern "C" int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int 
   HIP_TRY(hipSetDevice(eng->device));
   Launch L;
   // matrix-core kernel for per-item keys: p == 3, q <= 8192 (two int8 digit planes), 64 <= N <= 1024; automatic from N = 128
-  if ((eng->path == 0 || eng->path == 4) && p == 3 && q <= 8192 && N <= 1024 && N >= (eng->path == 4 ? 64 : 128)) {
+  if ((eng->path == 0 || eng->path >= 4) && p == 3 && q <= 8192 && N <= 1024 && N >= (eng->path >= 4 ? 64 : 128)) {
     PGeom pg;
     pg.N = N; pg.NT = (N + 31) / 32; pg.tpitch = ((16 * pg.NT + 31) / 32) * 32 + 8;
     const size_t lds = PI_WAVES * pi_wave_bytes(pg);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timing-only ablations of the matrix-core kernels (never shipped, results unchecked):
-#   bit 1 = result stores disabled, 2 = matrix loops disabled, 4 = encrypt: r not loaded, 8 = encrypt: m not loaded;
+#   bit 1 = result stores disabled, 2 = matrix loops disabled, 4 = r / e not loaded, 8 = encrypt: m not loaded, 32 = no image
+#   expansion, 64 = no mod-3 table, 128 / 256 = product 1 / 2 epilogue skipped, 512 = stores to one L2-resident row block;
 #   ABL_SET="3 7 11 15" selects the combinations (default 1 2 3).
 # Build here:   tools/ablate.sh build      -> ntru-circom_amd/lib/ab/libntru_abl{1,2,3}.so
 # Run on a GPU: tools/ablate.sh run [bench.py args]
@@ -9,8 +10,10 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
   mkdir -p ntru-circom_amd/lib/ab
   for a in ${ABL_SET:-1 2 3}; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -DNTRU_ABLATE=$a -shared \
-      -o ntru-circom_amd/lib/ab/libntru_abl$a.so ntru-circom_amd/csrc/ntru_engine.hip
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -DNTRU_ABLATE=$a -c \
+      -o ntru-circom_amd/lib/ab/engine_abl$a.o ntru-circom_amd/csrc/ntru_engine.hip
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ntru-circom_amd/lib/ab/libntru_abl$a.so \
+      ntru-circom_amd/lib/ab/engine_abl$a.o ntru-circom_amd/lib/obj/ntru_host.o ntru-circom_amd/lib/obj/ntru_generic.o -lpthread
   done
 else
   shift || true
