@@ -1801,6 +1801,7 @@ __global__ void k_unpack(int bits, int per, int packed_size, const unsigned long
 // the measurements behind the layout choices.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned int v2u __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 #ifndef ST_AUX
 #define ST_AUX 0     // cache policy bits of the result stores (0 measured best; 2 = non-temporal is 1.6x slower)
 #endif
@@ -2025,10 +2026,14 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
 // The NT column tiles are cut into 4 R strips of at most 4 tiles (sizes as even as possible, in column order); in round
 // rho the four waves take the adjacent strips 4 rho .. 4 rho + 3, so neighbouring strips are stored at about the same
 // time and the cache lines they share are completed in L2 instead of being written to HBM twice.  body(kb0, nt).
+// The first `rem` strips are one tile wider (at N = 821: waves 0, 1 carry 7 tiles per product, waves 2, 3 six), and wave w
+// of every workgroup runs on SIMD w.  The workgroups of the second half of the grid (the second resident workgroup of a CU
+// under the usual dispatch order) therefore take the strips in the order 2, 3, 0, 1, so that each SIMD sees 7 + 6 tiles.
 template <class Body>
 static __device__ __forceinline__ void for_each_strip(int NT, int wave, Body body) {
   const int rounds = (((NT + 3) >> 2) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int n_str = rounds * WAVES_PER_BLOCK, base = NT / n_str, rem = NT % n_str;
+  if (2 * blockIdx.x >= gridDim.x) wave ^= 2;
   for (int rho = 0; rho < rounds; rho++) {
     const int j = rho * WAVES_PER_BLOCK + wave;
     const int nt = base + (j < rem ? 1 : 0);
@@ -2220,6 +2225,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
         int voff[NTS];
 #pragma unroll
         for (int t = 0; t < NTS; t++) voff[t] = 32 * (kb0 + t) + (lane & 31) < N ? 2 * lane_off : (int)0x80000000;
+        // Stores: a tile register holds row R in lanes 0-31 and row R + 4 in lanes 32-63 (32 columns each), so a store of it
+        // writes two 64-byte pieces of two rows.  v_permlane32_swap exchanges the upper half of tile t's register with the
+        // lower half of tile t+1's: one register then is ONE row across both tiles, 128 contiguous bytes per store (a whole
+        // cache line on rows pitched to 64 elements).  What the store path pays for is the number of lines touched, not
+        // the instruction count: 8-byte stores of four rows per lane group were 14 % SLOWER (profiles/r02_ablation_*).
+        const int pv0 = 32 * kb0 + lane;                 // column of this lane in a tile pair starting at tile kb0
         auto out = [&](auto wq) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {                  // 4 rows per half-wave at a time, across the strip's tiles
@@ -2228,20 +2239,40 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
             for (int t = 0; t < NTS; t++)
 #pragma unroll
               for (int ii = 0; ii < 4; ii++) mv[t][ii] = m_l[(8 * j + ii) * LD + 32 * t];
+            u32 ev[NTS][4], qv[NTS][4];
 #pragma unroll
-            for (int t = 0; t < NTS; t++) {
-              const int so = 2 * (8 * j * LD + 32 * (kb0 + t));
-              u32 ev[4], qv[4];
+            for (int t = 0; t < NTS; t++)
 #pragma unroll
               for (int ii = 0; ii < 4; ii++) {
-                ev[ii] = (u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + (int)mv[t][ii]) & (q - 1);
-                qv[ii] = (u32)(0 - hi[t][4 * j + ii]) & (q - 1);
+                ev[t][ii] = (u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + (int)mv[t][ii]) & (q - 1);
+                qv[t][ii] = (u32)(0 - hi[t][4 * j + ii]) & (q - 1);
               }
+#pragma unroll
+            for (int t = 0; t + 1 < NTS; t += 2) {       // tile pairs: one row of 64 columns per store
+              const int pvoff = pv0 + 32 * t < N ? 2 * lane : (int)0x80000000;
+#pragma unroll
+              for (int ii = 0; ii < 4; ii++) {
+                const auto se = __builtin_amdgcn_permlane32_swap(ev[t][ii], ev[t + 1][ii], false, false);
+                const int so = 2 * ((8 * j + ii) * LD + 32 * (kb0 + t));
+                if (1 ABL_STORE(lo[t][4 * j])) {
+                  __builtin_amdgcn_raw_buffer_store_b16((u16)se[0], rs_e, pvoff, so, ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b16((u16)se[1], rs_e, pvoff, so + 8 * LD, ST_AUX);
+                  if (decltype(wq)::value) {
+                    const auto sq = __builtin_amdgcn_permlane32_swap(qv[t][ii], qv[t + 1][ii], false, false);
+                    __builtin_amdgcn_raw_buffer_store_b16((u16)sq[0], rs_q, pvoff, so, ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b16((u16)sq[1], rs_q, pvoff, so + 8 * LD, ST_AUX);
+                  }
+                }
+              }
+            }
+            if (NTS & 1) {                               // the odd tile out: two rows of 32 columns per store
+              constexpr int t = NTS - 1;
+              const int so = 2 * (8 * j * LD + 32 * (kb0 + t));
               if (1 ABL_STORE(lo[t][4 * j])) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ii++) {
-                  __builtin_amdgcn_raw_buffer_store_b16((u16)ev[ii], rs_e, voff[t], so + 2 * ii * LD, ST_AUX);
-                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)qv[ii], rs_q, voff[t], so + 2 * ii * LD, ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b16((u16)ev[t][ii], rs_e, voff[t], so + 2 * ii * LD, ST_AUX);
+                  if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)qv[t][ii], rs_q, voff[t], so + 2 * ii * LD, ST_AUX);
                 }
               }
             }
@@ -2380,15 +2411,23 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
                 xs[t][ii] = x;
                 const int so = 2 * (ro * LD + 32 * (kb0 + t));
                 if (1 ABL_STORE(lo[t][i])) {
+#if NTRU_ABLATE & 32768
+                  __builtin_amdgcn_raw_buffer_store_b16((u16)(x ^ (u32)hi[t][i]), rs_r1, voff[t], so, ST_AUX);       // timing only: one store
+#else
                   if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, voff[t], so, ST_AUX);
                   if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, voff[t], so, ST_AUX);
+#endif
                 }
               }
             }
 #pragma unroll
             for (int t = 0; t < NTS; t++)
 #pragma unroll
+#if NTRU_ABLATE & 16384
+              for (int ii = 0; ii < 4; ii++) lv[t][ii] = xs[t][ii] & 1u;                       // timing only: no lift lookups
+#else
               for (int ii = 0; ii < 4; ii++) lv[t][ii] = lift_lut[xs[t][ii]];
+#endif
 #pragma unroll
             for (int t = 0; t < NTS; t++) {
               const int col = 32 * (kb0 + t) + (lane & 31);
@@ -2464,8 +2503,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
             for (int t = 0; t < NTS; t++)
 #pragma unroll
               for (int ii = 0; ii < 4; ii++) {
+#if NTRU_ABLATE & 4096
+                va[t][ii] = (u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii]); vb[t][ii] = (u32)hi[t][4 * j + ii];   // timing only: no lookups
+#else
                 va[t][ii] = lds[(u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + M3V)];
                 vb[t][ii] = decltype(wq)::value ? (u32)lds[(u32)hi[t][4 * j + ii]] : 0u;
+#endif
               }
 #pragma unroll
             for (int ii = 0; ii < 4; ii++) {
@@ -2473,8 +2516,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
               for (int t = 0; t < NTS; t++) {
                 const int so = (ii + 8 * j) * LD + 32 * (kb0 + t);
                 if (1 ABL_STORE(lo[t][4 * j + ii])) {
+#if NTRU_ABLATE & 8192
+                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(va[t][ii] ^ vb[t][ii]), rs_v, voff[t], so, ST_AUX);   // timing only: one store
+#else
                   __builtin_amdgcn_raw_buffer_store_b8((uint8_t)va[t][ii], rs_v, voff[t], so, ST_AUX);
                   if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)vb[t][ii], rs_q2, voff[t], so, ST_AUX);
+#endif
                 }
               }
             }
@@ -2810,72 +2857,121 @@ static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T
   wave_lds_fence();                                                       // chunk matrices: their pads are zero again
 }
 
-// Digit planes of 16 values < q (u16 pairs in x[8]) -> natural-order int8 bytes; hs = d0 + 128 d1 is the signed
-// representative used by k_encrypt_m.  mul: the operand is (mul v) mod q (p fq of index.js:155; 1 otherwise).
-// q <= 256: the centred representative fits ONE int8 plane (d1 = 0; the callers skip that plane's matrix instructions).
+// Digit planes of 16 values (u16 pairs in x[8], element i0 + j; zero at and beyond N) -> natural-order int8 bytes, on
+// packed 16-bit pairs.  mul: the operand is (mul v) mod q (p fq of index.js:155; 1 otherwise).  q > 256: v = d0 + 128 d1 with
+// d0 = v & 127, d1 = v >> 7 <= 63 (the two planes have SEPARATE accumulators, so nothing needs a signed representative).
+// q <= 256: ONE plane, the centred representative in [-q/2, q/2) (d1 = 0; the callers skip that plane's matrix instructions).
 static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 mul, int i0, int N, v4i &o0, v4i &o1) {
-  union { v4i v; signed char c[16]; } d0, d1;
-  const int hthr = q <= 256 ? (int)(q >> 1) - 1 : (int)(q >> 1) - 65;
+  const u32 qm2 = (q - 1) * 0x00010001u;
+  u32 v[8];
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    const u32 v = ((x[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) * mul;
-    int hs = i0 + j < N ? (int)(v & (q - 1)) : 0;
-    hs = hs > hthr ? hs - (int)q : hs;
-    const int lo = q <= 256 ? hs : ((hs + 64) & 127) - 64;
-    d0.c[j] = (signed char)lo;
-    d1.c[j] = (signed char)((hs - lo) >> 7);
+  for (int c = 0; c < 8; c++) {
+    const int left = N - (i0 + 2 * c);                     // valid elements of this pair
+    const u32 keep = left >= 2 ? 0xFFFFFFFFu : (left == 1 ? 0x0000FFFFu : 0u);
+    const u32 t = mul == 1u ? x[c] : as_u32(as_pair(x[c]) * (u16x2){(u16)mul, (u16)mul});
+    v[c] = t & qm2 & keep;
   }
-  o0 = d0.v; o1 = d1.v;
+  if (q <= 256) {
+    const u32 h2 = (q >> 1) * 0x00010001u;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const u32 a = as_u32(as_pair((as_u32(as_pair(v[2 * c]) + as_pair(h2)) & qm2)) - as_pair(h2));           // two's complement low bytes
+      const u32 b = as_u32(as_pair((as_u32(as_pair(v[2 * c + 1]) + as_pair(h2)) & qm2)) - as_pair(h2));
+      o0[c] = (int)__builtin_amdgcn_perm(b, a, 0x06040200u);
+      o1[c] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const u32 a = v[2 * c], b = v[2 * c + 1];
+      o0[c] = (int)__builtin_amdgcn_perm(b & 0x007F007Fu, a & 0x007F007Fu, 0x06040200u);
+      o1[c] = (int)__builtin_amdgcn_perm((b >> 7) & 0x007F007Fu, (a >> 7) & 0x007F007Fu, 0x06040200u);
+    }
+  }
 }
 
 // One plane-pair product: acc{L,H}{0,1} += chunk matrices fa0 / fa1 (x) Toeplitz fragments of T.  TWO = false: one plane.
+// A step (tile distance d) is one or two matrix instructions on operands that are used once, so the loop lives on its
+// LDS reads: they are requested TWO steps ahead into three rotating register sets (unrolled by three, no register moves;
+// one step ahead left the wave waiting on LDS latency at the top of every iteration: 64 matrix clocks per step against
+// ~130 of latency).  The first instruction of every accumulator takes C = 0.
 template <bool TWO>
 static __device__ __forceinline__ void pi_product(const unsigned char *pa0, const unsigned char *pa1, const u32 *tb, int NT,
                                                   const u32 (&mlow)[4], v16i &L0, v16i &L1, v16i &H0, v16i &H1) {
-#pragma unroll
-  for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
-  // operands of distance d: fragment of the reversed array 8 d dwords below the lane's base, chunk rows shifted by d.
-  // The operands of the next distance are requested before the current products (one past the end reads pad bytes).
-  auto ld = [&](int d, v4i &a0, v4i &a1, v4i &w) {
+  struct Ops { v4i a0, a1, w; };
+  auto ld = [&](int d, Ops &o) {                          // distance d: fragment 8 d dwords below the lane's base, rows shifted by d
+    d = d < NT ? d : NT;                                  // requests past the last step read pad bytes (never used)
     const u32 *p = tb - 8 * d;
-    w = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
-    a0 = *(const v4i *)(pa0 - 32 * d);
-    if (TWO) a1 = *(const v4i *)(pa1 - 32 * d);
+    o.w = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+    o.a0 = *(const v4i *)(pa0 - 32 * d);
+    if (TWO) o.a1 = *(const v4i *)(pa1 - 32 * d);
   };
-  v4i a0, a1, w;
-  ld(-(NT - 1), a0, a1, w);
-  for (int d = -(NT - 1); d < 0; d++) {
-    v4i n0, n1, nw;
-    ld(d + 1, n0, n1, nw);
-    H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w, H0, 0, 0, 0);
-    if (TWO) H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w, H1, 0, 0, 0);
-    a0 = n0; a1 = n1; w = nw;
-  }
-  {
-    v4i n0, n1, nw;
-    ld(1, n0, n1, nw);
-    const v4i wl = and4(w, mlow);
-    const v4i wh = {(int)((u32)w[0] & ~mlow[0]), (int)((u32)w[1] & ~mlow[1]), (int)((u32)w[2] & ~mlow[2]), (int)((u32)w[3] & ~mlow[3])};
-    L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wl, L0, 0, 0, 0);
-    H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wh, H0, 0, 0, 0);
-    if (TWO) {
-      L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wl, L1, 0, 0, 0);
-      H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wh, H1, 0, 0, 0);
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool firstH = true, firstL = true;                      // resolved at compile time where the step kind is static
+  auto step = [&](int d, const Ops &o) {                  // d < 0: high, d > 0: low, d == 0: split by the diagonal mask
+    if (d < 0) {
+      H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, o.w, H0, 0, 0, 0);
+      if (TWO) H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, o.w, H1, 0, 0, 0);
+    } else if (d > 0) {
+      L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, o.w, L0, 0, 0, 0);
+      if (TWO) L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, o.w, L1, 0, 0, 0);
+    } else {
+      const v4i wl = and4(o.w, mlow);
+      const v4i wh = {(int)((u32)o.w[0] & ~mlow[0]), (int)((u32)o.w[1] & ~mlow[1]), (int)((u32)o.w[2] & ~mlow[2]), (int)((u32)o.w[3] & ~mlow[3])};
+      L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, wl, zero, 0, 0, 0);          // the first term of `low`
+      H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, wh, H0, 0, 0, 0);
+      if (TWO) {
+        L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, wl, zero, 0, 0, 0);
+        H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, wh, H1, 0, 0, 0);
+      }
     }
-    a0 = n0; a1 = n1; w = nw;
+  };
+  (void)firstH; (void)firstL;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { H0[i] = 0; H1[i] = 0; }   // NT = 1 has no d < 0 step; otherwise folded into the first step below
+  Ops A, Bq, C;
+  int d = -(NT - 1);
+  ld(d, A); ld(d + 1, Bq);
+  // high part: steps d = -(NT-1) .. -1, three per trip
+  for (; d + 2 < 0; d += 3) {
+    ld(d + 2, C); step(-1, A);
+    ld(d + 3, A); step(-1, Bq);
+    ld(d + 4, Bq); step(-1, C);
   }
-  for (int d = 1; d < NT; d++) {
-    v4i n0, n1, nw;
-    ld(d + 1, n0, n1, nw);
-    L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w, L0, 0, 0, 0);
-    if (TWO) L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w, L1, 0, 0, 0);
-    a0 = n0; a1 = n1; w = nw;
+  // 0, 1 or 2 steps of the high part are left; then the diagonal; then the low part.  The rotation continues with moves
+  // for these few steps (at most two high steps + the diagonal), after which the low part runs three per trip again.
+  for (; d < 0; d++) {
+    ld(d + 2, C); step(-1, A);
+    A = Bq; Bq = C;
+  }
+  ld(2, C); step(0, A);                                   // d == 0
+  A = Bq; Bq = C;
+  d = 1;
+  for (; d + 2 < NT; d += 3) {
+    ld(d + 2, C); step(1, A);
+    ld(d + 3, A); step(1, Bq);
+    ld(d + 4, Bq); step(1, C);
+  }
+  for (; d < NT; d++) {
+    ld(d + 2, C); step(1, A);
+    A = Bq; Bq = C;
+  }
+  if (!TWO) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) { L1[i] = 0; H1[i] = 0; }
   }
 }
 
 static __device__ __forceinline__ int wave_max(int v) {
+  // the lane index is re-materialised here: otherwise the six permute addresses are hoisted out of the item loop and,
+  // at the register limit of three waves per SIMD, spilled to scratch
+  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int o = __builtin_amdgcn_ds_bpermute((l ^ off) << 2, v);
+    v = o > v ? o : v;
+  }
   return v;
 }
 
@@ -2902,35 +2998,42 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
     const long row = item * N, left = (B - item) * N;
     u32 fl = 0;
-    // Operands are fetched where they are first needed (rows at any alignment: aligned chunks + a wave-uniform byte
-    // shift); holding all five across the products costs ~40 registers and a wave of occupancy.
-    auto fetch8 = [&](const void *base) {                                 // 16 bytes per lane of a byte row
-      const AlignedSrc sr = aligned_src(base, left);
-      const RawChunks<1> rw = load_raw<1>(sr, sr.a0 + 16 * lane, 0);
+    // Every operand row is requested one product ahead of its use (rows at any alignment: aligned chunks + a wave-uniform
+    // byte shift at use): fq, f and fp at the top, g and fq again (an L2 hit) before product 2, h before product 3.  A fetch
+    // right where each product needs it left the wave idle for a round trip to HBM three times per item.
+    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_g = aligned_src(gg + row, left),
+                     s_fp = aligned_src(fp + row, left);
+    RawChunks<2> r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * lane, 0);
+    const RawChunks<1> r_f = load_raw<1>(s_f, s_f.a0 + 16 * lane, 0);
+    const RawChunks<1> r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * lane, 0);
+    auto bytes_of = [&](const RawChunks<1> &rw, const AlignedSrc &sr) {
       v4i v[1];
       shift_raw<1>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
       return v[0];
     };
-    auto fetch_fq = [&](u32 (&x)[8]) {                                    // 16 coefficients per lane as u16 pairs
-      const AlignedSrc sr = aligned_src(fq + row, 2 * left);
-      const RawChunks<2> rw = load_raw<2>(sr, sr.a0 + 32 * lane, 0);
+    auto fq_pairs = [&](u32 (&x)[8]) {                                    // 16 coefficients per lane as u16 pairs
       v4i v[2];
-      shift_raw<2>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
+      shift_raw<2>(r_fq, __builtin_amdgcn_readfirstlane(s_fq.a0), v);
 #pragma unroll
       for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
     };
-    // ternary operands: any negative byte is -1 (ValTernary), bytes at and beyond N are zero
+    // ternary operands: any negative byte is -1 (ValTernary), bytes at and beyond N are zero -- four bytes at a time
     auto ternary = [&](v4i v) {
-      union { v4i v; signed char c[16]; } u; u.v = v & cmask;
+      v4i o;
 #pragma unroll
-      for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
-      return u.v;
+      for (int c = 0; c < 4; c++) {
+        const u32 w = (u32)(v[c] & cmask[c]);
+        u32 neg = (w >> 7) & 0x01010101u;                                  // 1 in every negative byte ...
+        neg |= neg << 1; neg |= neg << 2; neg |= neg << 4;                 // ... spread to 0xFF
+        o[c] = (int)(w | neg);
+      }
+      return o;
     };
     // ---- product 1: fq * f mod q (index.js:158-160)
     {
       u32 xq[8];
-      fetch_fq(xq);
-      const v4i tf = ternary(fetch8(f + row));
+      fq_pairs(xq);
+      const v4i tf = ternary(bytes_of(r_f, s_f));
       pi_build_array(nat, T, g, lane, tf);
       if (stager) {
         v4i o0, o1;
@@ -2962,13 +3065,15 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     wave_lds_fence();
     // ---- product 2: fp * f mod p (index.js:161-163): the array of f serves again, one plane of fp mod 3
     {
-      const v4i vfp = fetch8(fp + row);
+      const v4i vfp = bytes_of(r_fp, s_fp);
       union { v4i v; unsigned char c[16]; } u; u.v = vfp & cmask;
 #pragma unroll
       for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
       if (stager) *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = u.v;
     }
     wave_lds_fence();
+    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * lane, 0);                       // for product 3, in flight during product 2
+    const RawChunks<1> r_g = load_raw<1>(s_g, s_g.a0 + 16 * lane, 0);
     pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
@@ -2990,8 +3095,8 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     // ---- product 3: ((p fq) mod q) * g mod q, compared with h below its trimmed length (index.js:155,164-166)
     {
       u32 xq[8];
-      fetch_fq(xq);
-      const v4i tg = ternary(fetch8(gg + row));
+      fq_pairs(xq);
+      const v4i tg = ternary(bytes_of(r_g, s_g));
       pi_build_array(nat, T, g, lane, tg);
       if (stager) {
         v4i o0, o1;
@@ -3001,32 +3106,46 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
       wave_lds_fence();
     }
+    // h is requested before the product whose remainder it is compared with, as a row chunk (16 coefficients per lane);
+    // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
+    const AlignedSrc s_h = aligned_src(h + row, 2 * left);
+    const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * lane, 0);
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
-      const __amdgpu_buffer_rsrc_t rs_h = rows_rsrc(h + row, 2L * N);
-      u32 hv[16];                                                       // indices >= N read as zero
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-        hv[i] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_h, 2 * kl, 64 * ((i & 3) + 8 * (i >> 2)), 0);
-      int top = -1;
-      u32 differs = 0;                                                  // bit i: h differs from the remainder at this lane's i-th index
+      u16 *remx = (u16 *)nat;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
         const u32 rv = (u32)(lo + hi) & (q - 1);
         __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
         __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
-        if (hv[i]) top = k > top ? k : top;
-        differs |= (k < N && hv[i] != rv) ? 1u << i : 0u;
+        remx[ko + kl] = (u16)rv;                                          // ko + kl < 32 NT <= (3 N + 64) / 2
       }
+      wave_lds_fence();
+      // index.js:165: h[k] must equal the remainder for every k below h's trimmed length
+      v4i hc[2];
+      shift_raw<2>(r_h, __builtin_amdgcn_readfirstlane(s_h.a0), hc);
+      const int i0 = 16 * lane;
+      u32 nz = 0, df = 0;                                                 // bit j: h[i0 + j] != 0 / != remainder[i0 + j]
+      if (stager) {
+        const v4i rc0 = *(const v4i *)(nat + 32 * lane), rc1 = *(const v4i *)(nat + 32 * lane + 16);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const int lf = N - (i0 + 2 * c);
+          const u32 keep = lf >= 2 ? 0xFFFFFFFFu : (lf == 1 ? 0x0000FFFFu : 0u);
+          const u32 hx = (u32)(c < 4 ? hc[0][c] : hc[1][c - 4]) & keep, rx = (u32)(c < 4 ? rc0[c] : rc1[c - 4]) & keep;
+          const u32 x = hx ^ rx;
+          nz |= ((hx & 0xFFFFu) ? 1u : 0u) << (2 * c) | ((hx >> 16) ? 2u : 0u) << (2 * c);
+          df |= ((x & 0xFFFFu) ? 1u : 0u) << (2 * c) | ((x >> 16) ? 2u : 0u) << (2 * c);
+        }
+      }
+      const int top = nz ? i0 + 31 - __builtin_clz(nz) : -1;
       const int wtop = wave_max(top);
       const int hl = wtop >= 0 ? wtop + 1 : 1;                          // trimmed length of h (1 for the zero polynomial)
-      bool bad = false;
-#pragma unroll
-      for (int i = 0; i < 16; i++) bad |= ((differs >> i) & 1u) && 32 * ((i & 3) + 8 * (i >> 2)) + kl < hl;
-      if (__ballot(bad) != 0) fl |= NTRU_FLAG_INVALID_H;
+      const int nv = hl - i0 < 0 ? 0 : (hl - i0 > 16 ? 16 : hl - i0);   // this lane's indices below hl
+      if (__ballot((df & ((1u << nv) - 1u)) != 0) != 0) fl |= NTRU_FLAG_INVALID_H;
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
     wave_lds_fence();
