@@ -167,6 +167,11 @@ def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
 
 def main():
     args = parse_args()
+    # Rank 0 prints ONE JSON line on stdout.  RCCL prints a version banner to stdout when the process group starts, so
+    # file descriptor 1 is pointed at stderr for the duration of the run and the line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import __graft_entry__ as ge
     pkg = ge.load_package()
@@ -425,7 +430,8 @@ def main():
             out["cpu_baseline"] = faithful
             out["cpu_baseline_all_cores"] = faithful_all
             out["cpu_baseline_optimized"] = optimized
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

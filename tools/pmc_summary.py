@@ -43,16 +43,19 @@ def main():
     ap.add_argument("--N", type=int, default=821)
     ap.add_argument("--logB", type=int, default=20)
     ap.add_argument("--items", type=int, default=0, help="items per launch when it is not 2^logB (per-item kernels)")
+    ap.add_argument("--prefix", default="prof", help="gpurun_out/<prefix>_{stats,fetch,write}: prof (bench.py) or prof_sec (bench_configs.py)")
+    ap.add_argument("--largest", action="store_true", help="average only the launches of the largest batch of each kernel")
+    ap.add_argument("--no-latest", action="store_true", help="do not overwrite profiles/pmc_hbm_latest.json (secondary kernels)")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
-    sdir = os.path.join(ROOT, "gpurun_out", "prof_stats")
+    sdir = os.path.join(ROOT, "gpurun_out", a.prefix + "_stats")
     stats = glob.glob(os.path.join(sdir, "**", "*_kernel_stats.csv"), recursive=True)
     trace = glob.glob(os.path.join(sdir, "**", "*kernel_trace.csv"), recursive=True)
     if stats:
-        rows = list(csv.reader(open(sorted(stats)[-1])))
+        rows = list(csv.reader(open(max(stats, key=os.path.getmtime))))
     elif trace:      # rocpd output converted with rocpd2csv: rebuild the --stats table from the kernel trace
         dur = collections.defaultdict(list)
-        for r in csv.DictReader(open(sorted(trace)[-1])):
+        for r in csv.DictReader(open(max(trace, key=os.path.getmtime))):
             dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         total = float(sum(sum(v) for v in dur.values()))
         rows = [["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]]
@@ -68,17 +71,22 @@ def main():
             for r in rows:
                 w.writerow([r[0][:110]] + r[1:])
     kern = {}
-    for cname, sub in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
+    for cname, sub in (("FETCH_SIZE", a.prefix + "_fetch"), ("WRITE_SIZE", a.prefix + "_write")):
         files = glob.glob(os.path.join(ROOT, "gpurun_out", sub, "**", "*counter_collection*.csv"), recursive=True)
         if not files:
             continue
         acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(sorted(files)[-1])):
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):     # gpurun merges into gpurun_out/: older passes stay
             k = short(r["Kernel_Name"])
             if k and r["Counter_Name"] == cname:
                 acc[k].append(float(r["Counter_Value"]))
         for k, v in acc.items():
+            # --largest: the persistent kernels launch the same grid for every batch size, so launches of different batches
+            # (tools/bench_configs.py) can only be told apart by their traffic: keep the largest batch's launches
+            if a.largest:
+                v = [x for x in v if x >= 0.9 * max(v)]
             kern.setdefault(k, {})[cname + "_KiB_per_launch"] = sum(v) / len(v)
+            kern[k][cname + "_launches_averaged"] = len(v)
     B = 1 << a.logB
     per_item = {"k_encrypt": (6, 4), "k_decrypt": (8, 3), "k_verify_keys": (17, 17), "k_polymul": (8, 8), "k_public_key": (5, 5)}
     if a.items:
@@ -105,7 +113,7 @@ def main():
            "engine_source_sha256": engine_source_hash(),
            "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py",
            "kernels": kern}
-    for name in (a.tag + "_pmc_hbm.json", "pmc_hbm_latest.json"):
+    for name in (a.tag + "_pmc_hbm.json",) + (() if a.no_latest else ("pmc_hbm_latest.json",)):
         with open(os.path.join(out, name), "w") as fh:
             json.dump(doc, fh, indent=1)
     print(json.dumps(doc, indent=1))

@@ -29,11 +29,13 @@ def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     grid = {}
     for sub in (a.prefix + "1", a.prefix + "2"):
-        for path in glob.glob(os.path.join(ROOT, "gpurun_out", sub, "**", "*counter_collection*.csv"), recursive=True):
+        paths = glob.glob(os.path.join(ROOT, "gpurun_out", sub, "**", "*counter_collection*.csv"), recursive=True)
+        for path in ([max(paths, key=os.path.getmtime)] if paths else []):      # gpurun merges: older passes stay around
             for r in csv.DictReader(open(path)):
                 k = short(r["Kernel_Name"])
                 if not k:
                     continue
+                k = "%s grid=%s" % (k, r["Grid_Size"])                      # launches of different sizes are kept apart
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 grid[k] = (int(r["Grid_Size"]), int(r["Workgroup_Size"]))
     out = {"tag": a.tag, "engine_source_sha256": engine_source_hash(), "unit_note": __doc__.split("\n\n")[-1], "kernels": {}}
