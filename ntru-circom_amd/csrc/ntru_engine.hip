@@ -2029,9 +2029,9 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
 // The first `rem` strips are one tile wider (at N = 821: waves 0, 1 carry 7 tiles per product, waves 2, 3 six), and wave w
 // of every workgroup runs on SIMD w.  The workgroups of the second half of the grid (the second resident workgroup of a CU
 // under the usual dispatch order) therefore take the strips in the order 2, 3, 0, 1, so that each SIMD sees 7 + 6 tiles.
-template <class Body>
+template <int MAXT = 4, class Body>
 static __device__ __forceinline__ void for_each_strip(int NT, int wave, Body body) {
-  const int rounds = (((NT + 3) >> 2) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int rounds = (((NT + MAXT - 1) / MAXT) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int n_str = rounds * WAVES_PER_BLOCK, base = NT / n_str, rem = NT % n_str;
   if (2 * blockIdx.x >= gridDim.x) wave ^= 2;
   for (int rho = 0; rho < rounds; rho++) {
@@ -2124,10 +2124,14 @@ static __device__ __forceinline__ v4i col_mask16(int c16, int N) {
 
 // encryptBits on the matrix cores: e = (r * h + m) split by 1 - x^N; r in {0..3} bytes, h < q <= 8192.
 // h is taken in the representative hs = d0 + 128 d1, d0 in [-64,63], 4 d1 in [-128,124]; planes [r | 32 r] x [d0 ; 4 d1].
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, const u16 *__restrict__ h,
-                                                             const uint8_t *__restrict__ r,
-                                                             const uint8_t *__restrict__ m, long B,
-                                                             u16 *__restrict__ e, u16 *__restrict__ quotE) {
+// MAXT: widest strip.  8 (one workgroup per CU, 512 registers per wave, one strip per wave and row block) was measured at
+// 2.28 ms per 2^20 against 1.51-1.58 ms for 4: with one wave per SIMD nothing overlaps the matrix loops
+// (DESIGN.md section 5b); only 4 is instantiated.
+template <int MAXT>
+static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 *__restrict__ h,
+                                                      const uint8_t *__restrict__ r,
+                                                      const uint8_t *__restrict__ m, long B,
+                                                      u16 *__restrict__ e, u16 *__restrict__ quotE) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;
   unsigned char *stA = (unsigned char *)(T1 + 4 * g.tpitch);
@@ -2203,7 +2207,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
     __syncthreads();
     STAMP(3);
     sidx = 0;
-    for_each_strip(g.NT, wave, [&](int kb0, int nt) {
+    for_each_strip<MAXT>(g.NT, wave, [&](int kb0, int nt) {
       // Result register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31: a per-lane offset
       // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
       // (Packing 4 columns per lane with in-quad transposes and 64-bit stores was measured 8 % slower: the rows are only
@@ -2284,11 +2288,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
         case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
-        default: toeplitz_strip<M_ENC, 4>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 4: toeplitz_strip<M_ENC, 4>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        default: break;                                  // MAXT = 4
       }
       sidx++;
     });
   }
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, const u16 *__restrict__ h,
+                                                             const uint8_t *__restrict__ r,
+                                                             const uint8_t *__restrict__ m, long B,
+                                                             u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  encrypt_m_body<4>(g, q, h, r, m, B, e, quotE);
 }
 
 // decryptBits on the matrix cores.  Product 1: a = f * e, e = lo7 + 128 hi (both digits non-negative, q <= 8192), planes

@@ -912,3 +912,47 @@ def test_full_size_batch_properties(eng, profile, logB):
         assert torch.equal(u(e3), (u(e1) + u(e2)) % q)
     finally:
         eng.set_stream(None)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pipeline_many_chunks_equal_oracle(eng, pinned):
+    """The host-pointer entry points (ntru_host.hip) cut a batch into chunks that alternate between two slots (stream, pinned
+    arena, device arena): 150 001 items = five chunks, ragged last one, with pageable numpy arrays (staged through the pinned
+    arenas) and with arrays from ntru_host_alloc (DMA'd in place); every output array against the oracle.  Then a smaller and a
+    larger batch through the same engine: the arenas only grow and are reused."""
+    N, q, p, d = 167, 128, 3, 18
+    rng = np.random.default_rng(4242)
+    h = rng.integers(0, q, N); fp = rng.integers(0, p, N)
+    f = ternary_rows(rng, 1, N, 61, 60, two=-1)[0]
+    for B in (150001, 7, 70000):
+        base = np.zeros(N, np.uint8); base[:d] = 1; base[d:2 * d] = 2
+        r_src = rng.permuted(np.tile(base, (B, 1)), axis=1)
+        m_src = rng.integers(0, 3, (B, N)).astype(np.uint8)
+        if pinned:
+            r = eng.pinned_empty((B, N), np.uint8); r[:] = r_src
+            m = eng.pinned_empty((B, N), np.uint8); m[:] = m_src
+        else:
+            r, m = r_src, m_src
+        e, quot = eng.encrypt_batch(N, q, h, r, m)
+        e_o, quot_o = orc.encrypt_batch(N, q, h, r_src, m_src)
+        assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (B, pinned)
+        if pinned:
+            ein = eng.pinned_empty((B, N), np.uint16); ein[:] = e_o
+        else:
+            ein = e_o
+        got = eng.decrypt_batch(N, q, p, f, fp, ein)
+        want = orc.decrypt_batch(N, q, p, f, fp, e_o)
+        for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
+            assert np.array_equal(g_, w_), (B, pinned, name)
+        v_only = eng.decrypt_batch(N, q, p, f, fp, ein, want_witness=False)
+        assert np.array_equal(v_only[0], want[0])
+    # per-item entry points through the same pipeline (several chunks as well)
+    B = 9000
+    a = rng.integers(0, q, (B, N)); b = rng.integers(0, q, (B, N))
+    quot, rem = eng.polymul_split(N, q, a, b)
+    qo, ro = orc.polymul_split_batch(N, q, a, b)
+    assert np.array_equal(quot, qo) and np.array_equal(rem, ro)
+    key = np.arange(8, dtype=np.uint32) + 3
+    s = eng.sample_ternary(N, d, d, 2, key, 10, B)
+    assert np.array_equal(s[B - 1], orc.sample_ternary_batch(N, d, d, 2, key, 10 + B - 1, 1)[0])      # first_item advances per chunk
+    assert np.array_equal(s[0], orc.sample_ternary_batch(N, d, d, 2, key, 10, 1)[0])
