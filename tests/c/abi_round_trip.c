@@ -66,6 +66,39 @@ int main(void) {
     fprintf(stderr, "q = 12 was not refused\n");
     bad |= 1;
   }
+  /* page-locked buffers from the engine: the same encrypt, every array DMA'd in place, must give the same bytes */
+  {
+    const int N = 509, q = 2048; const int64_t B = 40000;                 /* four chunks through the two slots */
+    const size_t n = (size_t)B * N;
+    uint16_t *h = malloc(2 * (size_t)N), *e1 = malloc(2 * n);
+    uint8_t *r = ntru_host_alloc(n), *m = ntru_host_alloc(n);
+    uint16_t *e2 = ntru_host_alloc(2 * n), *qe2 = ntru_host_alloc(2 * n);
+    if (!r || !m || !e2 || !qe2) { fprintf(stderr, "ntru_host_alloc failed: %s\n", ntru_last_error()); return 2; }
+    for (int i = 0; i < N; i++) h[i] = (uint16_t)(rnd() % (uint32_t)q);
+    for (size_t i = 0; i < n; i++) { r[i] = (uint8_t)(rnd() % 3); m[i] = (uint8_t)(rnd() & 1); }
+    CHECK(ntru_encrypt_batch(eng, N, q, h, r, m, B, e2, qe2));
+    uint8_t *rp = malloc(n), *mp = malloc(n);
+    memcpy(rp, r, n); memcpy(mp, m, n);
+    CHECK(ntru_encrypt_batch(eng, N, q, h, rp, mp, B, e1, NULL));           /* pageable, value-only */
+    const int same = !memcmp(e1, e2, 2 * n);
+    printf("pinned vs pageable host buffers, N=%d B=%lld: %s\n", N, (long long)B, same ? "identical" : "DIFFERENT");
+    bad |= !same;
+    ntru_host_free(r); ntru_host_free(m); ntru_host_free(e2); ntru_host_free(qe2); free(h); free(e1); free(rp); free(mp);
+  }
+  /* generic family: the two divisions of test/circuits.test.js:165-170 that the reference computes / refuses, and its
+   * worked Euclid example (index.js:411-423): [4,2,0,3]^-1 mod [3,2,1] over Z_11 = [5,8] */
+  {
+    const int64_t a1[3] = {81, 2, 96}, b1[3] = {48, 2, 31}, a2[2] = {1, 2}, b2[2] = {2, 3}, a3[4] = {4, 2, 0, 3}, b3[3] = {3, 2, 1};
+    int64_t quot[32], rem[32], gcd[32], inv[32]; int32_t ql, rl, gl, il; uint8_t st;
+    CHECK(ntru_generic_divide(eng, 3, 3, 128, a1, b1, 1, quot, &ql, rem, &rl, &st));
+    const int ok1 = st == 0 && ql == 1 && quot[0] == 32 && rl == 2 && rem[0] == 81 && rem[1] == 66;
+    CHECK(ntru_generic_divide(eng, 2, 2, 3, a2, b2, 1, quot, &ql, rem, &rl, &st));
+    const int ok2 = st == NTRU_GENERIC_NO_INVERSE;
+    CHECK(ntru_generic_eea(eng, 4, 3, 11, a3, b3, 1, gcd, &gl, inv, &il, &st));
+    const int ok3 = st == 0 && gl == 1 && gcd[0] == 1 && il == 2 && inv[0] == 5 && inv[1] == 8;
+    printf("generic family: divide %s, refused divide %s, Euclid example %s\n", ok1 ? "ok" : "WRONG", ok2 ? "ok" : "WRONG", ok3 ? "ok" : "WRONG");
+    bad |= !(ok1 && ok2 && ok3);
+  }
   ntru_engine_destroy(eng);
   return bad;
 }
