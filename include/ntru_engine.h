@@ -78,9 +78,11 @@ int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
 /* Tuning / test knob: 0 = pick the fastest applicable kernel family (default), 1 = always the packed-u16 MAC
  * kernels, 2 = the ternary add path wherever it applies, 3 = the add path without its dot8 product, 4 = the int8
  * matrix-core path wherever it applies (encrypt / decrypt: shared key, q <= 8192, N <= 1024; verify_keys: q <= 8192,
- * p == 3, 64 <= N <= 1024), even for small N, with one role per wave (k_encrypt_m / k_decrypt_m), 5 = the same with the
- * role-split workgroups (k_encrypt_m2: matrix waves + io waves, 16-byte aligned batch arrays) where they apply -- which is
- * also what 0 picks for them.  Results are identical. */
+ * p == 3, 64 <= N <= 1024), even for small N, as two independent four-wave workgroups per CU (k_encrypt_m, k_decrypt_m),
+ * 5 = the same as ONE workgroup of two four-wave groups whose matrix-loop and epilogue phases are interleaved by barriers
+ * (k_encrypt_m8, k_decrypt_m8; falls back to 4 where 160 KB of LDS do not hold two groups), 6 = 4 with the role-split encrypt
+ * kernel (k_encrypt_m2: matrix waves + io waves, needs 16-byte aligned batch arrays).  0 picks k_encrypt_m and, for N > 512,
+ * k_decrypt_m8.  Results are identical. */
 int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
 /* Name of the kernel the last *_dev call on this engine launched, e.g. "k_decrypt_s<13,13>" (for reports). */
 const char *ntru_engine_last_kernel(ntru_engine_t *eng);

@@ -2029,15 +2029,16 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
 // The first `rem` strips are one tile wider (at N = 821: waves 0, 1 carry 7 tiles per product, waves 2, 3 six), and wave w
 // of every workgroup runs on SIMD w.  The workgroups of the second half of the grid (the second resident workgroup of a CU
 // under the usual dispatch order) therefore take the strips in the order 2, 3, 0, 1, so that each SIMD sees 7 + 6 tiles.
+// all: the body is called for empty strips too (nt = 0) and the caller has applied the swap itself (lock-step kernels).
 template <int MAXT = 4, class Body>
-static __device__ __forceinline__ void for_each_strip(int NT, int wave, Body body) {
+static __device__ __forceinline__ void for_each_strip(int NT, int wave, Body body, bool all = false) {
   const int rounds = (((NT + MAXT - 1) / MAXT) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int n_str = rounds * WAVES_PER_BLOCK, base = NT / n_str, rem = NT % n_str;
-  if (2 * blockIdx.x >= gridDim.x) wave ^= 2;
+  if (!all && 2 * blockIdx.x >= gridDim.x) wave ^= 2;
   for (int rho = 0; rho < rounds; rho++) {
     const int j = rho * WAVES_PER_BLOCK + wave;
     const int nt = base + (j < rem ? 1 : 0);
-    if (nt > 0) body(j * base + (j < rem ? j : rem), nt);
+    if (nt > 0 || all) body(j * base + (j < rem ? j : rem), nt);
   }
 }
 
@@ -2127,24 +2128,32 @@ static __device__ __forceinline__ v4i col_mask16(int c16, int N) {
 // MAXT: widest strip.  8 (one workgroup per CU, 512 registers per wave, one strip per wave and row block) was measured at
 // 2.28 ms per 2^20 against 1.51-1.58 ms for 4: with one wave per SIMD nothing overlaps the matrix loops
 // (DESIGN.md section 5b); only 4 is instantiated.
-template <int MAXT>
+template <int MAXT, int GROUPS>                              // GROUPS = 2: the lock-step schedule of decrypt_m_body (k_encrypt_m8)
 static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 *__restrict__ h,
                                                       const uint8_t *__restrict__ r,
                                                       const uint8_t *__restrict__ m, long B,
                                                       u16 *__restrict__ e, u16 *__restrict__ quotE) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;
-  unsigned char *stA = (unsigned char *)(T1 + 4 * g.tpitch);
+  const int group = GROUPS == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;         // key arrays (shared by the groups), then per group [r stage][m image]
+  const int gbytes = 32 * g.pitchA + ((32 * g.ld + 15) & ~15) + 16;
+  unsigned char *stA = (unsigned char *)(T1 + 4 * g.tpitch) + group * gbytes;
   unsigned char *mimg = stA + 32 * g.pitchA;             // rows b0..b0+31 of m exactly as in memory (pitch g.ld)
-  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int tid0 = threadIdx.x & (BLOCK_THREADS - 1), lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int hthr = (int)(q >> 1) - 65;
   auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
-  build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, tid0, BLOCK_THREADS);
-  build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, tid0, BLOCK_THREADS);
+  build_toeplitz_array(T0, g, [&](int i) { const int hs = hs_of(i); return ((hs + 64) & 127) - 64; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
+  build_toeplitz_array(T1, g, [&](int i) { const int hs = hs_of(i); const int d0 = ((hs + 64) & 127) - 64; return ((hs - d0) >> 7) * 4; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
   const bool want_q = quotE != nullptr;
   const long nrb = (B + 31) >> 5;
   int sidx = 0, stamp_iter = -1;
-  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+  auto phase = [&]() { if (GROUPS == 2) __syncthreads(); };
+  if (GROUPS == 2 && group == 1) __syncthreads();          // group 1 runs one phase behind group 0
+  const long stride = (long)gridDim.x * GROUPS, iters = (nrb + stride - 1) / stride;
+  const int rounds = (((g.NT + MAXT - 1) / MAXT) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  for (long it = 0; it < iters; it++) {
+    long rb = (long)blockIdx.x * GROUPS + group + it * stride;   // past the end: a row block of zeros whose stores are dropped
+    rb = rb < nrb ? rb : nrb;
     stamp_iter++;
     STAMP(0);
     // Re-materialise the lane index and N per row block: otherwise every per-lane address / predicate of the staging
@@ -2155,7 +2164,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
     const unsigned char *st0 = stA + (lane & 31) * g.pitchA + 16 * (lane >> 5);
     u32 mlow[4];
     diag_low_mask(lane, mlow);
-    const long b0 = rb << 5, left = (B - b0) * LD;       // elements from this row block to the end of the batch
+    const long b0 = rb << 5 < B ? rb << 5 : B, left = (B - b0) * LD;   // elements from this row block to the end of the batch
     const AlignedSrc src_r = aligned_src(r + b0 * LD, left), src_m = aligned_src(m + b0 * LD, left);
     // All loads of the row block (r rows and the m image) are requested BEFORE the barrier: they land in registers, so
     // they need not wait for the previous row block's readers, and the two HBM round trips become one that overlaps the
@@ -2207,7 +2216,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
     __syncthreads();
     STAMP(3);
     sidx = 0;
-    for_each_strip<MAXT>(g.NT, wave, [&](int kb0, int nt) {
+    for_each_strip<MAXT>(g.NT, GROUPS == 2 ? wave ^ (2 * group) : wave, [&](int kb0, int nt) {
       // Result register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31: a per-lane offset
       // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
       // (Packing 4 columns per lane with in-quad transposes and 64-bit stores was measured 8 % slower: the rows are only
@@ -2215,6 +2224,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
       const int lane_off = (lane >> 5) * 4 * LD + (lane & 31);
       auto epi = [&](auto &lo, auto &hi) {               // arrays of the strip's tiles
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        phase();                                         // matrix loop | epilogue
         long bb = b0;                                    // descriptors made where they are used: see k_decrypt_m
 #if NTRU_ABLATE & 512
         bb = 0;                                          // timing only: every workgroup writes the first row block (L2-resident)
@@ -2285,6 +2295,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
         if (want_q) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
+        case 0: phase(); break;
         case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
@@ -2292,48 +2303,78 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
         default: break;                                  // MAXT = 4
       }
       sidx++;
-    });
+      if (sidx < rounds) phase();                        // epilogue | next matrix loop
+    }, GROUPS == 2);
   }
+  if (GROUPS == 2 && group == 0) __syncthreads();        // group 1's last phase
 }
 
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, const u16 *__restrict__ h,
                                                              const uint8_t *__restrict__ r,
                                                              const uint8_t *__restrict__ m, long B,
                                                              u16 *__restrict__ e, u16 *__restrict__ quotE) {
-  encrypt_m_body<4>(g, q, h, r, m, B, e, quotE);
+  encrypt_m_body<4, 1>(g, q, h, r, m, B, e, quotE);
+}
+
+__global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_encrypt_m8(MGeom g, u32 q, const u16 *__restrict__ h,
+                                                                  const uint8_t *__restrict__ r,
+                                                                  const uint8_t *__restrict__ m, long B,
+                                                                  u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  encrypt_m_body<4, 2>(g, q, h, r, m, B, e, quotE);
 }
 
 // decryptBits on the matrix cores.  Product 1: a = f * e, e = lo7 + 128 hi (both digits non-negative, q <= 8192), planes
 // [e_lo | 2 e_hi] x [f ; 64 f]; centred lift (index.js:117 verbatim); product 2: c = fp * lifted, one plane.  The lifted
 // message goes from the accumulator layout (column per lane) to the operand stage (row per lane) through a 2-bit packed
 // LDS image [column][8 bytes] and one expansion pass.
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
-                                                             const uint8_t *__restrict__ fp,
-                                                             const u16 *__restrict__ e, long B,
-                                                             uint8_t *__restrict__ value, u16 *__restrict__ quot1,
-                                                             u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+// GROUPS = 1: one workgroup = four waves = one row block at a time, two workgroups per CU (k_decrypt_m).
+// GROUPS = 2 (k_decrypt_m8): ONE workgroup of eight waves per CU = two groups of four, each with its own row blocks, stages and
+// packed image, sharing the key arrays and the lift table.  Every matrix loop and every epilogue is a PHASE between two
+// workgroup barriers, and group 1 runs one phase behind group 0: while one group's waves are in their matrix loops, the
+// other group's waves (their partners on the SIMDs) are in an epilogue / staging phase, by construction instead of by
+// luck.  Phases per row block: stage, then (loop, epilogue) per strip and product, with the image expansion between the
+// products: 10 at N = 821 -- an even number, so the two groups stay in opposite phases.
+template <int GROUPS>
+static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                      const uint8_t *__restrict__ fp,
+                                                      const u16 *__restrict__ e, long B,
+                                                      uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                      u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // LDS layout: the e_hi stage comes FIRST because the mod-p table of product 2 is overlaid on it: at LDS address 0 its
-  // lookups need no base add (ds_read_u8 v, index offset:0|1)
-  unsigned char *stHi = lds;
+  const int group = GROUPS == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  // LDS layout: per group [e_hi stage][e_lo stage][packed image], then the shared key arrays and the lift table.  Group 0's
+  // e_hi stage is at LDS address 0: the mod-p tables of product 2 are overlaid on it and their lookups need no base add.
+  const int gbytes = 64 * g.pitchA + 256 * g.NT;
+  unsigned char *stHi = lds + group * gbytes;
   unsigned char *stLo = stHi + 32 * g.pitchA;
-  u32 *TF = (u32 *)(stLo + 32 * g.pitchA), *TP = TF + 4 * g.tpitch;
-  unsigned char *blp = (unsigned char *)(TP + 4 * g.tpitch);   // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
-  unsigned char *lift_lut = blp + 256 * g.NT;            // [q]: centred lift followed by mod p, index.js:117 verbatim
+  unsigned char *blp = stLo + 32 * g.pitchA;             // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
+  u32 *TF = (u32 *)(lds + GROUPS * gbytes), *TP = TF + 4 * g.tpitch;
+  unsigned char *lift_lut = (unsigned char *)(TP + 4 * g.tpitch);   // [q]: centred lift followed by mod p, index.js:117 verbatim
   // mod-p tables of product 2, rebuilt per row block once the e stages are dead: (-x) mod p at LDS address x, so that
   // the quotient lookup's address IS the `high` accumulator; x mod p at M3V + x, the base folded into the low + high add
   const int M3V = __builtin_amdgcn_readfirstlane(((int)((p - 1) * (p - 1)) * g.N + 4) & ~3);   // both tables inside the e_hi stage
-  unsigned char *m3_lut = lds;
-  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, tid0, BLOCK_THREADS);
-  build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, tid0, BLOCK_THREADS);
-  for (u32 x = tid0; x < q; x += BLOCK_THREADS) lift_lut[x] = (unsigned char)mod_small(2 * x > q ? x + 1 : x, p);
+  unsigned char *m3_lut = stHi;
+  const int tid0 = threadIdx.x & (BLOCK_THREADS - 1), lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
+  build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
+  for (u32 x = threadIdx.x; x < q; x += GROUPS * BLOCK_THREADS) lift_lut[x] = (unsigned char)mod_small(2 * x > q ? x + 1 : x, p);
+#ifndef NTRU_PHASE_MASK
+#define NTRU_PHASE_MASK 15       // which boundaries of the lock-step schedule are barriers (tuning experiments): 1 = product 1 loop | epilogue,
+#endif                           // 2 = product 1 epilogue | next loop, 4 / 8 = the same for product 2
+  auto phase = [&](int kind) { if (GROUPS == 2 && (NTRU_PHASE_MASK & kind)) __syncthreads(); };
+  if (GROUPS == 2 && group == 1) __syncthreads();                      // group 1 runs one phase behind group 0
   const bool want_q1 = quot1 != nullptr, want_r1 = rem1 != nullptr, want_q2 = quot2 != nullptr;
   const long nrb = (B + 31) >> 5;
   const int nch = 2 * g.NT;
   const u32 qm2 = (q - 1) * 0x00010001u;
   int sidx = 0, stamp_iter = -1;
-  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+  const long stride = (long)gridDim.x * GROUPS, iters = (nrb + stride - 1) / stride;
+  const int rounds = (((g.NT + 3) >> 2) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  for (long it = 0; it < iters; it++) {
+    // a group without a row block left (the last trip of an odd count) still walks through every phase: its row block is
+    // placed at the end of the batch, where every load reads zero and every store is dropped by the buffer descriptors
+    long rb = (long)blockIdx.x * GROUPS + group + it * stride;
+    rb = rb < nrb ? rb : nrb;
     stamp_iter++;
     STAMP(0);
     int lane = lane0, N = g.N, LD = g.ld;                // see k_encrypt_m
@@ -2343,31 +2384,35 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     const unsigned char *st1 = stHi + (lane & 31) * g.pitchA + 16 * (lane >> 5);
     u32 mlow[4];
     diag_low_mask(lane, mlow);
-    const long b0 = rb << 5, left = (B - b0) * LD;
+    const long b0 = rb << 5 < B ? rb << 5 : B, left = (B - b0) * LD;
     const AlignedSrc src_e = aligned_src(e + b0 * LD, 2 * left);
-    // (requesting these loads before the barrier, as k_encrypt_m does, measured 3 % slower here.)  lane = 16 coefficients.
-    __syncthreads();
-    STAMP(1);
-    {
-      const int c16 = lane;
-      constexpr int RPW = 32 / WAVES_PER_BLOCK;
-      RawChunks<2> raw[RPW];
-      int sh[RPW];
-      u32 cmask[8];                                      // columns >= N of the last chunk(s) are zero; coefficients mod q
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const int left2 = N - (16 * c16 + 2 * c);
-        cmask[c] = qm2 & (left2 >= 2 ? 0xFFFFFFFFu : (left2 == 1 ? 0x0000FFFFu : 0u));
-      }
+    // lane = 16 coefficients.  (Requesting these loads before the barrier, as k_encrypt_m does, measured 3 % slower with two
+    // workgroups per CU and 5 % slower in the lock-step schedule.)
+    constexpr int RPW = 32 / WAVES_PER_BLOCK;
+    RawChunks<2> raw[RPW];
+    int sh[RPW];
+    auto request_rows = [&]() {
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
         const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * LD;
         sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
 #if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
-        raw[j] = fake_raw<2>(pos0 + c16);
+        raw[j] = fake_raw<2>(pos0 + lane);
 #else
-        raw[j] = load_raw<2>(src_e, pos0 + 32 * c16, sh[j]);
+        raw[j] = load_raw<2>(src_e, pos0 + 32 * lane, sh[j]);
 #endif
+      }
+    };
+    __syncthreads();
+    STAMP(1);
+    request_rows();
+    {
+      const int c16 = lane;
+      u32 cmask[8];                                      // columns >= N of the last chunk(s) are zero; coefficients mod q
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int left2 = N - (16 * c16 + 2 * c);
+        cmask[c] = qm2 & (left2 >= 2 ? 0xFFFFFFFFu : (left2 == 1 ? 0x0000FFFFu : 0u));
       }
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
@@ -2396,9 +2441,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     const int lane_off = (lane >> 5) * 4 * LD + (lane & 31);
     // ---- product 1: a = f * e mod q; witness stores; lifted message -> packed image
     sidx = 0;
-    for_each_strip(g.NT, wave, [&](int kb0, int nt) {
+    for_each_strip<4>(g.NT, GROUPS == 2 ? wave ^ (2 * group) ^ (2 * blockIdx.x >= gridDim.x ? 2 : 0) : wave, [&](int kb0, int nt) {
       auto epi = [&](auto &lo, auto &hi) {
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        phase(1);                                        // matrix loop | epilogue
         // descriptors are made here, from a re-materialised row-block base, so that they live in scalar registers only
         // while they are used (held across the matrix loops they are spilled to VGPRs and every store becomes a
         // waterfall loop)
@@ -2454,13 +2500,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         else out(std::false_type{}, std::false_type{});
       };
       switch (nt) {
+        case 0: phase(1); break;                         // (the strip list hands out empty strips only to keep the phases in step)
         case 1: toeplitz_strip<M_DEC1, 1>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 2: toeplitz_strip<M_DEC1, 2>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 3: toeplitz_strip<M_DEC1, 3>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         default: toeplitz_strip<M_DEC1, 4>(st0, st1, tbf, tbf, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
       }
       sidx++;
-    });
+      if (sidx < rounds) phase(2);                       // epilogue | next matrix loop (after the last strip: the barrier below)
+    }, GROUPS == 2);
     __syncthreads();                                    // every wave is done with the e stages; packed image complete
     STAMP(8);
 #if !(NTRU_ABLATE & 64)
@@ -2496,9 +2544,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
     STAMP(10);
     // ---- product 2: c = fp * lifted mod p
     sidx = 0;
-    for_each_strip(g.NT, wave, [&](int kb0, int nt) {
+    for_each_strip<4>(g.NT, GROUPS == 2 ? wave ^ (2 * group) ^ (2 * blockIdx.x >= gridDim.x ? 2 : 0) : wave, [&](int kb0, int nt) {
       auto epi = [&](auto &lo, auto &hi) {
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
+        phase(4);                                        // matrix loop | epilogue
         long bb = b0;                                    // see product 1
         asm volatile("" : "+s"(bb));
         const long lf = (B - bb) * LD;
@@ -2518,8 +2567,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
 #if NTRU_ABLATE & 4096
                 va[t][ii] = (u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii]); vb[t][ii] = (u32)hi[t][4 * j + ii];   // timing only: no lookups
 #else
-                va[t][ii] = lds[(u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + M3V)];
-                vb[t][ii] = decltype(wq)::value ? (u32)lds[(u32)hi[t][4 * j + ii]] : 0u;
+                va[t][ii] = m3_lut[(u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + M3V)];
+                vb[t][ii] = decltype(wq)::value ? (u32)m3_lut[(u32)hi[t][4 * j + ii]] : 0u;
 #endif
               }
 #pragma unroll
@@ -2542,15 +2591,35 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
         if (want_q2) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
+        case 0: phase(4); break;
         case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
         case 2: toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
         case 3: toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
         default: toeplitz_strip<M_DEC2, 4>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
       }
       sidx++;
-    });
+      if (sidx < rounds) phase(8);
+    }, GROUPS == 2);
   }
+  if (GROUPS == 2 && group == 0) __syncthreads();        // group 1's last phase
 }
+
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                             const uint8_t *__restrict__ fp,
+                                                             const u16 *__restrict__ e, long B,
+                                                             uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                             u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  decrypt_m_body<1>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
+}
+
+__global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                                  const uint8_t *__restrict__ fp,
+                                                                  const u16 *__restrict__ e, long B,
+                                                                  uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                                  u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  decrypt_m_body<2>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
+}
+
 
 // ---- family 4, role-split variants ----------------------------------------------------------------------------------
 // k_encrypt_m / k_decrypt_m above give every wave the whole job of its column strips: stage, matrix loops, epilogue
@@ -2919,7 +2988,6 @@ static __device__ __forceinline__ void pi_product(const unsigned char *pa0, cons
     if (TWO) o.a1 = *(const v4i *)(pa1 - 32 * d);
   };
   const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  bool firstH = true, firstL = true;                      // resolved at compile time where the step kind is static
   auto step = [&](int d, const Ops &o) {                  // d < 0: high, d > 0: low, d == 0: split by the diagonal mask
     if (d < 0) {
       H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, o.w, H0, 0, 0, 0);
@@ -2938,7 +3006,6 @@ static __device__ __forceinline__ void pi_product(const unsigned char *pa0, cons
       }
     }
   };
-  (void)firstH; (void)firstL;
 #pragma unroll
   for (int i = 0; i < 16; i++) { H0[i] = 0; H1[i] = 0; }   // NT = 1 has no d < 0 step; otherwise folded into the first step below
   Ops A, Bq, C;
@@ -3455,9 +3522,9 @@ extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
 
 extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (path < 0 || path > 5)
-    return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8), 4 (matrix cores, one role per "
-                              "wave) or 5 (matrix cores, role-split workgroups)");
+  if (path < 0 || path > 6)
+    return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8), 4 (matrix cores, two workgroups per CU), "
+                              "5 (matrix cores, lock-step groups) or 6 (matrix cores, role-split encrypt)");
   eng->path = path;
   return NTRU_OK;
 }
@@ -3535,7 +3602,7 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
 
 // Matrix-core path (family 4): shared key, q a power of two <= 8192 (two int8 digit planes), LDS for a 32-row block.
 static bool make_mgeom(const ntru_engine *eng, int N, int q, int ld, MGeom *g) {
-  if (eng->path != 0 && eng->path != 4 && eng->path != 5) return false;
+  if (eng->path != 0 && eng->path != 4 && eng->path != 5 && eng->path != 6) return false;
   if (q > 8192 || N > 1024 || ld > 1024 || N < (eng->path >= 4 || ld != N ? 2 : 64)) return false;   // staging: lane = 16-byte chunk of a row
   g->N = N;
   g->ld = ld;
@@ -3635,7 +3702,19 @@ extern "C" int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
                            ? (size_t)32 * mg.tpitch + (size_t)32 * mg.pitchA + (((size_t)32 * ld + 15) & ~(size_t)15) + 16 : 0;
     // role-split kernel (one workgroup of 8 waves per CU): needs 16-byte aligned batch arrays and its LDS to fit.  Only on
     // request for now: 1.9 ms per 2^20 at N = 821 against 1.5 ms for k_encrypt_m (profiles/r02_*role_split*).
-    if (lds && eng->path == 5 && ((((uintptr_t)d_r | (uintptr_t)d_m | (uintptr_t)d_e | (uintptr_t)d_quotE) & 15) == 0)) {
+    if (lds && eng->path == 5) {                           // lock-step variant: two four-wave groups per workgroup, one workgroup per CU
+      const size_t per_group = (size_t)32 * mg.pitchA + (((size_t)32 * ld + 15) & ~(size_t)15) + 16;
+      const size_t lds8 = (size_t)32 * mg.tpitch + 2 * per_group;
+      if (lds8 <= 160 * 1024) {
+        const long nrb = (long)((B + 31) / 32);
+        if (int rc = resident_grid(eng, k_encrypt_m8, lds8, (nrb + 1) / 2, &L.grid, 2 * BLOCK_THREADS)) return rc;
+        snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_encrypt_m8");
+        hipLaunchKernelGGL(k_encrypt_m8, L.grid, dim3(2 * BLOCK_THREADS), lds8, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B, d_e, d_quotE);
+        HIP_TRY(hipGetLastError());
+        return NTRU_OK;
+      }
+    }
+    if (lds && eng->path == 6 && ((((uintptr_t)d_r | (uintptr_t)d_m | (uintptr_t)d_e | (uintptr_t)d_quotE) & 15) == 0)) {
       size_t lds2 = (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA;
       for (int w = 0; w < 4; w++) lds2 += (size_t)32 * m2_chunk_pitch(mg.NT, w);
       if (lds2 <= 160 * 1024) {
@@ -3703,6 +3782,21 @@ extern "C" int ntru_decrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
     MGeom mg;
     const size_t lds = (p == 3 && make_mgeom(eng, N, q, ld, &mg))
                            ? (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT + (((size_t)q + 15) & ~(size_t)15) : 0;
+    // lock-step variant: one workgroup of two four-wave groups per CU, phases of the two groups interleaved by barriers.
+    // The default where its LDS fits and a product takes two rounds of strips (N > 512): 2.52 against 2.63 ms per 2^20 at N = 821
+    // (profiles/r02_ab_lockstep_phase_masks.txt), 2.16 against 2.24 ms at N = 701; at N = 509 (one round) it is 6 % slower.
+    if (lds && (eng->path == 5 || (eng->path == 0 && mg.NT > 16))) {
+      const size_t lds8 = 2 * ((size_t)64 * mg.pitchA + (size_t)256 * mg.NT) + (size_t)32 * mg.tpitch + (((size_t)q + 15) & ~(size_t)15);
+      if (lds8 <= 160 * 1024) {
+        const long nrb = (long)((B + 31) / 32);
+        if (int rc = resident_grid(eng, k_decrypt_m8, lds8, (nrb + 1) / 2, &L.grid, 2 * BLOCK_THREADS)) return rc;
+        snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_decrypt_m8");
+        hipLaunchKernelGGL(k_decrypt_m8, L.grid, dim3(2 * BLOCK_THREADS), lds8, eng->stream, mg, (u32)q, (u32)p, d_f, d_fp, d_e,
+                           (long)B, d_value, d_quot1, d_rem1, d_quot2);
+        HIP_TRY(hipGetLastError());
+        return NTRU_OK;
+      }
+    }
     if (lds && lds <= 160 * 1024) {
       if (int rc = allow_lds(k_decrypt_m, lds)) return rc;
       if (int rc = resident_grid(eng, k_decrypt_m, lds, (long)((B + 31) / 32), &L.grid)) return rc;

@@ -237,7 +237,7 @@ def test_kernel_families_agree(eng):
         f = ternary_rows(rng, 1, N, d, d - 1, two=-1)[0]
         r = ternary_rows(rng, 9, N, d, d); m = rng.integers(0, 2, (9, N))
         outs, names = [], []
-        for path in (1, 2, 3, 4, 5, 0):
+        for path in (1, 2, 3, 4, 5, 6, 0):
             eng.set_kernel_path(path)
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             names.append(eng.last_kernel() if False else None)
@@ -252,9 +252,9 @@ def test_kernel_families_agree(eng):
 @pytest.mark.parametrize("N,q,d", [(17, 32, 2), (31, 64, 5), (32, 128, 6), (33, 32, 7), (64, 8192, 20), (65, 4096, 21),
                                    (167, 128, 18), (509, 2048, 169), (701, 8192, 233), (821, 4096, 273),
                                    (1024, 8192, 300)])
-@pytest.mark.parametrize("path", [4, 5])
+@pytest.mark.parametrize("path", [4, 5, 6])
 def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
-    """Family 4 forced (ntru_engine_set_kernel_path 4: one role per wave; 5: role-split workgroups), including sizes the
+    """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step groups; 6: role-split encrypt), including sizes the
     automatic choice leaves to other families, batches that do not fill a 32-row block, and h at the corners of the
     digit-plane range."""
     rng = np.random.default_rng(N * 31 + q)
@@ -269,7 +269,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             r = ternary_rows(rng, B, N, d, d)
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
-            assert eng.last_kernel() == ("k_encrypt_m" if path == 4 else "k_encrypt_m2")
+            assert eng.last_kernel() == {4: "k_encrypt_m", 5: "k_encrypt_m8", 6: "k_encrypt_m2"}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -278,7 +278,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             ein[-1] = rng.integers(0, q, N)
             ein[0, :4] = (q - 1, 0, q // 2, q // 2 + 1)
             got = eng.decrypt_batch(N, q, p, f, fp, ein)
-            assert eng.last_kernel() in ("k_decrypt_m", "k_decrypt_m2")
+            assert eng.last_kernel() == ("k_decrypt_m8" if path == 5 and N < 1024 else "k_decrypt_m")   # N = 1024: 160 KB of LDS do not hold two groups
             want = orc.decrypt_batch(N, q, p, f, fp, ein)
             for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
                 assert np.array_equal(g_, w_), (B, name)
@@ -288,7 +288,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
         eng.set_kernel_path(0)
 
 
-@pytest.mark.parametrize("path", [4, 5])
+@pytest.mark.parametrize("path", [4, 5, 6])
 def test_matrix_core_path_random_parameter_sweep(eng, path):
     """Differential sweep: 40 random (N, q, B) with N in [2, 1024] (odd and even, around the 32-tile boundaries), q any
     power of two up to 8192, ragged B; matrix-core family (forced) against the CPU oracle, all outputs."""
@@ -308,7 +308,7 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
             r = ternary_rows(rng, B, N, d, d)
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
-            assert eng.last_kernel() == ("k_encrypt_m" if path == 4 else "k_encrypt_m2")
+            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8", "k_encrypt_m"), 6: ("k_encrypt_m2",)}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
             ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])
@@ -332,18 +332,20 @@ def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
     r[:, :d] = 1; r[:, d:2 * d] = 2
     r = rng.permuted(r, axis=1)
     m = rng.integers(0, 3, (B, N))
-    eng.set_kernel_path(5)
-    try:
-        e, quot = eng.encrypt_batch(N, q, h, r, m)
-        assert eng.last_kernel() == "k_encrypt_m2"
-        got = eng.decrypt_batch(N, q, p, f, fp, e)
-    finally:
-        eng.set_kernel_path(0)
     e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
-    assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o)
     want = orc.decrypt_batch(N, q, p, f, fp, e_o)
-    for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
-        assert np.array_equal(g_, w_), name
+    for path, ename, dname in ((5, "k_encrypt_m8", "k_decrypt_m8"), (6, "k_encrypt_m2", "k_decrypt_m")):
+        eng.set_kernel_path(path)
+        try:
+            e, quot = eng.encrypt_batch(N, q, h, r, m)
+            assert eng.last_kernel() == ename
+            got = eng.decrypt_batch(N, q, p, f, fp, e)
+            assert eng.last_kernel() == dname
+        finally:
+            eng.set_kernel_path(0)
+        assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), path
+        for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
+            assert np.array_equal(g_, w_), (path, name)
 
 
 @pytest.mark.parametrize("N,q", [(821, 4096), (167, 128), (701, 8192)])
