@@ -3784,8 +3784,9 @@ extern "C" int ntru_decrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
                            ? (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT + (((size_t)q + 15) & ~(size_t)15) : 0;
     // lock-step variant: one workgroup of two four-wave groups per CU, phases of the two groups interleaved by barriers.
     // The default where its LDS fits and a product takes two rounds of strips (N > 512): 2.52 against 2.63 ms per 2^20 at N = 821
-    // (profiles/r02_ab_lockstep_phase_masks.txt), 2.16 against 2.24 ms at N = 701; at N = 509 (one round) it is 6 % slower.
-    if (lds && (eng->path == 5 || (eng->path == 0 && mg.NT > 16))) {
+    // (profiles/r02_ab_lockstep_phase_masks.txt), 2.16 against 2.24 ms at N = 701; at N = 509 (one round) it is 6 % slower, and so
+    // it is without the witness arrays (shorter epilogues: 2.23 against 2.02 ms).
+    if (lds && (eng->path == 5 || (eng->path == 0 && mg.NT > 16 && d_quot1 && d_rem1 && d_quot2))) {
       const size_t lds8 = 2 * ((size_t)64 * mg.pitchA + (size_t)256 * mg.NT) + (size_t)32 * mg.tpitch + (((size_t)q + 15) & ~(size_t)15);
       if (lds8 <= 160 * 1024) {
         const long nrb = (long)((B + 31) / 32);
