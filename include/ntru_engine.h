@@ -208,6 +208,23 @@ int ntru_verify_keys_batch_dev(ntru_engine_t *eng, int N, int q, int p, const in
 void *ntru_host_alloc(size_t bytes);
 void ntru_host_free(void *p);
 
+/* ---- several devices in one process (contiguous batch shards, no exchange between devices).  One engine
+ *      per listed device id (an id may be listed more than once: every entry is its own engine with its own streams), one
+ *      host thread per engine for the duration of a call; device g gets the items [g B / G, (g + 1) B / G).  Host pointers,
+ *      same meaning as the single-device entry points above; on failure the message names the shard.  (bench.py's multi-GPU
+ *      mode is one process per GPU under torchrun instead; this is for a host that owns all GPUs of a node, e.g. Node.js.) */
+typedef struct ntru_multi ntru_multi_t;
+int ntru_multi_create(const int *device_ids, int n_dev, ntru_multi_t **out);
+void ntru_multi_destroy(ntru_multi_t *m);
+int ntru_multi_engines(const ntru_multi_t *m);
+int ntru_multi_encrypt_batch(ntru_multi_t *m, int N, int q, const uint16_t *h, const uint8_t *r, const uint8_t *mm, int64_t B,
+                             uint16_t *e, uint16_t *quotE);
+int ntru_multi_decrypt_batch(ntru_multi_t *m, int N, int q, int p, const int8_t *f, const uint8_t *fp, const uint16_t *e,
+                             int64_t B, uint8_t *value, uint16_t *quot1, uint16_t *rem1, uint8_t *quot2);
+int ntru_multi_verify_keys_batch(ntru_multi_t *m, int N, int q, int p, const int8_t *f, const int8_t *g, const uint16_t *fq,
+                                 const uint8_t *fp, const uint16_t *h, int64_t B, uint16_t *quot_fq, uint16_t *rem_fq,
+                                 uint8_t *quot_fp, uint8_t *rem_fp, uint16_t *quot_h, uint16_t *rem_h, uint8_t *flags);
+
 /* ---- generic, reference-faithful family (ntru_generic.hip): the reference's own algorithms on int64 coefficients, for
  *      what the fast kernels do not cover -- moduli above 65536 (multiplyPolynomials(a, b, 2^20), test/circuits.test.js:72),
  *      arbitrary divisors (dividePolynomials, index.js:358-401, e.g. test/circuits.test.js:165-170), and the stand-alone

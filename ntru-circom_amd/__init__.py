@@ -12,7 +12,7 @@ Layout
 There is no CPU implementation in this package: everything that computes goes through the HIP library and
 raises `EngineError` when it (or a GPU) is missing.
 """
-from .engine import Engine, EngineError, library_path, load_library  # noqa: F401
+from .engine import Engine, EngineError, MultiEngine, library_path, load_library  # noqa: F401
 from . import sharding  # noqa: F401
 from .ntru import (NTRU, addCiphertexts, addPolynomials, bigintToBits, bitsToBigInt, bitsToString, degree,  # noqa: F401
                    dividePolynomials, expandArray, extendedEuclideanAlgorithm, generateCustomArray, modInverse,

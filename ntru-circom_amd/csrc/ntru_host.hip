@@ -361,3 +361,93 @@ extern "C" int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bit
     return ntru_unpack_batch_dev(eng, max_val, packed_bits, (const uint64_t *)d[ii], packed_size, n, (uint16_t *)d[io]);
   });
 }
+
+// ---- several devices in ONE process: contiguous shards, one host thread + engine (with its two streams) per device ------
+// item b depends only on (key, m[b], r[b]) / (key, e[b]) / key[b], so a host batch is cut into contiguous
+// slices [g B / G, (g + 1) B / G) and every slice runs the single-device pipeline above on its own thread; nothing is exchanged
+// between devices.  (The benchmark's multi-GPU mode is one PROCESS per GPU instead -- bench.py under torchrun; this is for a
+// host program, e.g. the Node.js addon, that owns all the GPUs of a node itself.)
+struct ntru_multi {
+  std::vector<ntru_engine_t *> eng;
+};
+
+extern "C" int ntru_multi_create(const int *device_ids, int n_dev, ntru_multi_t **out) {
+  if (!out) return ntru_fail(NTRU_ERR_ARG, "ntru_multi_create: out is NULL");
+  *out = nullptr;
+  if (!device_ids || n_dev < 1 || n_dev > 64) return ntru_fail(NTRU_ERR_ARG, "ntru_multi_create: need 1 .. 64 device ids");
+  ntru_multi *m = new ntru_multi;
+  for (int i = 0; i < n_dev; i++) {
+    ntru_engine_t *e = nullptr;
+    if (int rc = ntru_engine_create(device_ids[i], &e)) {
+      for (ntru_engine_t *x : m->eng) ntru_engine_destroy(x);
+      delete m;
+      return rc;
+    }
+    m->eng.push_back(e);
+  }
+  *out = m;
+  return NTRU_OK;
+}
+
+extern "C" void ntru_multi_destroy(ntru_multi_t *m) {
+  if (!m) return;
+  for (ntru_engine_t *e : m->eng) ntru_engine_destroy(e);
+  delete m;
+}
+
+extern "C" int ntru_multi_engines(const ntru_multi_t *m) { return m ? (int)m->eng.size() : 0; }
+
+namespace {
+// fn(engine, first item, items) on one thread per engine; the first failure (lowest shard) is what the caller sees
+template <class F>
+int for_each_shard(ntru_multi_t *m, int64_t B, F fn) {
+  if (!m) return ntru_fail(NTRU_ERR_ARG, "multi-device engine is NULL");
+  if (B < 0) return ntru_fail(NTRU_ERR_ARG, "negative batch size");
+  const int G = (int)m->eng.size();
+  std::vector<int> rc(G, NTRU_OK);
+  std::vector<std::string> msg(G);
+  std::vector<std::thread> th;
+  auto shard = [&](int g) {
+    const int64_t base = B / G, extra = B % G, lo = g * base + (g < extra ? g : extra), n = base + (g < extra ? 1 : 0);
+    rc[g] = fn(m->eng[g], lo, n);
+    if (rc[g]) msg[g] = ntru_last_error();               // the message is per thread: carry it over
+  };
+  for (int g = 1; g < G; g++) th.emplace_back(shard, g);
+  shard(0);
+  for (auto &t : th) t.join();
+  for (int g = 0; g < G; g++)
+    if (rc[g]) return ntru_fail(rc[g], "device shard " + std::to_string(g) + ": " + msg[g]);
+  return NTRU_OK;
+}
+}  // namespace
+
+extern "C" int ntru_multi_encrypt_batch(ntru_multi_t *m, int N, int q, const uint16_t *h, const uint8_t *r, const uint8_t *mm,
+                                        int64_t B, uint16_t *e, uint16_t *quotE) {
+  return for_each_shard(m, B, [&](ntru_engine_t *eng, int64_t lo, int64_t n) {
+    const size_t o = (size_t)lo * N;
+    return ntru_encrypt_batch(eng, N, q, h, r ? r + o : r, mm ? mm + o : mm, n, e ? e + o : e, quotE ? quotE + o : nullptr);
+  });
+}
+
+extern "C" int ntru_multi_decrypt_batch(ntru_multi_t *m, int N, int q, int p, const int8_t *f, const uint8_t *fp,
+                                        const uint16_t *e, int64_t B, uint8_t *value, uint16_t *quot1, uint16_t *rem1,
+                                        uint8_t *quot2) {
+  return for_each_shard(m, B, [&](ntru_engine_t *eng, int64_t lo, int64_t n) {
+    const size_t o = (size_t)lo * N;
+    return ntru_decrypt_batch(eng, N, q, p, f, fp, e ? e + o : e, n, value ? value + o : value, quot1 ? quot1 + o : nullptr,
+                              rem1 ? rem1 + o : nullptr, quot2 ? quot2 + o : nullptr);
+  });
+}
+
+extern "C" int ntru_multi_verify_keys_batch(ntru_multi_t *m, int N, int q, int p, const int8_t *f, const int8_t *g,
+                                            const uint16_t *fq, const uint8_t *fp, const uint16_t *h, int64_t B,
+                                            uint16_t *quot_fq, uint16_t *rem_fq, uint8_t *quot_fp, uint8_t *rem_fp,
+                                            uint16_t *quot_h, uint16_t *rem_h, uint8_t *flags) {
+  if (B > 0 && (!f || !g || !fq || !fp || !h || !quot_fq || !rem_fq || !quot_fp || !rem_fp || !quot_h || !rem_h || !flags))
+    return ntru_fail(NTRU_ERR_ARG, "ntru_multi_verify_keys_batch: NULL buffer");
+  return for_each_shard(m, B, [&](ntru_engine_t *eng, int64_t lo, int64_t n) {
+    const size_t o = (size_t)lo * N;
+    return ntru_verify_keys_batch(eng, N, q, p, f + o, g + o, fq + o, fp + o, h + o, n, quot_fq + o, rem_fq + o, quot_fp + o,
+                                  rem_fp + o, quot_h + o, rem_h + o, flags + lo);
+  });
+}

@@ -62,6 +62,12 @@ _SIGS["ntru_generic_multiply"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _
 _SIGS["ntru_generic_divide"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp])
 _SIGS["ntru_generic_eea"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp])
 _SIGS["ntru_generic_poly_inv"] = (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _vp, _vp])
+_SIGS["ntru_multi_create"] = (C.c_int, [_vp, _i, C.POINTER(_vp)])
+_SIGS["ntru_multi_destroy"] = (None, [_vp])
+_SIGS["ntru_multi_engines"] = (C.c_int, [_vp])
+_SIGS["ntru_multi_encrypt_batch"] = (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
+_SIGS["ntru_multi_decrypt_batch"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
+_SIGS["ntru_multi_verify_keys_batch"] = (C.c_int, [_vp, _i, _i, _i] + [_vp] * 5 + [_i64] + [_vp] * 7)
 _SIGS["ntru_encrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
 _SIGS["ntru_decrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
 
@@ -371,3 +377,72 @@ class Engine:
         self._chk(self._lib.ntru_verify_keys_batch_dev(self._h, N, q, p, dp(d_f), dp(d_g), dp(d_fq), dp(d_fp), dp(d_h),
                                                        B, dp(d_quot_fq), dp(d_rem_fq), dp(d_quot_fp), dp(d_rem_fp),
                                                        dp(d_quot_h), dp(d_rem_h), dp(d_flags)))
+
+
+class MultiEngine:
+    """Several devices in one process (ntru_multi_*): a host batch is cut into contiguous shards, one engine + host thread per
+    listed device id (an id may repeat).  Host numpy arrays in and out, same results as Engine."""
+
+    def __init__(self, device_ids):
+        self._lib = load_library()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        self._h = None
+        rc = self._lib.ntru_multi_create(ids, len(device_ids), C.byref(h))
+        if rc:
+            raise EngineError(rc, self._lib.ntru_last_error().decode())
+        self._h = h
+
+    def _chk(self, rc):
+        if rc:
+            raise EngineError(rc, self._lib.ntru_last_error().decode())
+
+    def close(self):
+        if self._h is not None:
+            self._lib.ntru_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def engines(self):
+        return int(self._lib.ntru_multi_engines(self._h))
+
+    def encrypt_batch(self, N, q, h, r, m, want_quot=True):
+        h = _np(h, np.uint16, (N,))
+        r, m = _np(r, np.uint8).reshape(-1, N), _np(m, np.uint8).reshape(-1, N)
+        B = r.shape[0]
+        e = np.empty((B, N), np.uint16)
+        quot = np.empty((B, N), np.uint16) if want_quot else None
+        self._chk(self._lib.ntru_multi_encrypt_batch(self._h, N, q, _ptr(h), _ptr(r), _ptr(m), B, _ptr(e), _ptr(quot)))
+        return e, quot
+
+    def decrypt_batch(self, N, q, p, f, fp, e, want_witness=True):
+        f, fp = _np(f, np.int8, (N,)), _np(fp, np.uint8, (N,))
+        e = _np(e, np.uint16).reshape(-1, N)
+        B = e.shape[0]
+        value = np.empty((B, N), np.uint8)
+        q1 = np.empty((B, N), np.uint16) if want_witness else None
+        r1 = np.empty((B, N), np.uint16) if want_witness else None
+        q2 = np.empty((B, N), np.uint8) if want_witness else None
+        self._chk(self._lib.ntru_multi_decrypt_batch(self._h, N, q, p, _ptr(f), _ptr(fp), _ptr(e), B, _ptr(value),
+                                                     _ptr(q1), _ptr(r1), _ptr(q2)))
+        return value, q1, r1, q2
+
+    def verify_keys_batch(self, N, q, p, f, g, fq, fp, h):
+        f, g = _np(f, np.int8).reshape(-1, N), _np(g, np.int8).reshape(-1, N)
+        fq, h = _np(fq, np.uint16).reshape(-1, N), _np(h, np.uint16).reshape(-1, N)
+        fp = _np(fp, np.uint8).reshape(-1, N)
+        B = f.shape[0]
+        out = {"quot_fq": np.empty((B, N), np.uint16), "rem_fq": np.empty((B, N), np.uint16),
+               "quot_fp": np.empty((B, N), np.uint8), "rem_fp": np.empty((B, N), np.uint8),
+               "quot_h": np.empty((B, N), np.uint16), "rem_h": np.empty((B, N), np.uint16),
+               "flags": np.empty(B, np.uint8)}
+        self._chk(self._lib.ntru_multi_verify_keys_batch(self._h, N, q, p, _ptr(f), _ptr(g), _ptr(fq), _ptr(fp), _ptr(h), B,
+                                                         _ptr(out["quot_fq"]), _ptr(out["rem_fq"]), _ptr(out["quot_fp"]),
+                                                         _ptr(out["rem_fp"]), _ptr(out["quot_h"]), _ptr(out["rem_h"]),
+                                                         _ptr(out["flags"])))
+        return out

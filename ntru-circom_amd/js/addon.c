@@ -23,6 +23,7 @@
   } while (0)
 
 static ntru_engine_t *g_engine = NULL;
+static ntru_multi_t *g_multi = NULL;     /* useDevices([...]): the batch entry points shard over these devices instead */
 
 static napi_value throw_engine(napi_env env, int rc) {
   char buf[512];
@@ -83,7 +84,24 @@ static napi_value Create(napi_env env, napi_callback_info info) {
 static napi_value Destroy(napi_env env, napi_callback_info info) {
   (void)info;
   if (g_engine) { ntru_engine_destroy(g_engine); g_engine = NULL; }
+  if (g_multi) { ntru_multi_destroy(g_multi); g_multi = NULL; }
   return undefined(env);
+}
+
+/* useDevices(ids:Int32Array) -> number of engines.  An empty array goes back to the single engine of create(). */
+static napi_value UseDevices(napi_env env, napi_callback_info info) {
+  ARGS(1)
+  bool is_ta = false;
+  if (napi_is_typedarray(env, argv[0], &is_ta) != napi_ok || !is_ta) BAD_ARGS();
+  napi_typedarray_type t; size_t len; void *data;
+  NAPI_OK(napi_get_typedarray_info(env, argv[0], &t, &len, &data, NULL, NULL));
+  if (t != napi_int32_array || len > 64) BAD_ARGS();
+  if (g_multi) { ntru_multi_destroy(g_multi); g_multi = NULL; }
+  if (len) {
+    int rc = ntru_multi_create((const int *)data, (int)len, &g_multi);
+    if (rc) return throw_engine(env, rc);
+  }
+  napi_value r; NAPI_OK(napi_create_int32(env, ntru_multi_engines(g_multi), &r)); return r;
 }
 
 static napi_value Supports(napi_env env, napi_callback_info info) {
@@ -170,7 +188,8 @@ static napi_value EncryptBatch(napi_env env, napi_callback_info info) {
       !get_buf(env, argv[4], napi_uint8_array, n, 0, &m) || !get_buf(env, argv[6], napi_uint16_array, n, 0, &e) ||
       !get_buf(env, argv[7], napi_uint16_array, n, 1, &quot)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_encrypt_batch(g_engine, N, q, h, r, m, B, e, quot);
+  int rc = g_multi ? ntru_multi_encrypt_batch(g_multi, N, q, h, r, m, B, e, quot)
+                   : ntru_encrypt_batch(g_engine, N, q, h, r, m, B, e, quot);
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -187,7 +206,8 @@ static napi_value DecryptBatch(napi_env env, napi_callback_info info) {
       !get_buf(env, argv[8], napi_uint16_array, n, 1, &q1) || !get_buf(env, argv[9], napi_uint16_array, n, 1, &r1) ||
       !get_buf(env, argv[10], napi_uint8_array, n, 1, &q2)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_decrypt_batch(g_engine, N, q, p, f, fp, e, B, value, q1, r1, q2);
+  int rc = g_multi ? ntru_multi_decrypt_batch(g_multi, N, q, p, f, fp, e, B, value, q1, r1, q2)
+                   : ntru_decrypt_batch(g_engine, N, q, p, f, fp, e, B, value, q1, r1, q2);
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -206,7 +226,8 @@ static napi_value VerifyKeysBatch(napi_env env, napi_callback_info info) {
       !get_buf(env, argv[12], napi_uint8_array, n, 0, &o4) || !get_buf(env, argv[13], napi_uint16_array, n, 0, &o5) ||
       !get_buf(env, argv[14], napi_uint16_array, n, 0, &o6) || !get_buf(env, argv[15], napi_uint8_array, (size_t)B, 0, &fl)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_verify_keys_batch(g_engine, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl);
+  int rc = g_multi ? ntru_multi_verify_keys_batch(g_multi, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl)
+                   : ntru_verify_keys_batch(g_engine, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl);
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -303,7 +324,7 @@ static napi_value GenericOp(napi_env env, napi_callback_info info) {
   size_t la = 0, lb = 0;
   napi_typedarray_type t; bool is_ta = false;
   if (!get_i32(env, argv[0], &op) || op < 0 || op > 3 || napi_get_value_double(env, argv[3], &mod) != napi_ok ||
-      mod != (double)(int64_t)mod) BAD_ARGS();
+      !(mod >= 1.0 && mod <= 9007199254740992.0) || mod != (double)(int64_t)mod) BAD_ARGS();
   if (napi_is_typedarray(env, argv[1], &is_ta) != napi_ok || !is_ta ||
       napi_get_typedarray_info(env, argv[1], &t, &la, &a, NULL, NULL) != napi_ok || t != napi_float64_array) BAD_ARGS();
   if (napi_is_typedarray(env, argv[2], &is_ta) != napi_ok || !is_ta ||
@@ -315,15 +336,14 @@ static napi_value GenericOp(napi_env env, napi_callback_info info) {
   int64_t *buf = (int64_t *)malloc((la + lb + 2 * cap + 2) * sizeof(int64_t));
   if (!buf) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
   int64_t *ia = buf, *ib = ia + la + 1, *r0 = ib + lb + 1, *r1 = r0 + cap;
-  for (size_t i = 0; i < la; i++) {
-    const double v = ((double *)a)[i];
-    if (v != (double)(int64_t)v) { free(buf); napi_throw_type_error(env, NULL, "coefficients must be integers"); return NULL; }
-    ia[i] = (int64_t)v;
-  }
-  for (size_t i = 0; i < lb; i++) {
-    const double v = ((double *)b)[i];
-    if (v != (double)(int64_t)v) { free(buf); napi_throw_type_error(env, NULL, "coefficients must be integers"); return NULL; }
-    ib[i] = (int64_t)v;
+  for (size_t i = 0; i < la + lb; i++) {                      /* doubles -> int64: integers only, and only where the cast is defined */
+    const double v = i < la ? ((double *)a)[i] : ((double *)b)[i - la];
+    if (!(v >= -9007199254740992.0 && v <= 9007199254740992.0) || v != (double)(int64_t)v) {
+      free(buf);
+      napi_throw_type_error(env, NULL, "coefficients must be integers");
+      return NULL;
+    }
+    if (i < la) ia[i] = (int64_t)v; else ib[i - la] = (int64_t)v;
   }
   int32_t len0 = 0, len1 = 0; uint8_t st = 0;
   int rc;
@@ -348,6 +368,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
     {"create", NULL, Create, NULL, NULL, NULL, napi_default, NULL},
     {"destroy", NULL, Destroy, NULL, NULL, NULL, napi_default, NULL},
+    {"useDevices", NULL, UseDevices, NULL, NULL, NULL, napi_default, NULL},
     {"supports", NULL, Supports, NULL, NULL, NULL, napi_default, NULL},
     {"polymulSplit", NULL, PolymulSplit, NULL, NULL, NULL, napi_default, NULL},
     {"splitByI", NULL, SplitByI, NULL, NULL, NULL, napi_default, NULL},

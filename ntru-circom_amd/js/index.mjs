@@ -410,6 +410,9 @@ export default class NTRU {
 
   // ---- additive batch API (typed arrays, fixed stride N; see include/ntru_engine.h for the layout) -----------
   // Page-locked typed arrays (ntru_host_alloc): the batch calls DMA straight from / to them, no staging copy.
+  // NTRU.useDevices([0, 1, ...]): encryptBatch / decryptBatch / verifyKeysInputs batches are cut into contiguous shards, one
+  // engine + host thread per listed device (ntru_multi_*); [] goes back to the single device.  Returns the engine count.
+  static useDevices(ids) { return engine().useDevices(Int32Array.from(ids)); }
   static allocUint8(n) { return new Uint8Array(engine().allocPinned(n), 0, n); }
   static allocUint16(n) { return new Uint16Array(engine().allocPinned(2 * n), 0, n); }
 

@@ -173,4 +173,21 @@ deepStrictEqual(lib.stringToBits('Hello World'), pure.misc.stringToBits[0].out);
   deepStrictEqual(Array.from(dec.value), Array.from(m));       // q = 128 = 2 mod 3: round trip holds
 }
 
+// several devices in one process (NTRU.useDevices -> ntru_multi_*): the device is listed three times here (three engines,
+// three host threads, three contiguous shards); results must equal the single-engine ones
+{
+  const g = golden('scheme_n167_q128.json'); const key = g.keys[0]; const N = g.options.N;
+  const ntru = new NTRU({ ...g.options, f: key.f, fp: key.fp, h: key.h });
+  const B = 1000;
+  const r = ntru.sampleR(Uint32Array.from([9, 8, 7, 6, 5, 4, 3, 2]), 0, B);
+  const m = new Uint8Array(B * N); for (let i = 0; i < m.length; i++) m[i] = (i * 7 + (i >> 5)) % 3;
+  const enc1 = ntru.encryptBatch(r, m, B), dec1 = ntru.decryptBatch(enc1.e, B);
+  strictEqual(NTRU.useDevices([0, 0, 0]), 3);
+  const enc3 = ntru.encryptBatch(r, m, B), dec3 = ntru.decryptBatch(enc3.e, B);
+  strictEqual(NTRU.useDevices([]), 0);
+  for (const k of ['e', 'quotientE']) strictEqual(Buffer.compare(Buffer.from(enc1[k].buffer), Buffer.from(enc3[k].buffer)), 0);
+  for (const k of ['value', 'quotient1', 'remainder1', 'quotient2'])
+    strictEqual(Buffer.compare(Buffer.from(dec1[k].buffer), Buffer.from(dec3[k].buffer)), 0);
+}
+
 console.log(`shim_golden: ${checks} scheme checks, ${nMul} multiply and ${nDiv} divide vectors OK`);

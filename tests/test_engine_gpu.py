@@ -958,3 +958,95 @@ def test_host_pipeline_many_chunks_equal_oracle(eng, pinned):
     s = eng.sample_ternary(N, d, d, 2, key, 10, B)
     assert np.array_equal(s[B - 1], orc.sample_ternary_batch(N, d, d, 2, key, 10 + B - 1, 1)[0])      # first_item advances per chunk
     assert np.array_equal(s[0], orc.sample_ternary_batch(N, d, d, 2, key, 10, 1)[0])
+
+
+def test_generic_family_random_differential(eng):
+    """300 random (lengths, modulus, signed / unreduced coefficients) per operation against the Python restatement: long
+    division, the Euclidean algorithm and polyInv with every status the reference can raise; moduli prime, composite, powers
+    of two, 1; operands shorter and longer than each other, zero polynomials, trailing zeros."""
+    from oracle import ntru_keygen as kg
+    rng = np.random.default_rng(777)
+    mods = [1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 15, 16, 31, 32, 64, 97, 128, 255, 256, 1000, 4096, 65537, 1 << 20, (1 << 26)]
+    seen = set()
+    for trial in range(300):
+        p = int(rng.choice(mods))
+        la, lb = int(rng.integers(0, 24)), int(rng.integers(1, 24))
+        span = min(int(rng.choice([1, 2, p, 3 * p])), 1 << 26)     # the family's documented operand bound
+        a = rng.integers(-span, span + 1, la)
+        b = rng.integers(-span if trial % 3 == 0 else 0, span + 1, lb)
+        if trial % 7 == 0:
+            b[lb // 2:] = 0                                  # degree below the length; sometimes the zero polynomial
+        if trial % 11 == 0 and la:
+            a[la // 2:] = 0
+        quot, rem, st = eng.generic_divide(a, b, p)
+        try:
+            qo, ro = kg._divide(a, b, p)
+            assert st[0] == 0 and quot[0] == qo.tolist() and rem[0] == ro.tolist(), (trial, p, a, b)
+        except ZeroDivisionError:
+            assert st[0] == 1, (trial, p, a, b)
+        except ArithmeticError:
+            assert st[0] == 2, (trial, p, a, b)
+        seen.add(int(st[0]))
+        gcd, inv, st2 = eng.generic_eea(a, b, p)
+        try:
+            go, io = kg.extended_euclid(a, b, p, True)
+            assert st2[0] == 0 and gcd[0] == go.tolist() and inv[0] == io.tolist(), (trial, p, a, b)
+        except kg.InvalidGcd:
+            assert st2[0] == 3, (trial, p, a, b)
+        except ZeroDivisionError:
+            assert st2[0] == 1
+        except ArithmeticError:
+            assert st2[0] == 2, (trial, p, a, b)
+        seen.add(10 + int(st2[0]))
+        if lb >= 3 and p <= 4096:
+            I = np.zeros(lb, np.int64); I[0] = 1; I[-1] = -1
+            f = rng.integers(-1, 2, min(la, lb - 1))
+            got, st3 = eng.generic_poly_inv(f, I, p)
+            try:
+                want = kg.poly_inv_generic(f, I, p).tolist()
+                assert st3[0] == 0 and got[0] == want, (trial, p, f)
+            except kg.InvalidGcd:
+                assert st3[0] == 3, (trial, p, f)
+            except ZeroDivisionError:
+                assert st3[0] == 1
+            except ArithmeticError:
+                assert st3[0] == 2, (trial, p, f)
+        prod = eng.generic_multiply(a, b, p)
+        assert prod[0] == kg._multiply(a, b, p).tolist()
+    assert {0, 1, 2, 10, 12, 13} <= seen                     # every status was exercised
+
+
+def test_multi_device_host_api_shards_equal_oracle():
+    """ntru_multi_* (several devices in one process, contiguous shards, one host thread per engine).  The box has one GPU, so
+    the device list names it three times: three engines, three threads, three shards of unequal size -- the sharding,
+    threading and error plumbing are what is under test; results against the oracle."""
+    me = pkg.MultiEngine([0, 0, 0])
+    assert me.engines() == 3
+    N, q, p, d = 167, 128, 3, 18
+    rng = np.random.default_rng(31)
+    B = 10001                                               # 3334 + 3334 + 3333
+    h = rng.integers(0, q, N); fp = rng.integers(0, p, N)
+    f = ternary_rows(rng, 1, N, 61, 60, two=-1)[0]
+    base = np.zeros(N, np.uint8); base[:d] = 1; base[d:2 * d] = 2
+    r = rng.permuted(np.tile(base, (B, 1)), axis=1)
+    m = rng.integers(0, 3, (B, N)).astype(np.uint8)
+    e, quot = me.encrypt_batch(N, q, h, r, m)
+    e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
+    assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o)
+    got = me.decrypt_batch(N, q, p, f, fp, e)
+    want = orc.decrypt_batch(N, q, p, f, fp, e_o)
+    for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
+        assert np.array_equal(g_, w_), name
+    Bk = 50
+    kf = ternary_rows(rng, Bk, N, 61, 60, two=-1); kg_ = ternary_rows(rng, Bk, N, 20, 20, two=-1)
+    kfq = rng.integers(0, q, (Bk, N)); kfp = rng.integers(0, p, (Bk, N)); kh = rng.integers(0, q, (Bk, N))
+    outv = me.verify_keys_batch(N, q, p, kf, kg_, kfq, kfp, kh)
+    wantv = orc.verify_keys_batch(N, q, p, kf, kg_, kfq, kfp, kh)
+    for k in wantv:
+        assert np.array_equal(outv[k], wantv[k]), k
+    assert me.encrypt_batch(N, q, h, r[:2], m[:2])[0].shape == (2, N)          # fewer items than engines: empty shards
+    with pytest.raises(pkg.EngineError, match="device shard 0"):
+        me.encrypt_batch(N, 12, h, r[:5], m[:5])                               # q = 12: refused, the message names the shard
+    me.close()
+    with pytest.raises(pkg.EngineError):
+        pkg.MultiEngine([0, 99])                                               # no such device

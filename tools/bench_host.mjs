@@ -19,6 +19,7 @@ import NTRU from '../ntru-circom_amd/js/index.mjs';
 const here = dirname(fileURLToPath(import.meta.url));
 const arg = (name, dflt) => { const i = process.argv.indexOf(name); return i > 0 ? process.argv[i + 1] : dflt; };
 const log2 = Number(arg('--log2', 18)), iters = Number(arg('--iters', 5)), profile = arg('--profile', 'n821_q4096');
+const devices = arg('--devices', '');   // e.g. 0,1,2,3: shard the batches over several devices (ntru_multi_*)
 const PCIE_GBS = 63.0;       // PCIe Gen5 x16, one direction (the figure DESIGN.md section 5 uses)
 
 const g = JSON.parse(readFileSync(join(here, '..', 'tests', 'golden', `scheme_${profile}.json`), 'utf8'));
@@ -55,6 +56,7 @@ function roundTrips(alloc8, alloc16) {
     checksum: decOut.value.reduce((s, x) => (s + x) >>> 0, 0) + encOut.e[encOut.e.length - 1] };
 }
 
+if (devices) NTRU.useDevices(devices.split(',').map(Number));
 const pinned = roundTrips(n => NTRU.allocUint8(n), n => NTRU.allocUint16(n));
 const pageable = roundTrips(n => new Uint8Array(n), n => new Uint16Array(n));
 if (pinned.checksum !== pageable.checksum) throw new Error('pinned and pageable paths disagree');
@@ -69,7 +71,7 @@ const verLat = lat(() => { ntru.verifyKeysInputs(); }, 50);
 
 console.log(JSON.stringify({
   what: 'host-inclusive Node.js path: encryptBatch + decryptBatch, full witness, host TypedArrays in and out',
-  N, q: ntru.q, batch: B, iters, host_cpus: cpus().length, pcie_roof_GBs_one_direction: PCIE_GBS,
+  N, q: ntru.q, batch: B, iters, devices: devices || 'single', host_cpus: cpus().length, pcie_roof_GBs_one_direction: PCIE_GBS,
   bound_round_trips_per_s_at_14N_over_pcie: PCIE_GBS * 1e9 / (14 * N),
   pinned, pageable,
   single_call_latency: { encryptBits: encLat, decryptBits: decLat, verifyKeysInputs: verLat,
