@@ -224,6 +224,12 @@ int ntru_multi_decrypt_batch(ntru_multi_t *m, int N, int q, int p, const int8_t 
 int ntru_multi_verify_keys_batch(ntru_multi_t *m, int N, int q, int p, const int8_t *f, const int8_t *g, const uint16_t *fq,
                                  const uint8_t *fp, const uint16_t *h, int64_t B, uint16_t *quot_fq, uint16_t *rem_fq,
                                  uint8_t *quot_fp, uint8_t *rem_fp, uint16_t *quot_h, uint16_t *rem_h, uint8_t *flags);
+int ntru_multi_polymul_split(ntru_multi_t *m, int N, int mod, const uint16_t *a, const uint16_t *b, int64_t B, uint16_t *quot,
+                             uint16_t *rem);
+int ntru_multi_invert_key_batch(ntru_multi_t *m, int N, int q, int p, const int8_t *f, int64_t B, uint16_t *fq, uint8_t *fp,
+                                uint8_t *flags);
+int ntru_multi_public_key_batch(ntru_multi_t *m, int N, int q, int p, const uint16_t *fq, const int8_t *g, int64_t B,
+                                uint16_t *h);
 
 /* ---- generic, reference-faithful family (ntru_generic.hip): the reference's own algorithms on int64 coefficients, for
  *      what the fast kernels do not cover -- moduli above 65536 (multiplyPolynomials(a, b, 2^20), test/circuits.test.js:72),

@@ -451,3 +451,30 @@ extern "C" int ntru_multi_verify_keys_batch(ntru_multi_t *m, int N, int q, int p
                                   rem_fp + o, quot_h + o, rem_h + o, flags + lo);
   });
 }
+
+extern "C" int ntru_multi_polymul_split(ntru_multi_t *m, int N, int mod, const uint16_t *a, const uint16_t *b, int64_t B,
+                                        uint16_t *quot, uint16_t *rem) {
+  if (B > 0 && (!a || !b || !quot || !rem)) return ntru_fail(NTRU_ERR_ARG, "ntru_multi_polymul_split: NULL buffer");
+  return for_each_shard(m, B, [&](ntru_engine_t *eng, int64_t lo, int64_t n) {
+    const size_t o = (size_t)lo * N;
+    return ntru_polymul_split(eng, N, mod, a + o, b + o, n, quot + o, rem + o);
+  });
+}
+
+extern "C" int ntru_multi_invert_key_batch(ntru_multi_t *m, int N, int q, int p, const int8_t *f, int64_t B, uint16_t *fq,
+                                           uint8_t *fp, uint8_t *flags) {
+  if (B > 0 && (!f || !flags)) return ntru_fail(NTRU_ERR_ARG, "ntru_multi_invert_key_batch: NULL buffer");
+  return for_each_shard(m, B, [&](ntru_engine_t *eng, int64_t lo, int64_t n) {
+    const size_t o = (size_t)lo * N;
+    return ntru_invert_key_batch(eng, N, q, p, f + o, n, fq ? fq + o : nullptr, fp ? fp + o : nullptr, flags + lo);
+  });
+}
+
+extern "C" int ntru_multi_public_key_batch(ntru_multi_t *m, int N, int q, int p, const uint16_t *fq, const int8_t *g, int64_t B,
+                                           uint16_t *h) {
+  if (B > 0 && (!fq || !g || !h)) return ntru_fail(NTRU_ERR_ARG, "ntru_multi_public_key_batch: NULL buffer");
+  return for_each_shard(m, B, [&](ntru_engine_t *eng, int64_t lo, int64_t n) {
+    const size_t o = (size_t)lo * N;
+    return ntru_public_key_batch(eng, N, q, p, fq + o, g + o, n, h + o);
+  });
+}

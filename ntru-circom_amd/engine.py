@@ -68,6 +68,9 @@ _SIGS["ntru_multi_engines"] = (C.c_int, [_vp])
 _SIGS["ntru_multi_encrypt_batch"] = (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
 _SIGS["ntru_multi_decrypt_batch"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
 _SIGS["ntru_multi_verify_keys_batch"] = (C.c_int, [_vp, _i, _i, _i] + [_vp] * 5 + [_i64] + [_vp] * 7)
+_SIGS["ntru_multi_polymul_split"] = (C.c_int, [_vp, _i, _i, _vp, _vp, _i64, _vp, _vp])
+_SIGS["ntru_multi_invert_key_batch"] = (C.c_int, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp])
+_SIGS["ntru_multi_public_key_batch"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp])
 _SIGS["ntru_encrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
 _SIGS["ntru_decrypt_batch_pitched_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
 
@@ -446,3 +449,24 @@ class MultiEngine:
                                                          _ptr(out["rem_fp"]), _ptr(out["quot_h"]), _ptr(out["rem_h"]),
                                                          _ptr(out["flags"])))
         return out
+
+    def polymul_split(self, N, mod, a, b):
+        a, b = _np(a, np.uint16).reshape(-1, N), _np(b, np.uint16).reshape(-1, N)
+        B = a.shape[0]
+        quot, rem = np.empty((B, N), np.uint16), np.empty((B, N), np.uint16)
+        self._chk(self._lib.ntru_multi_polymul_split(self._h, N, mod, _ptr(a), _ptr(b), B, _ptr(quot), _ptr(rem)))
+        return quot, rem
+
+    def invert_key_batch(self, N, q, p, f):
+        f = _np(f, np.int8).reshape(-1, N)
+        B = f.shape[0]
+        fq, fp, flags = np.empty((B, N), np.uint16), np.empty((B, N), np.uint8), np.empty(B, np.uint8)
+        self._chk(self._lib.ntru_multi_invert_key_batch(self._h, N, q, p, _ptr(f), B, _ptr(fq), _ptr(fp), _ptr(flags)))
+        return fq, fp, flags
+
+    def public_key_batch(self, N, q, p, fq, g):
+        fq, g = _np(fq, np.uint16).reshape(-1, N), _np(g, np.int8).reshape(-1, N)
+        B = fq.shape[0]
+        h = np.empty((B, N), np.uint16)
+        self._chk(self._lib.ntru_multi_public_key_batch(self._h, N, q, p, _ptr(fq), _ptr(g), B, _ptr(h)))
+        return h

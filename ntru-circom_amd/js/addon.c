@@ -7,6 +7,7 @@
  */
 #define NAPI_VERSION 6
 #include <node_api.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +25,9 @@
 
 static ntru_engine_t *g_engine = NULL;
 static ntru_multi_t *g_multi = NULL;     /* useDevices([...]): the batch entry points shard over these devices instead */
+/* One engine, one caller at a time: the *Async entry points run on libuv worker threads, everything else on the JS thread. */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+#define ENGINE_CALL(rc, expr) do { pthread_mutex_lock(&g_lock); (rc) = (expr); pthread_mutex_unlock(&g_lock); } while (0)
 
 static napi_value throw_engine(napi_env env, int rc) {
   char buf[512];
@@ -75,16 +79,20 @@ static napi_value Create(napi_env env, napi_callback_info info) {
   ARGS(1)
   int32_t dev;
   if (!get_i32(env, argv[0], &dev)) BAD_ARGS();
+  pthread_mutex_lock(&g_lock);
   if (g_engine) { ntru_engine_destroy(g_engine); g_engine = NULL; }
   int rc = ntru_engine_create(dev, &g_engine);
+  pthread_mutex_unlock(&g_lock);
   if (rc) return throw_engine(env, rc);
   return undefined(env);
 }
 
 static napi_value Destroy(napi_env env, napi_callback_info info) {
   (void)info;
+  pthread_mutex_lock(&g_lock);
   if (g_engine) { ntru_engine_destroy(g_engine); g_engine = NULL; }
   if (g_multi) { ntru_multi_destroy(g_multi); g_multi = NULL; }
+  pthread_mutex_unlock(&g_lock);
   return undefined(env);
 }
 
@@ -96,11 +104,11 @@ static napi_value UseDevices(napi_env env, napi_callback_info info) {
   napi_typedarray_type t; size_t len; void *data;
   NAPI_OK(napi_get_typedarray_info(env, argv[0], &t, &len, &data, NULL, NULL));
   if (t != napi_int32_array || len > 64) BAD_ARGS();
+  pthread_mutex_lock(&g_lock);
   if (g_multi) { ntru_multi_destroy(g_multi); g_multi = NULL; }
-  if (len) {
-    int rc = ntru_multi_create((const int *)data, (int)len, &g_multi);
-    if (rc) return throw_engine(env, rc);
-  }
+  int rc = len ? ntru_multi_create((const int *)data, (int)len, &g_multi) : 0;
+  pthread_mutex_unlock(&g_lock);
+  if (rc) return throw_engine(env, rc);
   napi_value r; NAPI_OK(napi_create_int32(env, ntru_multi_engines(g_multi), &r)); return r;
 }
 
@@ -120,7 +128,8 @@ static napi_value PolymulSplit(napi_env env, napi_callback_info info) {
   if (!get_buf(env, argv[2], napi_uint16_array, n, 0, &a) || !get_buf(env, argv[3], napi_uint16_array, n, 0, &b) ||
       !get_buf(env, argv[5], napi_uint16_array, n, 0, &quot) || !get_buf(env, argv[6], napi_uint16_array, n, 0, &rem)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_polymul_split(g_engine, N, mod, a, b, B, quot, rem);
+  int rc;
+  ENGINE_CALL(rc, ntru_polymul_split(g_engine, N, mod, a, b, B, quot, rem));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -133,7 +142,8 @@ static napi_value SplitByI(napi_env env, napi_callback_info info) {
   if (!get_buf(env, argv[2], napi_uint16_array, 2 * n, 0, &a) || !get_buf(env, argv[4], napi_uint16_array, n, 0, &quot) ||
       !get_buf(env, argv[5], napi_uint16_array, n, 0, &rem)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_split_by_I(g_engine, N, mod, a, B, quot, rem);
+  int rc;
+  ENGINE_CALL(rc, ntru_split_by_I(g_engine, N, mod, a, B, quot, rem));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -146,7 +156,8 @@ static napi_value AddBatch(napi_env env, napi_callback_info info) {
   if (!get_buf(env, argv[2], napi_uint16_array, n, 0, &a) || !get_buf(env, argv[3], napi_uint16_array, n, 0, &b) ||
       !get_buf(env, argv[5], napi_uint16_array, n, 0, &out)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_add_batch(g_engine, N, mod, a, b, B, out);
+  int rc;
+  ENGINE_CALL(rc, ntru_add_batch(g_engine, N, mod, a, b, B, out));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -160,7 +171,8 @@ static napi_value InvertKeyBatch(napi_env env, napi_callback_info info) {
   if (!get_buf(env, argv[3], napi_int8_array, n, 0, &f) || !get_buf(env, argv[5], napi_uint16_array, n, 1, &fq) ||
       !get_buf(env, argv[6], napi_uint8_array, n, 1, &fp) || !get_buf(env, argv[7], napi_uint8_array, (size_t)B, 0, &flags)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_invert_key_batch(g_engine, N, q, p, f, B, fq, fp, flags);
+  int rc;
+  ENGINE_CALL(rc, ntru_invert_key_batch(g_engine, N, q, p, f, B, fq, fp, flags));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -174,7 +186,8 @@ static napi_value PublicKeyBatch(napi_env env, napi_callback_info info) {
   if (!get_buf(env, argv[3], napi_uint16_array, n, 0, &fq) || !get_buf(env, argv[4], napi_int8_array, n, 0, &g) ||
       !get_buf(env, argv[6], napi_uint16_array, n, 0, &h)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_public_key_batch(g_engine, N, q, p, fq, g, B, h);
+  int rc;
+  ENGINE_CALL(rc, ntru_public_key_batch(g_engine, N, q, p, fq, g, B, h));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -188,8 +201,9 @@ static napi_value EncryptBatch(napi_env env, napi_callback_info info) {
       !get_buf(env, argv[4], napi_uint8_array, n, 0, &m) || !get_buf(env, argv[6], napi_uint16_array, n, 0, &e) ||
       !get_buf(env, argv[7], napi_uint16_array, n, 1, &quot)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = g_multi ? ntru_multi_encrypt_batch(g_multi, N, q, h, r, m, B, e, quot)
-                   : ntru_encrypt_batch(g_engine, N, q, h, r, m, B, e, quot);
+  int rc;
+  ENGINE_CALL(rc, g_multi ? ntru_multi_encrypt_batch(g_multi, N, q, h, r, m, B, e, quot)
+                   : ntru_encrypt_batch(g_engine, N, q, h, r, m, B, e, quot));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -206,8 +220,9 @@ static napi_value DecryptBatch(napi_env env, napi_callback_info info) {
       !get_buf(env, argv[8], napi_uint16_array, n, 1, &q1) || !get_buf(env, argv[9], napi_uint16_array, n, 1, &r1) ||
       !get_buf(env, argv[10], napi_uint8_array, n, 1, &q2)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = g_multi ? ntru_multi_decrypt_batch(g_multi, N, q, p, f, fp, e, B, value, q1, r1, q2)
-                   : ntru_decrypt_batch(g_engine, N, q, p, f, fp, e, B, value, q1, r1, q2);
+  int rc;
+  ENGINE_CALL(rc, g_multi ? ntru_multi_decrypt_batch(g_multi, N, q, p, f, fp, e, B, value, q1, r1, q2)
+                   : ntru_decrypt_batch(g_engine, N, q, p, f, fp, e, B, value, q1, r1, q2));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -226,8 +241,9 @@ static napi_value VerifyKeysBatch(napi_env env, napi_callback_info info) {
       !get_buf(env, argv[12], napi_uint8_array, n, 0, &o4) || !get_buf(env, argv[13], napi_uint16_array, n, 0, &o5) ||
       !get_buf(env, argv[14], napi_uint16_array, n, 0, &o6) || !get_buf(env, argv[15], napi_uint8_array, (size_t)B, 0, &fl)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = g_multi ? ntru_multi_verify_keys_batch(g_multi, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl)
-                   : ntru_verify_keys_batch(g_engine, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl);
+  int rc;
+  ENGINE_CALL(rc, g_multi ? ntru_multi_verify_keys_batch(g_multi, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl)
+                   : ntru_verify_keys_batch(g_engine, N, q, p, f, g, fq, fp, h, B, o1, o2, o3, o4, o5, o6, fl));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -241,7 +257,8 @@ static napi_value SampleTernary(napi_env env, napi_callback_info info) {
   if (!get_buf(env, argv[4], napi_uint32_array, 8, 0, &key) ||
       !get_buf(env, argv[7], napi_uint8_array, (size_t)N * (size_t)B, 0, &out)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  int rc = ntru_sample_ternary(g_engine, N, n1, n2, other, key, (uint64_t)first, B, out);
+  int rc;
+  ENGINE_CALL(rc, ntru_sample_ternary(g_engine, N, n1, n2, other, key, (uint64_t)first, B, out));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -250,7 +267,8 @@ static napi_value PackParams(napi_env env, napi_callback_info info) {
   ARGS(2)
   int32_t mv, dl; int v[4];
   if (!get_i32(env, argv[0], &mv) || !get_i32(env, argv[1], &dl)) BAD_ARGS();
-  int rc = ntru_pack_params(mv, dl, &v[0], &v[1], &v[2], &v[3]);
+  int rc;
+  ENGINE_CALL(rc, ntru_pack_params(mv, dl, &v[0], &v[1], &v[2], &v[3]));
   if (rc) return throw_engine(env, rc);
   napi_value arr; NAPI_OK(napi_create_array_with_length(env, 4, &arr));
   for (int i = 0; i < 4; i++) { napi_value n; NAPI_OK(napi_create_int32(env, v[i], &n)); NAPI_OK(napi_set_element(env, arr, i, n)); }
@@ -262,12 +280,13 @@ static napi_value PackBatch(napi_env env, napi_callback_info info) {
   ARGS(5)
   int32_t mv, dl, B; void *data, *out; int v[4];
   if (!get_i32(env, argv[0], &mv) || !get_i32(env, argv[1], &dl) || !get_i32(env, argv[3], &B) || B < 0) BAD_ARGS();
-  int rc = ntru_pack_params(mv, dl, &v[0], &v[1], &v[2], &v[3]);
+  int rc;
+  ENGINE_CALL(rc, ntru_pack_params(mv, dl, &v[0], &v[1], &v[2], &v[3]));
   if (rc) return throw_engine(env, rc);
   if (!get_buf(env, argv[2], napi_uint16_array, (size_t)dl * (size_t)B, 0, &data) ||
       !get_buf(env, argv[4], napi_biguint64_array, (size_t)v[3] * 4 * (size_t)B, 0, &out)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  rc = ntru_pack_batch(g_engine, mv, dl, data, B, out);
+  ENGINE_CALL(rc, ntru_pack_batch(g_engine, mv, dl, data, B, out));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -277,13 +296,14 @@ static napi_value UnpackBatch(napi_env env, napi_callback_info info) {
   int32_t mv, pb, ps, B; void *in, *out; int v[4];
   if (!get_i32(env, argv[0], &mv) || !get_i32(env, argv[1], &pb) || !get_i32(env, argv[3], &ps) ||
       !get_i32(env, argv[4], &B) || B < 0 || ps < 0) BAD_ARGS();
-  int rc = ntru_pack_params(mv, 0, &v[0], &v[1], &v[2], &v[3]);
+  int rc;
+  ENGINE_CALL(rc, ntru_pack_params(mv, 0, &v[0], &v[1], &v[2], &v[3]));
   if (rc) return throw_engine(env, rc);
   const int per = pb / v[0];
   if (!get_buf(env, argv[2], napi_biguint64_array, (size_t)ps * 4 * (size_t)B, 0, &in) ||
       !get_buf(env, argv[5], napi_uint16_array, (size_t)ps * (size_t)(per > 0 ? per : 0) * (size_t)B, 0, &out)) BAD_ARGS();
   if (!ensure_engine(env)) return NULL;
-  rc = ntru_unpack_batch(g_engine, mv, pb, in, ps, B, out);
+  ENGINE_CALL(rc, ntru_unpack_batch(g_engine, mv, pb, in, ps, B, out));
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
@@ -347,10 +367,10 @@ static napi_value GenericOp(napi_env env, napi_callback_info info) {
   }
   int32_t len0 = 0, len1 = 0; uint8_t st = 0;
   int rc;
-  if (op == 0) rc = ntru_generic_multiply(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0);
-  else if (op == 1) rc = ntru_generic_divide(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, r1, &len1, &st);
-  else if (op == 2) rc = ntru_generic_eea(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, r1, &len1, &st);
-  else rc = ntru_generic_poly_inv(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, &st);
+  if (op == 0) ENGINE_CALL(rc, ntru_generic_multiply(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0));
+  else if (op == 1) ENGINE_CALL(rc, ntru_generic_divide(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, r1, &len1, &st));
+  else if (op == 2) ENGINE_CALL(rc, ntru_generic_eea(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, r1, &len1, &st));
+  else ENGINE_CALL(rc, ntru_generic_poly_inv(g_engine, (int)la, (int)lb, (int64_t)mod, ia, ib, 1, r0, &len0, &st));
   if (!rc) {
     for (int32_t i = 0; i < len0; i++) ((double *)o0)[i] = (double)r0[i];
     if (o1) for (int32_t i = 0; i < len1; i++) ((double *)o1)[i] = (double)r1[i];
@@ -361,6 +381,115 @@ static napi_value GenericOp(napi_env env, napi_callback_info info) {
   const int32_t v[3] = {st, len0, len1};
   for (int i = 0; i < 3; i++) { napi_value n; NAPI_OK(napi_create_int32(env, v[i], &n)); NAPI_OK(napi_set_element(env, arr, i, n)); }
   return arr;
+}
+
+/* ---- asynchronous batch calls (additive; the reference API stays synchronous).  encryptBatchAsync / decryptBatchAsync take
+ *      the arguments of their synchronous twins and return a Promise; the engine call runs on a libuv worker thread, so the
+ *      event loop keeps turning while a 2^18-item batch (tens of milliseconds of PCIe) is in flight.  The typed arrays are
+ *      pinned by references until the Promise settles; the caller must not touch the output arrays before that. */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref keep[8];
+  int n_keep;
+  int kind;                       /* 0 encrypt, 1 decrypt */
+  int N, q, p, B;
+  void *ptr[8];
+  int rc;
+  char err[400];
+} AsyncJob;
+
+static void async_execute(napi_env env, void *data) {
+  (void)env;
+  AsyncJob *j = (AsyncJob *)data;
+  pthread_mutex_lock(&g_lock);
+  if (!g_engine) { j->rc = NTRU_ERR_ARG; snprintf(j->err, sizeof j->err, "ntru engine not created"); }
+  else {
+    if (j->kind == 0)
+      j->rc = g_multi ? ntru_multi_encrypt_batch(g_multi, j->N, j->q, j->ptr[0], j->ptr[1], j->ptr[2], j->B, j->ptr[3], j->ptr[4])
+                      : ntru_encrypt_batch(g_engine, j->N, j->q, j->ptr[0], j->ptr[1], j->ptr[2], j->B, j->ptr[3], j->ptr[4]);
+    else
+      j->rc = g_multi ? ntru_multi_decrypt_batch(g_multi, j->N, j->q, j->p, j->ptr[0], j->ptr[1], j->ptr[2], j->B, j->ptr[3],
+                                                 j->ptr[4], j->ptr[5], j->ptr[6])
+                      : ntru_decrypt_batch(g_engine, j->N, j->q, j->p, j->ptr[0], j->ptr[1], j->ptr[2], j->B, j->ptr[3], j->ptr[4],
+                                           j->ptr[5], j->ptr[6]);
+    if (j->rc) snprintf(j->err, sizeof j->err, "ntru engine error %d: %s", j->rc, ntru_last_error());   /* per thread: read it here */
+  }
+  pthread_mutex_unlock(&g_lock);
+}
+
+static void async_complete(napi_env env, napi_status status, void *data) {
+  AsyncJob *j = (AsyncJob *)data;
+  napi_value v;
+  if (status == napi_ok && j->rc == 0) {
+    napi_get_undefined(env, &v);
+    napi_resolve_deferred(env, j->deferred, v);
+  } else {
+    napi_value msg;
+    napi_create_string_utf8(env, status == napi_ok ? j->err : "ntru engine: asynchronous work was cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  for (int i = 0; i < j->n_keep; i++) napi_delete_reference(env, j->keep[i]);
+  napi_delete_async_work(env, j->work);
+  free(j);
+}
+
+static napi_value async_start(napi_env env, AsyncJob *j, napi_value *hold, int n_hold, const char *name) {
+  napi_value promise, rname;
+  if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j); napi_throw_error(env, NULL, "napi_create_promise failed"); return NULL; }
+  for (int i = 0; i < n_hold; i++) {
+    napi_valuetype vt;
+    if (napi_typeof(env, hold[i], &vt) == napi_ok && vt == napi_object &&
+        napi_create_reference(env, hold[i], 1, &j->keep[j->n_keep]) == napi_ok) j->n_keep++;
+  }
+  napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname);
+  if (napi_create_async_work(env, NULL, rname, async_execute, async_complete, j, &j->work) != napi_ok ||
+      napi_queue_async_work(env, j->work) != napi_ok) {
+    for (int i = 0; i < j->n_keep; i++) napi_delete_reference(env, j->keep[i]);
+    free(j);
+    napi_throw_error(env, NULL, "could not queue asynchronous work");
+    return NULL;
+  }
+  return promise;
+}
+
+/* encryptBatchAsync(N, q, h, r, m, B, e, quotE|null) -> Promise<undefined> */
+static napi_value EncryptBatchAsync(napi_env env, napi_callback_info info) {
+  ARGS(8)
+  int32_t N, q, B; void *h, *r, *m, *e, *quot;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[5], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[2], napi_uint16_array, (size_t)N, 0, &h) || !get_buf(env, argv[3], napi_uint8_array, n, 0, &r) ||
+      !get_buf(env, argv[4], napi_uint8_array, n, 0, &m) || !get_buf(env, argv[6], napi_uint16_array, n, 0, &e) ||
+      !get_buf(env, argv[7], napi_uint16_array, n, 1, &quot)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
+  if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  j->kind = 0; j->N = N; j->q = q; j->B = B;
+  j->ptr[0] = h; j->ptr[1] = r; j->ptr[2] = m; j->ptr[3] = e; j->ptr[4] = quot;
+  napi_value hold[5] = {argv[2], argv[3], argv[4], argv[6], argv[7]};
+  return async_start(env, j, hold, 5, "ntru.encryptBatchAsync");
+}
+
+/* decryptBatchAsync(N, q, p, f, fp, e, B, value, quot1|null, rem1|null, quot2|null) -> Promise<undefined> */
+static napi_value DecryptBatchAsync(napi_env env, napi_callback_info info) {
+  ARGS(11)
+  int32_t N, q, p, B; void *f, *fp, *e, *value, *q1, *r1, *q2;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) ||
+      !get_i32(env, argv[6], &B) || N < 1 || B < 0) BAD_ARGS();
+  size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[3], napi_int8_array, (size_t)N, 0, &f) || !get_buf(env, argv[4], napi_uint8_array, (size_t)N, 0, &fp) ||
+      !get_buf(env, argv[5], napi_uint16_array, n, 0, &e) || !get_buf(env, argv[7], napi_uint8_array, n, 0, &value) ||
+      !get_buf(env, argv[8], napi_uint16_array, n, 1, &q1) || !get_buf(env, argv[9], napi_uint16_array, n, 1, &r1) ||
+      !get_buf(env, argv[10], napi_uint8_array, n, 1, &q2)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
+  if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  j->kind = 1; j->N = N; j->q = q; j->p = p; j->B = B;
+  j->ptr[0] = f; j->ptr[1] = fp; j->ptr[2] = e; j->ptr[3] = value; j->ptr[4] = q1; j->ptr[5] = r1; j->ptr[6] = q2;
+  napi_value hold[7] = {argv[3], argv[4], argv[5], argv[7], argv[8], argv[9], argv[10]};
+  return async_start(env, j, hold, 7, "ntru.decryptBatchAsync");
 }
 
 static napi_value Init(napi_env env, napi_value exports) {
@@ -385,6 +514,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"allocPinned", NULL, AllocPinned, NULL, NULL, NULL, napi_default, NULL},
     {"genericCapacity", NULL, GenericCapacity, NULL, NULL, NULL, napi_default, NULL},
     {"genericOp", NULL, GenericOp, NULL, NULL, NULL, napi_default, NULL},
+    {"encryptBatchAsync", NULL, EncryptBatchAsync, NULL, NULL, NULL, napi_default, NULL},
+    {"decryptBatchAsync", NULL, DecryptBatchAsync, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof props / sizeof props[0], props) != napi_ok) return NULL;
   return exports;

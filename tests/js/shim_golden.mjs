@@ -190,4 +190,31 @@ deepStrictEqual(lib.stringToBits('Hello World'), pure.misc.stringToBits[0].out);
     strictEqual(Buffer.compare(Buffer.from(dec1[k].buffer), Buffer.from(dec3[k].buffer)), 0);
 }
 
+// Promise-returning batch calls: several in flight at once (serialised inside the addon), the event loop turns meanwhile,
+// results equal the synchronous ones; a refused call rejects with the engine's message
+const asyncChecks = (async () => {
+  const g = golden('scheme_n167_q128.json'); const key = g.keys[0]; const N = g.options.N;
+  const ntru = new NTRU({ ...g.options, f: key.f, fp: key.fp, h: key.h });
+  const B = 3000;
+  const r = ntru.sampleR(Uint32Array.from([3, 1, 4, 1, 5, 9, 2, 6]), 0, B);
+  const m = new Uint8Array(B * N); for (let i = 0; i < m.length; i++) m[i] = (i * 5 + (i >> 7)) % 3;
+  const encSync = ntru.encryptBatch(r, m, B), decSync = ntru.decryptBatch(encSync.e, B);
+  let ticks = 0; const timer = setInterval(() => { ticks++; }, 0);
+  const pending = [ntru.encryptBatchAsync(r, m, B), ntru.encryptBatchAsync(r, m, B, false), ntru.decryptBatchAsync(encSync.e, B)];
+  const [enc, encValueOnly, dec] = await Promise.all(pending);
+  clearInterval(timer);
+  for (const k of ['e', 'quotientE']) strictEqual(Buffer.compare(Buffer.from(encSync[k].buffer), Buffer.from(enc[k].buffer)), 0);
+  strictEqual(encValueOnly.quotientE, null);
+  strictEqual(Buffer.compare(Buffer.from(encSync.e.buffer), Buffer.from(encValueOnly.e.buffer)), 0);
+  for (const k of ['value', 'quotient1', 'remainder1', 'quotient2'])
+    strictEqual(Buffer.compare(Buffer.from(decSync[k].buffer), Buffer.from(dec[k].buffer)), 0);
+  const bad = new NTRU({ ...g.options, q: 12, f: key.f, fp: key.fp, h: key.h });
+  let msg = null;
+  try { await bad.encryptBatchAsync(r, m, 4); } catch (err) { msg = err.message; }
+  ok(msg && /ntru engine error/.test(msg), `rejection message: ${msg}`);
+  return ticks;
+})();
+asyncChecks.then(ticks => console.log(`shim_golden: async batch calls OK (${ticks} event-loop ticks while in flight)`),
+  err => { console.error(err); process.exit(1); });
+
 console.log(`shim_golden: ${checks} scheme checks, ${nMul} multiply and ${nDiv} divide vectors OK`);

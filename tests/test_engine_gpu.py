@@ -1044,6 +1044,17 @@ def test_multi_device_host_api_shards_equal_oracle():
     wantv = orc.verify_keys_batch(N, q, p, kf, kg_, kfq, kfp, kh)
     for k in wantv:
         assert np.array_equal(outv[k], wantv[k]), k
+    kfq2, kfp2, fl = me.invert_key_batch(N, q, p, kf)                          # inverses: f fq = 1 mod q, f fp = 1 mod 3
+    ok = fl == 0
+    assert ok.any()
+    one = np.zeros(N, np.int64); one[0] = 1
+    _, rq = orc.polymul_split_batch(N, q, kf % q, kfq2)
+    _, r3 = orc.polymul_split_batch(N, 3, kf % 3, kfp2)
+    assert all(np.array_equal(rq[i], one) and np.array_equal(r3[i], one) for i in range(Bk) if ok[i])
+    assert np.array_equal(me.public_key_batch(N, q, p, kfq, kg_), orc.public_key_batch(N, q, p, kfq, kg_))
+    pq, pr = me.polymul_split(N, q, kfq, kh)
+    pq_o, pr_o = orc.polymul_split_batch(N, q, kfq, kh)
+    assert np.array_equal(pq, pq_o) and np.array_equal(pr, pr_o)
     assert me.encrypt_batch(N, q, h, r[:2], m[:2])[0].shape == (2, N)          # fewer items than engines: empty shards
     with pytest.raises(pkg.EngineError, match="device shard 0"):
         me.encrypt_batch(N, 12, h, r[:5], m[:5])                               # q = 12: refused, the message names the shard
