@@ -3,6 +3,10 @@
 //   pattern 0: one instruction = lanes 0-31 -> 32 consecutive columns of row r, lanes 32-63 -> the same columns of row r+4
 //              (the accumulator layout of v_mfma_i32_32x32x32_i8)
 //   pattern 1: one instruction = 64 consecutive columns of ONE row (after a v_permlane32_swap between two tiles)
+//   pattern 3: a strip's row segment (192-256 bytes at a 2-byte aligned start) as ALIGNED 16-byte pieces (lane = piece,
+//              4 rows x 16 pieces per instruction) plus its two edges as 2-byte stores (lane = row x element): 4 store
+//              instructions per 8 rows and strip instead of 12-16
+//   pattern 4: the whole row block as one contiguous run of aligned 16-byte pieces (what a full LDS image would allow)
 // hipcc -O3 --offload-arch=gfx950 -o store_pattern store_pattern.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,6 +18,11 @@ __global__ __launch_bounds__(256) void k(unsigned short* out, long nrb, int N) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     unsigned short* blk = out + rb * 32 * N;
+    if (PAT == 4) {
+      uint4* b4 = (uint4*)blk;                                   // 32 N u16 = 64 N bytes: a multiple of 16
+      for (int i = threadIdx.x; i < 4 * N; i += 256) b4[i] = make_uint4((unsigned)rb, i, i, i);
+      continue;
+    }
     for (int strip = wave; strip < 8; strip += 4) {           // 8 strips of 3-4 tiles; here: 3 tiles of 32 columns (+1 for even strips)
       const int kb0 = strip * 3 + (strip < 2 ? strip : 2), nt = strip < 2 ? 4 : 3;
       for (int j = 0; j < 4; j++)
@@ -23,6 +32,23 @@ __global__ __launch_bounds__(256) void k(unsigned short* out, long nrb, int N) {
             for (int t = 0; t < nt; t++) {
               const int col = 32 * (kb0 + t) + (lane & 31), row = ro + 4 * (lane >> 5);
               if (col < N) blk[row * N + col] = (unsigned short)(rb + col);
+            }
+          } else if (PAT == 3) {
+            if (ii == 0) {
+              const int c0 = 32 * kb0, c1 = 32 * (kb0 + nt) < N ? 32 * (kb0 + nt) : N;
+              for (int half = 0; half < 2; half++) {
+                const int row = 8 * j + 4 * half + (lane >> 4);
+                const unsigned long long S = (unsigned long long)(blk + row * N + c0), E = (unsigned long long)(blk + row * N + c1);
+                const unsigned long long A0 = (S + 15) & ~15ull, A1 = E & ~15ull, pp = A0 + 16 * (lane & 15);
+                if (pp + 16 <= A1) *(uint4*)pp = make_uint4((unsigned)rb, lane, row, c0);
+              }
+              for (int side = 0; side < 2; side++) {
+                const int row = 8 * j + (lane >> 3), el = lane & 7;
+                const unsigned long long S = (unsigned long long)(blk + row * N + c0), E = (unsigned long long)(blk + row * N + c1);
+                const unsigned long long A0 = (S + 15) & ~15ull, A1 = E & ~15ull;
+                const unsigned long long q = (side == 0 ? S : A1) + 2 * el;
+                if (side == 0 ? q < A0 : q < E) *(unsigned short*)q = (unsigned short)(rb + el);
+              }
             }
           } else if (PAT == 2) {                                 // quad-packed: one 8-byte store per lane = 4 columns of row (lane & 3)
             if (ii == 0)
@@ -48,13 +74,13 @@ int main(int argc, char** argv) {
   const long nrb = 32768;
   unsigned short* d; CK(hipMalloc(&d, (size_t)nrb * 32 * N * 2));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int pat = 0; pat < 3; pat++)
+  for (int pat = 0; pat < 5; pat++)
     for (int rep = 0; rep < 3; rep++) {
       CK(hipEventRecord(e0));
-      if (pat == 0) k<0><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 1) k<1><<<cus * 2, 256>>>(d, nrb, N); else k<2><<<cus * 2, 256>>>(d, nrb, N);
+      if (pat == 0) k<0><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 1) k<1><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 2) k<2><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 3) k<3><<<cus * 2, 256>>>(d, nrb, N); else k<4><<<cus * 2, 256>>>(d, nrb, N);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      if (rep == 2) printf("pattern %d (%s): %.3f ms  %.0f GB/s\n", pat, pat == 0 ? "2 rows x 64 B per instruction" : pat == 1 ? "1 row x 128 B per instruction" : "8 rows x 64 B per instruction (8 B per lane)", ms,
+      if (rep == 2) printf("pattern %d (%s): %.3f ms  %.0f GB/s\n", pat, pat == 0 ? "2 rows x 64 B per instruction" : pat == 1 ? "1 row x 128 B per instruction" : pat == 2 ? "8 rows x 64 B per instruction (8 B per lane)" : pat == 3 ? "aligned 16 B pieces + 2 B edges per row segment" : "whole row block, aligned 16 B pieces", ms,
                            (double)nrb * 32 * N * 2 / ms * 1e-6);
     }
   return 0;

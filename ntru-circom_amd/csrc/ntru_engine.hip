@@ -2128,7 +2128,11 @@ static __device__ __forceinline__ v4i col_mask16(int c16, int N) {
 // MAXT: widest strip.  8 (one workgroup per CU, 512 registers per wave, one strip per wave and row block) was measured at
 // 2.28 ms per 2^20 against 1.51-1.58 ms for 4: with one wave per SIMD nothing overlaps the matrix loops
 // (DESIGN.md section 5b); only 4 is instantiated.
-template <int MAXT, int GROUPS>                              // GROUPS = 2: the lock-step schedule of decrypt_m_body (k_encrypt_m8)
+// Result chunk of one wave (CHUNK variants): 8 rows x OC_PITCH bytes = a strip's <= 128 u16 columns of 8 rows, each row
+// at the 16-byte phase it has in global memory (<= 14 bytes of slack in front).
+constexpr int OC_PITCH = 272, OC_BYTES = 8 * OC_PITCH;
+
+template <int MAXT, int GROUPS, bool CHUNK = false>          // GROUPS = 2: the lock-step schedule of decrypt_m_body (k_encrypt_m8)
 static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 *__restrict__ h,
                                                       const uint8_t *__restrict__ r,
                                                       const uint8_t *__restrict__ m, long B,
@@ -2136,9 +2140,10 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int group = GROUPS == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
   u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;         // key arrays (shared by the groups), then per group [r stage][m image]
-  const int gbytes = 32 * g.pitchA + ((32 * g.ld + 15) & ~15) + 16;
+  const int gbytes = 32 * g.pitchA + ((32 * g.ld + 15) & ~15) + 16 + (CHUNK ? WAVES_PER_BLOCK * OC_BYTES : 0);
   unsigned char *stA = (unsigned char *)(T1 + 4 * g.tpitch) + group * gbytes;
   unsigned char *mimg = stA + 32 * g.pitchA;             // rows b0..b0+31 of m exactly as in memory (pitch g.ld)
+  unsigned char *ochunks = mimg + ((32 * g.ld + 15) & ~15) + 16;   // CHUNK: one result chunk per wave
   const int tid0 = threadIdx.x & (BLOCK_THREADS - 1), lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int hthr = (int)(q >> 1) - 65;
   auto hs_of = [&](int i) { int hv = (int)(h[i] & (q - 1)); return hv > hthr ? hv - (int)q : hv; };
@@ -2292,7 +2297,70 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
             }
           }
         };
-        if (want_q) out(std::true_type{}); else out(std::false_type{});
+        // CHUNK: the strip's results go through the wave's LDS chunk, 8 rows at a time, laid out with the 16-byte phase the
+        // rows have in global memory, and leave as ALIGNED 16-byte pieces (lane = piece: 4 rows x 16 pieces per store) plus the
+        // two edges of every row segment as 2-byte stores (lane = row x element): 4 store instructions per 8 rows and array
+        // instead of 4 per tile, and no 64-byte piece straddling two cache lines (bench_micro/store_pattern: 3.3 against
+        // 2.4 TB/s for dense rows at N = 821).
+        auto out_chunk = [&](auto wq) {
+          unsigned char *oc = ochunks + wave * OC_BYTES;
+          const int Wb = 2 * ((32 * NTS < N - 32 * kb0) ? 32 * NTS : N - 32 * kb0);      // bytes of a row segment of this strip
+          const int LD2 = 2 * LD;
+          // descriptor bases are e + bb LD (rows of this row block on): byte phase of row R's segment = (gA + 2 R LD) & 15
+          const int g_e = (int)(((unsigned long long)(e + bb * LD + 32 * kb0)) & 15);
+          const int g_q = (int)(((unsigned long long)((decltype(wq)::value ? quotE : e) + bb * LD + 32 * kb0)) & 15);
+          const int rd = 4 * (lane >> 5), rp = lane >> 4, re = lane >> 3, sl = lane & 15, el = lane & 7;
+          auto one = [&](int gA, const __amdgpu_buffer_rsrc_t &rs, auto with_m, auto val) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              // every LDS read of a step is requested before the step's LDS writes / global stores: the compiler must keep
+              // the program order between the byte reads of the m image, the chunk writes and the chunk reads
+              u32 mv[NTS][4];
+#pragma unroll
+              for (int t = 0; t < NTS; t++)
+#pragma unroll
+                for (int ii = 0; ii < 4; ii++) mv[t][ii] = decltype(with_m)::value ? m_l[(8 * j + ii) * LD + 32 * t] : 0u;
+#pragma unroll
+              for (int ii = 0; ii < 4; ii++) {             // dump rows 8 j + ii (+ 4 for the upper half-wave)
+                const int a = (gA + (rd + ii) * LD2) & 15;
+                unsigned char *row = oc + (rd + ii) * OC_PITCH + a + 2 * (lane & 31);
+#pragma unroll
+                for (int t = 0; t < NTS; t++) *(u16 *)(row + 64 * t) = (u16)val(t, 4 * j + ii, mv[t][ii]);
+              }
+              const int sj = 8 * j * LD2 + 64 * kb0;         // scalar part of the global byte offset: row 8 j, the strip's first column
+              v4i pv[2]; int pvo[2]; u16 ev[2]; int evo[2];
+#pragma unroll
+              for (int half = 0; half < 2; half++) {        // aligned pieces of rows 8 j + 4 half + (lane >> 4)
+                const int R = 4 * half + rp, a = (gA + R * LD2) & 15, A0 = (a + 15) & ~15, A1 = (a + Wb) & ~15;
+                const int po = A0 + 16 * sl;
+                pv[half] = *(const v4i *)(oc + R * OC_PITCH + po);
+                pvo[half] = po + 16 <= A1 ? R * LD2 - a + po + sj : (int)0x80000000;
+              }
+#pragma unroll
+              for (int side = 0; side < 2; side++) {        // edges of rows 8 j + (lane >> 3): head, then tail
+                const int a = (gA + re * LD2) & 15, A0 = (a + 15) & ~15, A1 = (a + Wb) & ~15;
+                const int eo = (side == 0 ? a : A1) + 2 * el;
+                const bool ok = side == 0 ? eo < (A0 < a + Wb ? A0 : a + Wb) : (A1 >= A0 && eo < a + Wb);
+                ev[side] = *(const u16 *)(oc + re * OC_PITCH + eo);
+                evo[side] = ok ? re * LD2 - a + eo + sj : (int)0x80000000;
+              }
+              // The scalar offset is part of the vector offset: a buffer_store_dwordx4 with an SGPR soffset whose data
+              // registers the NEXT instruction overwrites stores the overwritten first dword on gfx950 under load
+              // (profiles/r02_hazard_store_x4_soffset.txt); the compiler only separates the two when soffset is no
+              // register (tests/test_build_quality.py scans the ISA for the pattern).
+              if (1 ABL_STORE(lo[0][0])) {
+                __builtin_amdgcn_raw_buffer_store_b128(pv[0], rs, pvo[0], 0, ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(pv[1], rs, pvo[1], 0, ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b16(ev[0], rs, evo[0], 0, ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b16(ev[1], rs, evo[1], 0, ST_AUX);
+              }
+            }
+          };
+          one(g_e, rs_e, std::true_type{}, [&](int t, int i, u32 mm) { return (u32)(lo[t][i] + hi[t][i] + (int)mm) & (q - 1); });
+          if (decltype(wq)::value) one(g_q, rs_q, std::false_type{}, [&](int t, int i, u32) { return (u32)(0 - hi[t][i]) & (q - 1); });
+        };
+        if (CHUNK) { if (want_q) out_chunk(std::true_type{}); else out_chunk(std::false_type{}); }
+        else if (want_q) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
         case 0: phase(); break;
@@ -2314,6 +2382,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
                                                              const uint8_t *__restrict__ m, long B,
                                                              u16 *__restrict__ e, u16 *__restrict__ quotE) {
   encrypt_m_body<4, 1>(g, q, h, r, m, B, e, quotE);
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_mc(MGeom g, u32 q, const u16 *__restrict__ h,
+                                                              const uint8_t *__restrict__ r,
+                                                              const uint8_t *__restrict__ m, long B,
+                                                              u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  encrypt_m_body<4, 1, true>(g, q, h, r, m, B, e, quotE);
 }
 
 __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_encrypt_m8(MGeom g, u32 q, const u16 *__restrict__ h,
@@ -3522,7 +3597,7 @@ extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
 
 extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (path < 0 || path > 6)
+  if (path < 0 || path > 7)
     return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8), 4 (matrix cores, two workgroups per CU), "
                               "5 (matrix cores, lock-step groups) or 6 (matrix cores, role-split encrypt)");
   eng->path = path;
@@ -3602,7 +3677,7 @@ static int shared_path_K(const ntru_engine *eng, int N, int q, int p, int *me) {
 
 // Matrix-core path (family 4): shared key, q a power of two <= 8192 (two int8 digit planes), LDS for a 32-row block.
 static bool make_mgeom(const ntru_engine *eng, int N, int q, int ld, MGeom *g) {
-  if (eng->path != 0 && eng->path != 4 && eng->path != 5 && eng->path != 6) return false;
+  if (eng->path != 0 && eng->path < 4) return false;
   if (q > 8192 || N > 1024 || ld > 1024 || N < (eng->path >= 4 || ld != N ? 2 : 64)) return false;   // staging: lane = 16-byte chunk of a row
   g->N = N;
   g->ld = ld;
@@ -3724,6 +3799,15 @@ extern "C" int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
         HIP_TRY(hipGetLastError());
         return NTRU_OK;
       }
+    }
+    if (lds && eng->path == 7 && 2 * (lds + WAVES_PER_BLOCK * OC_BYTES) <= 160 * 1024) {      // result chunks: aligned 16-byte stores
+      const size_t ldsc = lds + WAVES_PER_BLOCK * OC_BYTES;
+      if (int rc = resident_grid(eng, k_encrypt_mc, ldsc, (long)((B + 31) / 32), &L.grid)) return rc;
+      snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_encrypt_mc");
+      hipLaunchKernelGGL(k_encrypt_mc, L.grid, dim3(BLOCK_THREADS), ldsc, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B,
+                         d_e, d_quotE);
+      HIP_TRY(hipGetLastError());
+      return NTRU_OK;
     }
     if (lds && lds <= 160 * 1024) {
       if (int rc = allow_lds(k_encrypt_m, lds)) return rc;

@@ -19,3 +19,36 @@ def test_no_kernel_spills_to_scratch():
     assert not bad, bad
     for must in ("k_encrypt_t", "k_decrypt_s", "k_encrypt", "k_decrypt", "k_verify_keys", "k_polymul_split"):
         assert any(must in n for n in names), must
+
+
+def test_no_wide_store_followed_by_a_write_of_its_data_registers():
+    """gfx950, measured (profiles/r02_hazard_store_x4_soffset.txt): a buffer_store_dwordx4 whose data registers the very next
+    instruction overwrites can store the NEW value of the first dword when the memory pipe is busy.  The compiler separates
+    the two only when the store's soffset is not a register, so the kernels never pass a scalar offset to their 16-byte
+    stores; this scans the generated ISA of the whole library for the pattern (the asm target of the previous test wrote
+    /tmp/ntru_engine.s; it is rebuilt here if missing)."""
+    path = "/tmp/ntru_engine.s"
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(ge.PKG_DIR, "csrc", "ntru_engine.hip")):
+        subprocess.run(["make", "-C", os.path.join(ge.PKG_DIR, "csrc"), "asm"], capture_output=True, text=True, timeout=900)
+    lines = open(path).read().split("\n")
+    kern, n, bad = None, 0, []
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kern = m.group(1)
+        if not re.search(r"\b(buffer|global|flat|scratch)_store_dwordx[34]\b", line):
+            continue
+        data = re.search(r"v\[(\d+):(\d+)\]", line)
+        lo, hi = int(data.group(1)), int(data.group(2))
+        j = i + 1
+        while j < len(lines) and (lines[j].strip().startswith(";") or not lines[j].strip()):
+            j += 1
+        nxt = lines[j].strip()
+        n += 1
+        w = re.match(r"^v_\w+\s+v\[?(\d+)(?::(\d+))?", nxt)
+        if w and not nxt.startswith(("v_cmp", "v_cmpx")):
+            a = int(w.group(1)); b = int(w.group(2) or a)
+            if not (b < lo or a > hi):
+                bad.append((kern, line.strip(), nxt))
+    assert n >= 50, n                                     # the scan saw the library's wide stores
+    assert not bad, bad[:5]

@@ -252,7 +252,7 @@ def test_kernel_families_agree(eng):
 @pytest.mark.parametrize("N,q,d", [(17, 32, 2), (31, 64, 5), (32, 128, 6), (33, 32, 7), (64, 8192, 20), (65, 4096, 21),
                                    (167, 128, 18), (509, 2048, 169), (701, 8192, 233), (821, 4096, 273),
                                    (1024, 8192, 300)])
-@pytest.mark.parametrize("path", [4, 5, 6])
+@pytest.mark.parametrize("path", [4, 5, 6, 7])
 def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
     """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step groups; 6: role-split encrypt), including sizes the
     automatic choice leaves to other families, batches that do not fill a 32-row block, and h at the corners of the
@@ -269,7 +269,8 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             r = ternary_rows(rng, B, N, d, d)
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
-            assert eng.last_kernel() == {4: "k_encrypt_m", 5: "k_encrypt_m8", 6: "k_encrypt_m2"}[path]
+            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8",), 6: ("k_encrypt_m2",),
+                                         7: ("k_encrypt_mc",) if N < 1024 else ("k_encrypt_m",)}[path]   # 7: result chunks, when two workgroups' LDS fits
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -288,7 +289,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
         eng.set_kernel_path(0)
 
 
-@pytest.mark.parametrize("path", [4, 5, 6])
+@pytest.mark.parametrize("path", [4, 5, 6, 7])
 def test_matrix_core_path_random_parameter_sweep(eng, path):
     """Differential sweep: 40 random (N, q, B) with N in [2, 1024] (odd and even, around the 32-tile boundaries), q any
     power of two up to 8192, ragged B; matrix-core family (forced) against the CPU oracle, all outputs."""
@@ -308,7 +309,8 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
             r = ternary_rows(rng, B, N, d, d)
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
-            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8", "k_encrypt_m"), 6: ("k_encrypt_m2",)}[path]
+            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8", "k_encrypt_m"), 6: ("k_encrypt_m2",),
+                                         7: ("k_encrypt_mc", "k_encrypt_m")}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
             ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])
@@ -1061,3 +1063,48 @@ def test_multi_device_host_api_shards_equal_oracle():
     me.close()
     with pytest.raises(pkg.EngineError):
         pkg.MultiEngine([0, 99])                                               # no such device
+
+
+@pytest.mark.parametrize("N,q", [(821, 4096), (701, 8192), (509, 2048), (167, 128), (33, 64), (96, 256)])
+def test_chunked_result_stores_at_every_base_alignment(eng, N, q):
+    """Kernel path 7 (k_encrypt_mc): results leave through per-wave LDS chunks as aligned 16-byte pieces plus 2-byte edges,
+    so the geometry depends on the byte phase of every row segment.  Output arrays at all eight 2-byte phases of a 16-byte
+    line (e and quotE at different ones), dense rows (N odd and even), ragged batches; guard elements before and behind the
+    arrays must stay untouched."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N + q)
+    d = N // 3
+    h = rng.integers(0, q, N)
+    dh = torch.from_numpy(h.astype(np.int16)).to(dev)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_kernel_path(7)
+    try:
+        for phase in range(8):
+            B = (1, 31, 45, 64, 77, 33, 96, 5)[phase]
+            r = ternary_rows(rng, B, N, d, d); m = rng.integers(0, 256, (B, N))
+            e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
+            dr = torch.from_numpy(r.astype(np.uint8)).to(dev); dm = torch.from_numpy(m.astype(np.uint8)).to(dev)
+            G = 64                                            # guard elements on both sides
+            pe, pq = phase, (phase * 3 + 1) % 8
+            be = torch.full((G + pe + B * N + G,), 0x5A5A, dtype=torch.int16, device=dev)
+            bq = torch.full((G + pq + B * N + G,), 0x5A5A, dtype=torch.int16, device=dev)
+            assert be.data_ptr() % 16 == 0 and bq.data_ptr() % 16 == 0
+            e_ptr, q_ptr = be.data_ptr() + 2 * (G + pe), bq.data_ptr() + 2 * (G + pq)
+            eng.encrypt_batch_dev(N, q, dh.data_ptr(), dr.data_ptr(), dm.data_ptr(), B, e_ptr, q_ptr)
+            torch.cuda.synchronize()
+            assert eng.last_kernel() == "k_encrypt_mc"
+            for buf, ph, want, name in ((be, pe, e_o, "e"), (bq, pq, quot_o, "quotE")):
+                a = buf.cpu().numpy().astype(np.int64) & 0xFFFF
+                assert np.array_equal(a[G + ph:G + ph + B * N].reshape(B, N), want), (name, phase, B)
+                assert (a[:G + ph] == 0x5A5A).all() and (a[G + ph + B * N:] == 0x5A5A).all(), (name, phase, "wrote outside")
+            # value-only mode (no quotient array)
+            be.fill_(0x5A5A)
+            eng.encrypt_batch_dev(N, q, dh.data_ptr(), dr.data_ptr(), dm.data_ptr(), B, e_ptr, None)
+            torch.cuda.synchronize()
+            a = be.cpu().numpy().astype(np.int64) & 0xFFFF
+            assert np.array_equal(a[G + pe:G + pe + B * N].reshape(B, N), e_o), ("e only", phase)
+            assert (a[:G + pe] == 0x5A5A).all() and (a[G + pe + B * N:] == 0x5A5A).all()
+    finally:
+        eng.set_kernel_path(0)
+        eng.set_stream(None)
