@@ -1889,6 +1889,9 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   v16i accL[NT_S], accH[NT_S];
   v4i W0[NT_S], W1[NT_S];
   auto load_w = [&](int d, v4i &w0, v4i &w1) {
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 262144)       // timing only: no operand reads inside the loops (wrong values)
+    if (d != kb0) { asm volatile("" : "+v"(w0), "+v"(w1)); return; }
+#endif
     const u32 *p = tb0 - 8 * d;
     w0 = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
     if (MODE == M_ENC) {
@@ -1902,6 +1905,9 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     }
   };
   auto load_a = [&](int ib, v4i &a0, v4i &a1) {
+#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 262144)
+    if (ib != 0) { asm volatile("" : "+v"(a0), "+v"(a1)); return; }
+#endif
     a0 = *(const v4i *)(st0 + 32 * ib);
     if (MODE == M_ENC) {                               // 32 r: r <= 3, no carry between bytes
 #pragma unroll

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Timing-only ablations of the matrix-core kernels (never shipped, results unchecked):
 #   bit 1 = result stores disabled, 2 = matrix loops disabled, 4 = r / e not loaded, 8 = encrypt: m not loaded, 32 = no image
-#   expansion, 64 = no mod-3 table, 128 / 256 = product 1 / 2 epilogue skipped, 512 = stores to one L2-resident row block;
+#   expansion, 64 = no mod-3 table, 128 / 256 = product 1 / 2 epilogue skipped, 512 = stores to one L2-resident row block,
+#   262144 = no operand reads inside the matrix loops;
 #   ABL_SET="3 7 11 15" selects the combinations (default 1 2 3).
 # Build here:   tools/ablate.sh build      -> ntru-circom_amd/lib/ab/libntru_abl{1,2,3}.so
 # Run on a GPU: tools/ablate.sh run [bench.py args]
