@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k(unsigned short* out, long nrb, int N) {
               if (col < N) blk[row * N + col] = (unsigned short)(rb + col);
             }
           } else if (PAT == 3) {
-            if (ii == 0) {
+            if (ii == 0 && 32 * kb0 < N) {                       // (strips past the row end of a smaller N: nothing to write)
               const int c0 = 32 * kb0, c1 = 32 * (kb0 + nt) < N ? 32 * (kb0 + nt) : N;
               for (int half = 0; half < 2; half++) {
                 const int row = 8 * j + 4 * half + (lane >> 4);
