@@ -14,6 +14,7 @@ eng = pkg.Engine(0)
 lib = C.CDLL(os.environ["NTRU_ENGINE_LIB"])
 dev = torch.device("cuda:0")
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
+eng.set_kernel_path(4)      # two free-running workgroups per CU (the stamp buffer is laid out for four waves per workgroup)
 N, q, B = 821, 4096, 1 << 20
 h = torch.randint(0, q, (N,), dtype=torch.int32, device=dev).to(torch.int16)
 f = torch.randint(-1, 2, (N,), dtype=torch.int8, device=dev); fp = torch.randint(0, 3, (N,), dtype=torch.uint8, device=dev)
