@@ -252,7 +252,7 @@ def test_kernel_families_agree(eng):
 @pytest.mark.parametrize("N,q,d", [(17, 32, 2), (31, 64, 5), (32, 128, 6), (33, 32, 7), (64, 8192, 20), (65, 4096, 21),
                                    (167, 128, 18), (509, 2048, 169), (701, 8192, 233), (821, 4096, 273),
                                    (1024, 8192, 300)])
-@pytest.mark.parametrize("path", [4, 5, 6, 7])
+@pytest.mark.parametrize("path", [4, 5, 6, 7, 8])
 def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
     """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step groups; 6: role-split encrypt), including sizes the
     automatic choice leaves to other families, batches that do not fill a 32-row block, and h at the corners of the
@@ -270,7 +270,8 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8",), 6: ("k_encrypt_m2",),
-                                         7: ("k_encrypt_mc",) if N < 1024 else ("k_encrypt_m",)}[path]   # 7: result chunks, when two workgroups' LDS fits
+                                         7: ("k_encrypt_mc",) if N < 1024 else ("k_encrypt_m",),   # 7: result chunks, when two workgroups' LDS fits
+                                         8: ("k_encrypt_m",)}[path]                                # 8: direct-to-LDS row loads (decrypt only)
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -279,7 +280,8 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             ein[-1] = rng.integers(0, q, N)
             ein[0, :4] = (q - 1, 0, q // 2, q // 2 + 1)
             got = eng.decrypt_batch(N, q, p, f, fp, ein)
-            assert eng.last_kernel() == ("k_decrypt_m8" if path == 5 and N < 1024 else "k_decrypt_m")   # N = 1024: 160 KB of LDS do not hold two groups
+            assert eng.last_kernel() == ("k_decrypt_m8" if path == 5 and N < 1024 else
+                                         "k_decrypt_m8d" if path == 8 and N < 1024 else "k_decrypt_m")   # N = 1024: 160 KB of LDS do not hold two groups
             want = orc.decrypt_batch(N, q, p, f, fp, ein)
             for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
                 assert np.array_equal(g_, w_), (B, name)
@@ -289,7 +291,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
         eng.set_kernel_path(0)
 
 
-@pytest.mark.parametrize("path", [4, 5, 6, 7])
+@pytest.mark.parametrize("path", [4, 5, 6, 7, 8])
 def test_matrix_core_path_random_parameter_sweep(eng, path):
     """Differential sweep: 40 random (N, q, B) with N in [2, 1024] (odd and even, around the 32-tile boundaries), q any
     power of two up to 8192, ragged B; matrix-core family (forced) against the CPU oracle, all outputs."""
@@ -310,7 +312,7 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8", "k_encrypt_m"), 6: ("k_encrypt_m2",),
-                                         7: ("k_encrypt_mc", "k_encrypt_m")}[path]
+                                         7: ("k_encrypt_mc", "k_encrypt_m"), 8: ("k_encrypt_m",)}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
             ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])
@@ -336,7 +338,8 @@ def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
     m = rng.integers(0, 3, (B, N))
     e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
     want = orc.decrypt_batch(N, q, p, f, fp, e_o)
-    for path, ename, dname in ((5, "k_encrypt_m8", "k_decrypt_m8"), (6, "k_encrypt_m2", "k_decrypt_m")):
+    for path, ename, dname in ((5, "k_encrypt_m8", "k_decrypt_m8"), (6, "k_encrypt_m2", "k_decrypt_m"),
+                               (8, "k_encrypt_m", "k_decrypt_m8d")):      # 8: every trip but the first decrypts rows loaded straight into LDS
         eng.set_kernel_path(path)
         try:
             e, quot = eng.encrypt_batch(N, q, h, r, m)
@@ -350,8 +353,9 @@ def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
             assert np.array_equal(g_, w_), (path, name)
 
 
+@pytest.mark.parametrize("path", [0, 8])                   # 8: decrypt's rows arrive by direct-to-LDS loads (dword-aligned pieces + a shift)
 @pytest.mark.parametrize("N,q", [(821, 4096), (167, 128), (701, 8192)])
-def test_device_pointers_at_any_alignment(eng, N, q):
+def test_device_pointers_at_any_alignment(eng, N, q, path):
     """The *_dev entry points take any pointer: the matrix-core kernels read rows through aligned chunks + shifts and
     write through byte/short stores, so buffers that start at odd byte offsets must give the same results."""
     import torch
@@ -363,6 +367,7 @@ def test_device_pointers_at_any_alignment(eng, N, q):
     e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
     want = orc.decrypt_batch(N, q, p, f, fp, e_o)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_kernel_path(path)
     try:
         for off in (1, 2, 3, 5, 14, 15):
             def place(a, dtype, elt):                    # copy `a` into a byte buffer at byte offset off * elt' (u16 stays 2-aligned)
@@ -393,12 +398,14 @@ def test_device_pointers_at_any_alignment(eng, N, q):
             for g_, w_ in zip(got, want):
                 assert np.array_equal(g_, w_), off
     finally:
+        eng.set_kernel_path(0)
         eng.set_stream(None)
 
 
 @pytest.mark.parametrize("N,q,ld", [(821, 4096, 832), (821, 4096, 822), (821, 4096, 1024), (167, 128, 192), (701, 8192, 704),
                                     (509, 2048, 509), (64, 32, 80), (33, 8192, 47)])
-def test_pitched_rows_equal_oracle(eng, N, q, ld):
+@pytest.mark.parametrize("path", [0, 8])
+def test_pitched_rows_equal_oracle(eng, N, q, ld, path):
     """ntru_*_batch_pitched_dev: rows at a pitch of ld >= N elements.  Pad elements of the inputs hold garbage and must
     not reach any result; pad elements of the outputs must stay untouched; a ragged batch (B % 32 != 0) must not write
     past row B - 1."""
@@ -429,6 +436,7 @@ def test_pitched_rows_equal_oracle(eng, N, q, ld):
     dr = pitched(r, np.uint8, 256); dm = pitched(m, np.uint8, 256)
     de = outbuf(torch.int16, 0x5A5A); dq = outbuf(torch.int16, 0x5A5A)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_kernel_path(path)
     try:
         eng.encrypt_batch_dev(N, q, dh.data_ptr(), dr.data_ptr(), dm.data_ptr(), B, de.data_ptr(), dq.data_ptr(), ld=ld)
         torch.cuda.synchronize()
@@ -447,6 +455,7 @@ def test_pitched_rows_equal_oracle(eng, N, q, ld):
         torch.cuda.synchronize()
         check(dv2, want[0], 0xA5, "value (value-only)")
     finally:
+        eng.set_kernel_path(0)
         eng.set_stream(None)
 
 
