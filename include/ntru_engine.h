@@ -82,8 +82,9 @@ int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
  * 5 = the same as ONE workgroup of two four-wave groups whose matrix-loop and epilogue phases are interleaved by barriers
  * (k_encrypt_m8, k_decrypt_m8; falls back to 4 where 160 KB of LDS do not hold two groups), 6 = 4 with the role-split encrypt
  * kernel (k_encrypt_m2: matrix waves + io waves, needs 16-byte aligned batch arrays), 7 = 4 with the encrypt results leaving
- * through per-wave LDS chunks as aligned 16-byte stores (k_encrypt_mc; where two workgroups' LDS fits), 8 = 5 for decrypt with the
- * next row block's rows loaded straight into LDS ahead of the last epilogue's stores (k_decrypt_m8d).  0 picks k_encrypt_m and, for N > 512,
+ * through per-wave LDS chunks as aligned 16-byte stores (k_encrypt_mc; where two workgroups' LDS fits), 8 = the batch operands by
+ * direct-to-LDS loads, the next row block's rows ahead of the last epilogue's stores (k_encrypt_md = 4 with such loads; k_decrypt_m8d
+ * = 5 with them).  0 picks k_encrypt_md and, for N > 512,
  * k_decrypt_m8.  Results are identical. */
 int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
 /* Name of the kernel the last *_dev call on this engine launched, e.g. "k_decrypt_s<13,13>" (for reports). */

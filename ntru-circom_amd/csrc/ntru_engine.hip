@@ -2138,12 +2138,23 @@ static __device__ __forceinline__ v4i col_mask16(int c16, int N) {
 // at the 16-byte phase it has in global memory (<= 14 bytes of slack in front).
 constexpr int OC_PITCH = 272, OC_BYTES = 8 * OC_PITCH;
 
-template <int MAXT, int GROUPS, bool CHUNK = false>          // GROUPS = 2: the lock-step schedule of decrypt_m_body (k_encrypt_m8)
+// DMA (k_encrypt_md, GROUPS = 1): the batch operands reach LDS by direct global -> LDS loads (buffer_load_dwordx4 ... lds, no
+// registers; see k_decrypt_m8d).  r of the NEXT row block is requested into the r stage once every wave has left its last matrix
+// loop -- in front of the last epilogue's stores instead of behind them (phase stamps: the rows requested at the top of a trip
+// come back 8-9 k cycles later) -- and brought into operand form (shift to byte 0, columns >= N zeroed) in place by the wave that
+// owns the row; m is requested straight into the m image at the top of a trip and only waited for before the first epilogue.
+// Two more barriers per row block, all of them LDS-only.
+template <int MAXT, int GROUPS, bool CHUNK = false, bool DMA = false>   // GROUPS = 2: the lock-step schedule of decrypt_m_body (k_encrypt_m8)
 static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 *__restrict__ h,
                                                       const uint8_t *__restrict__ r,
                                                       const uint8_t *__restrict__ m, long B,
                                                       u16 *__restrict__ e, u16 *__restrict__ quotE) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  static_assert(!DMA || (GROUPS == 1 && !CHUNK), "the direct-to-LDS variant is built on the plain two-workgroup kernel");
+  auto wg_barrier = [&]() {                                // DMA: LDS-only (with such loads in flight __syncthreads() waits for vmcnt(0): every store)
+    if (DMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+  };
   const int group = GROUPS == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
   u32 *T0 = (u32 *)lds, *T1 = T0 + 4 * g.tpitch;         // key arrays (shared by the groups), then per group [r stage][m image]
   const int gbytes = 32 * g.pitchA + ((32 * g.ld + 15) & ~15) + 16 + (CHUNK ? WAVES_PER_BLOCK * OC_BYTES : 0);
@@ -2158,13 +2169,46 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
   const bool want_q = quotE != nullptr;
   const long nrb = (B + 31) >> 5;
   int sidx = 0, stamp_iter = -1;
-  auto phase = [&]() { if (GROUPS == 2) __syncthreads(); };
-  if (GROUPS == 2 && group == 1) __syncthreads();          // group 1 runs one phase behind group 0
+  auto phase = [&]() { if (GROUPS == 2) wg_barrier(); };
+  if (GROUPS == 2 && group == 1) wg_barrier();          // group 1 runs one phase behind group 0
   const long stride = (long)gridDim.x * GROUPS, iters = (nrb + stride - 1) / stride;
   const int rounds = (((g.NT + MAXT - 1) / MAXT) + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  // DMA: pieces start at absolutely dword-aligned addresses (descriptor based at the dword at or below the row block, size in
+  // whole dwords: see k_decrypt_m8d), so a row lands 0-3 bytes into its slot and the image 0-3 bytes into the m image.
+  auto dma_r = [&](long rbx, int lane) {                    // rows wave, wave + 4, ... into the r stage, one instruction per row
+    const long b0x = rbx << 5 < B ? rbx << 5 : B;
+    const unsigned long long a = (unsigned long long)(r + b0x * g.ld);
+    const int a0 = (int)(a & 3);
+    const __amdgpu_buffer_rsrc_t rs = rows_rsrc((const void *)(a & ~3ULL), ((B - b0x) * g.ld + a0 + 3) & ~3L);
+#pragma unroll
+    for (int j = 0; j < 32 / WAVES_PER_BLOCK; j++) {
+      const int row = wave + WAVES_PER_BLOCK * j, ro = a0 + row * g.ld;
+      if (lane < (((ro & 3) + g.N + 15) >> 4))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(stA + row * g.pitchA), 16,
+                                                 (ro & ~3) + 16 * lane, 0, 0, 0);
+    }
+  };
+  auto dma_m = [&](long rbx, int tid) {                     // the 32 rows of m as one run of 16-byte pieces into the m image
+    const long b0x = rbx << 5 < B ? rbx << 5 : B;
+    const unsigned long long a = (unsigned long long)(m + b0x * g.ld);
+    const int a0 = (int)(a & 3);
+    const __amdgpu_buffer_rsrc_t rs = rows_rsrc((const void *)(a & ~3ULL), ((B - b0x) * g.ld + a0 + 3) & ~3L);
+    const int npc = (a0 + 32 * g.ld + 15) >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; j++)                             // 8 x 256 pieces >= 32 x 1024 / 16
+      if (tid + j * BLOCK_THREADS < npc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(mimg + 16 * (wave * 64 + j * BLOCK_THREADS)), 16,
+                                                 16 * (tid + j * BLOCK_THREADS), 0, 0, 0);
+  };
+  if (DMA) {
+    dma_r((long)blockIdx.x < nrb ? (long)blockIdx.x : nrb, lane0);
+    __builtin_amdgcn_s_waitcnt(0);                         // nothing else is in flight yet
+  }
   for (long it = 0; it < iters; it++) {
     long rb = (long)blockIdx.x * GROUPS + group + it * stride;   // past the end: a row block of zeros whose stores are dropped
     rb = rb < nrb ? rb : nrb;
+    long rb_next = (long)blockIdx.x * GROUPS + group + (it + 1) * stride;
+    rb_next = rb_next < nrb ? rb_next : nrb;
     stamp_iter++;
     STAMP(0);
     // Re-materialise the lane index and N per row block: otherwise every per-lane address / predicate of the staging
@@ -2183,7 +2227,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
     constexpr int RPW = 32 / WAVES_PER_BLOCK;
     const int shm = __builtin_amdgcn_readfirstlane(src_m.a0);
     RawChunks<1> in_r[RPW], in_m[8];
-    {
+    if (!DMA) {
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
         const int pos0 = src_r.a0 + (wave + WAVES_PER_BLOCK * j) * LD;
@@ -2203,9 +2247,30 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
 #endif
       }
     }
-    __syncthreads();                                    // the previous row block's readers are done (first pass: key arrays built)
+    wg_barrier();                                    // the previous row block's readers are done (first pass: key arrays built)
     STAMP(1);
-    {
+    const int a0m = DMA ? __builtin_amdgcn_readfirstlane((int)((unsigned long long)(m + b0 * LD) & 3)) : 0;   // DMA: the m image starts a0m bytes in
+    if (DMA) {                                       // every wave's r rows have landed (each waited for its own in its last epilogue)
+      dma_m(rb, tid);
+      const int a0r = (int)((unsigned long long)(r + b0 * LD) & 3);
+      const v4i mk = col_mask16(16 * lane, N);
+      int s4[RPW];
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {                // all reads of the wave's rows before the first write back
+        const int row = wave + WAVES_PER_BLOCK * j;
+        const unsigned char *slot = stA + row * g.pitchA + 16 * (lane < 2 * g.NT ? lane : 0);
+        in_r[j].c[0] = *(const v4i *)slot;
+        in_r[j].tail = *(const u32 *)(slot + 16);
+        s4[j] = __builtin_amdgcn_readfirstlane((a0r + row * LD) & 3);
+      }
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const int row = wave + WAVES_PER_BLOCK * j;
+        v4i v[1];
+        shift_raw<1>(in_r[j], s4[j], v);
+        if (lane < 2 * g.NT) *(v4i *)(stA + row * g.pitchA + 16 * lane) = v[0] & mk;
+      }
+    } else {
       const v4i mk = col_mask16(16 * lane, N);
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
@@ -2224,10 +2289,20 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
       }
     }
     STAMP(2);
-    __syncthreads();
+    wg_barrier();
     STAMP(3);
     sidx = 0;
-    for_each_strip<MAXT>(g.NT, GROUPS == 2 ? wave ^ (2 * group) : wave, [&](int kb0, int nt) {
+    // DMA: what a wave does at the start of an epilogue, strip or no strip (every wave walks through every round): wait for its m
+    // pieces before the first one, barriers before the first (m image complete) and the last (r stage free of readers), then the
+    // request for the next row block's r rows -- in front of this epilogue's stores.
+    auto epi_sync = [&]() {
+      if (!DMA) return;
+      if (sidx == 0) __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));          // vmcnt(0): this wave's m pieces (the loops issue no vector memory operation)
+      if (sidx == 0 || sidx == rounds - 1) wg_barrier();
+      if (sidx == rounds - 1 && it + 1 < iters) dma_r(rb_next, lane);
+    };
+    const bool dma_now = DMA && it + 1 < iters;          // (in the last round) r rows of the next row block are in flight behind this epilogue's stores
+    for_each_strip<MAXT>(g.NT, GROUPS == 2 ? wave ^ (2 * group) : (DMA ? wave ^ (2 * (int)blockIdx.x >= (int)gridDim.x ? 2 : 0) : wave), [&](int kb0, int nt) {
       // Result register i of a tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31: a per-lane offset
       // plus a wave-uniform (scalar) offset per register; rows past the batch end are dropped by the descriptor.
       // (Packing 4 columns per lane with in-quad transposes and 64-bit stores was measured 8 % slower: the rows are only
@@ -2236,6 +2311,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
       auto epi = [&](auto &lo, auto &hi) {               // arrays of the strip's tiles
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
         phase();                                         // matrix loop | epilogue
+        epi_sync();
         long bb = b0;                                    // descriptors made where they are used: see k_decrypt_m
 #if NTRU_ABLATE & 512
         bb = 0;                                          // timing only: every workgroup writes the first row block (L2-resident)
@@ -2244,7 +2320,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
         const long lf = (B - bb) * LD;
         const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + bb * LD, 2 * lf);
         const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quotE + bb * LD : e + bb * LD, 2 * lf);
-        const unsigned char *m_l = mimg + 32 * kb0 + lane_off;
+        const unsigned char *m_l = mimg + a0m + 32 * kb0 + lane_off;
         // columns >= N (last tile only) get an offset beyond any descriptor: the hardware drops those lanes, no
         // exec-mask region per store
         int voff[NTS];
@@ -2301,6 +2377,10 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
                 }
               }
             }
+            // DMA: the row loads are older than the stores issued since and vector memory operations complete in order: at most K
+            // outstanding = the rows have landed (see k_decrypt_m8d)
+            constexpr int per_j = 4 * NTS * (decltype(wq)::value ? 2 : 1), jw = 2 * per_j <= 63 ? 1 : 0, K = per_j * (jw + 1);
+            if (DMA && j == jw && dma_now && sidx == rounds - 1) __builtin_amdgcn_s_waitcnt((K & 15) | (7 << 4) | (15 << 8) | ((K >> 4) << 14));
           }
         };
         // CHUNK: the strip's results go through the wave's LDS chunk, 8 rows at a time, laid out with the 16-byte phase the
@@ -2369,7 +2449,10 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
         else if (want_q) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
-        case 0: phase(); break;
+        case 0:                                          // no strip this round: keep the barriers (and this wave's row request) in step
+          phase(); epi_sync();
+          if (DMA && sidx == rounds - 1) __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0): nothing of its own is stored after them
+          break;
         case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
@@ -2378,9 +2461,9 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
       }
       sidx++;
       if (sidx < rounds) phase();                        // epilogue | next matrix loop
-    }, GROUPS == 2);
+    }, GROUPS == 2 || DMA);
   }
-  if (GROUPS == 2 && group == 0) __syncthreads();        // group 1's last phase
+  if (GROUPS == 2 && group == 0) wg_barrier();        // group 1's last phase
 }
 
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, const u16 *__restrict__ h,
@@ -2395,6 +2478,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_mc(MGeom g, u32 q,
                                                               const uint8_t *__restrict__ m, long B,
                                                               u16 *__restrict__ e, u16 *__restrict__ quotE) {
   encrypt_m_body<4, 1, true>(g, q, h, r, m, B, e, quotE);
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_md(MGeom g, u32 q, const u16 *__restrict__ h,
+                                                              const uint8_t *__restrict__ r,
+                                                              const uint8_t *__restrict__ m, long B,
+                                                              u16 *__restrict__ e, u16 *__restrict__ quotE) {
+  encrypt_m_body<4, 1, false, true>(g, q, h, r, m, B, e, quotE);
 }
 
 __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_encrypt_m8(MGeom g, u32 q, const u16 *__restrict__ h,
@@ -3898,6 +3988,16 @@ extern "C" int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
       if (int rc = resident_grid(eng, k_encrypt_mc, ldsc, (long)((B + 31) / 32), &L.grid)) return rc;
       snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_encrypt_mc");
       hipLaunchKernelGGL(k_encrypt_mc, L.grid, dim3(BLOCK_THREADS), ldsc, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B,
+                         d_e, d_quotE);
+      HIP_TRY(hipGetLastError());
+      return NTRU_OK;
+    }
+    // The default: the operands reach LDS by direct-to-LDS loads, r of the next row block ahead of the last epilogue's stores:
+    // 1.49-1.51 ms against 1.57-1.62 ms per 2^20 at N = 821 on the same device (profiles/r02_ab_direct_to_lds_rows.txt).
+    if (lds && (eng->path == 0 || eng->path == 8) && lds <= 160 * 1024) {
+      if (int rc = resident_grid(eng, k_encrypt_md, lds, (long)((B + 31) / 32), &L.grid)) return rc;
+      snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_encrypt_md");
+      hipLaunchKernelGGL(k_encrypt_md, L.grid, dim3(BLOCK_THREADS), lds, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B,
                          d_e, d_quotE);
       HIP_TRY(hipGetLastError());
       return NTRU_OK;

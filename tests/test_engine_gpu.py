@@ -271,7 +271,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8",), 6: ("k_encrypt_m2",),
                                          7: ("k_encrypt_mc",) if N < 1024 else ("k_encrypt_m",),   # 7: result chunks, when two workgroups' LDS fits
-                                         8: ("k_encrypt_m",)}[path]                                # 8: direct-to-LDS row loads (decrypt only)
+                                         8: ("k_encrypt_md",)}[path]                               # 8: direct-to-LDS loads of the operands
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -312,7 +312,7 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8", "k_encrypt_m"), 6: ("k_encrypt_m2",),
-                                         7: ("k_encrypt_mc", "k_encrypt_m"), 8: ("k_encrypt_m",)}[path]
+                                         7: ("k_encrypt_mc", "k_encrypt_m"), 8: ("k_encrypt_md",)}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
             ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])
@@ -339,7 +339,7 @@ def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
     e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
     want = orc.decrypt_batch(N, q, p, f, fp, e_o)
     for path, ename, dname in ((5, "k_encrypt_m8", "k_decrypt_m8"), (6, "k_encrypt_m2", "k_decrypt_m"),
-                               (8, "k_encrypt_m", "k_decrypt_m8d")):      # 8: every trip but the first decrypts rows loaded straight into LDS
+                               (8, "k_encrypt_md", "k_decrypt_m8d")):     # 8: every trip but the first works on rows loaded straight into LDS
         eng.set_kernel_path(path)
         try:
             e, quot = eng.encrypt_batch(N, q, h, r, m)
