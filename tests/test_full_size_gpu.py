@@ -214,6 +214,12 @@ def test_config4_encrypt_2e20(ctx):
             assert torch.equal(e, res[4][0]) and torch.equal(qe, res[4][1])
         else:
             res[path] = (e, qe, eng.last_kernel())
+    eng.set_kernel_path(8)                                  # and without the quotient array (other store counts behind the early loads)
+    e = new16()
+    eng.encrypt_batch_dev(n, q, h.data_ptr(), r.data_ptr(), m1.data_ptr(), B, e.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert eng.last_kernel() == "k_encrypt_md" and torch.equal(e, res[4][0])
+    del e
     eng.set_kernel_path(0)
     assert res[4][2] == "k_encrypt_m" and res[2][2].startswith("k_encrypt_t")
     assert torch.equal(res[4][0], res[2][0]) and torch.equal(res[4][1], res[2][1])
