@@ -2842,7 +2842,13 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
         if (want_q2) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
-        case 0: phase(4); break;
+        case 0:                                          // no strip this round: the phase barrier -- and this wave's rows of the next row block
+          phase(4);
+          if (DMA && sidx == rounds - 1 && it + 1 < iters) {
+            dma_rows(rb_next, lane);
+            __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));                       // vmcnt(0): it stores nothing behind them
+          }
+          break;
         case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
         case 2: toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
         case 3: toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;

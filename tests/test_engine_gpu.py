@@ -324,7 +324,8 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
         eng.set_kernel_path(0)
 
 
-@pytest.mark.parametrize("N,q,B", [(167, 128, 32 * 256 * 3 + 5), (821, 4096, 32 * 256 * 2 + 33), (65, 64, 32 * 256 + 1)])
+@pytest.mark.parametrize("N,q,B", [(167, 128, 32 * 256 * 3 + 5), (821, 4096, 32 * 256 * 2 + 33), (65, 64, 32 * 256 + 1),
+                                   (65, 64, 32 * 256 * 5 + 9), (33, 32, 32 * 256 * 5 + 3)])   # waves WITHOUT a strip (NT < 4) on their second trip
 def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
     """Batches of more than two row blocks per CU: the persistent loop of the role-split kernels alternates its two
     operand stages and drains every chunk one round late, the last one after the loop; ragged last row block."""
