@@ -2377,11 +2377,12 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
                 }
               }
             }
-            // DMA: the row loads are older than the stores issued since and vector memory operations complete in order: at most K
-            // outstanding = the rows have landed (see k_decrypt_m8d)
-            constexpr int per_j = 4 * NTS * (decltype(wq)::value ? 2 : 1), jw = 2 * per_j <= 63 ? 1 : 0, K = per_j * (jw + 1);
-            if (DMA && j == jw && dma_now && sidx == rounds - 1) __builtin_amdgcn_s_waitcnt((K & 15) | (7 << 4) | (15 << 8) | ((K >> 4) << 14));
           }
+          // DMA: the row loads are older than the S stores issued since and vector memory operations complete in order: at most
+          // min(S, 63) outstanding = the rows have landed (and the S - 63 oldest stores with them).  At the END of the epilogue:
+          // the loads have had its whole length (phase stamps: waiting after the second group of rows cost ~3 k cycles).
+          constexpr int S = 16 * NTS * (decltype(wq)::value ? 2 : 1), K = S < 63 ? S : 63;
+          if (DMA && dma_now && sidx == rounds - 1) __builtin_amdgcn_s_waitcnt((K & 15) | (7 << 4) | (15 << 8) | ((K >> 4) << 14));
         };
         // CHUNK: the strip's results go through the wave's LDS chunk, 8 rows at a time, laid out with the 16-byte phase the
         // rows have in global memory, and leave as ALIGNED 16-byte pieces (lane = piece: 4 rows x 16 pieces per store) plus the
@@ -2833,11 +2834,11 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
                 }
               }
             }
-            // DMA: the row loads are older than the stores issued since (vector memory operations complete in order): at most
-            // K outstanding operations = the loads have landed.  After the second group of rows when that keeps K <= 63.
-            constexpr int per_j = 4 * NTS * (decltype(wq)::value ? 2 : 1), jw = 2 * per_j <= 63 ? 1 : 0, K = per_j * (jw + 1);
-            if (DMA && j == jw && dma_now) __builtin_amdgcn_s_waitcnt((K & 15) | (7 << 4) | (15 << 8) | ((K >> 4) << 14));
           }
+          // DMA: the row loads are older than the S stores issued since (vector memory operations complete in order): at most
+          // min(S, 63) outstanding operations = the loads have landed.  At the end of the epilogue: they have had its whole length.
+          constexpr int S = 16 * NTS * (decltype(wq)::value ? 2 : 1), K = S < 63 ? S : 63;
+          if (DMA && dma_now) __builtin_amdgcn_s_waitcnt((K & 15) | (7 << 4) | (15 << 8) | ((K >> 4) << 14));
         };
         if (want_q2) out(std::true_type{}); else out(std::false_type{});
       };

@@ -48,6 +48,13 @@ for _ in range(2):
 st = read()
 report("k_encrypt_m", st, [(0, 1, "wait barrier1"), (1, 16, "stage r"), (16, 2, "stage m"), (2, 3, "wait barrier2"), (3, 4, "loops s1"), (4, 5, "epilogue s1"),
                            (5, 6, "loops s2"), (6, 7, "epilogue s2")], 512)
+eng.set_kernel_path(8)      # k_encrypt_md: operands by direct-to-LDS loads (the default encrypt kernel)
+for _ in range(2):
+    eng.encrypt_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e.data_ptr(), qe.data_ptr())
+st = read()
+report("k_encrypt_md", st, [(0, 1, "wait barrier1"), (1, 2, "request m, r in place"), (2, 3, "wait barrier2"), (3, 4, "loops s1"), (4, 5, "(m wait, barrier) epilogue s1"),
+                            (5, 6, "loops s2"), (6, 7, "(barrier, request r) epilogue s2")], 512)
+eng.set_kernel_path(4)
 for _ in range(2):
     eng.decrypt_batch_dev(N, q, 3, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr(), q1.data_ptr(), r1.data_ptr(), q2.data_ptr())
 st = read()
