@@ -31,7 +31,7 @@ int main() {
   for (int i = 0; i < n + 64; i++) h[i] = (unsigned char)(i * 7 + (i >> 8));
   unsigned char *d, *o; CK(hipMalloc(&d, n + 64)); CK(hipMalloc(&o, n));
   CK(hipMemcpy(d, h.data(), n + 64, hipMemcpyHostToDevice));
-  for (int off : {0, 4, 2}) for (int limit : {n, n - 1000}) for (int rev : {0, 1}) {
+  for (int off : {0, 4, 2, 1, 3, 7}) for (int limit : {n, n - 1000}) for (int rev : {0, 1}) {
     CK(hipMemset(o, 0, n));
     k<<<1, 256, 16 * 1024>>>(d + off, o, limit, rev);
     CK(hipDeviceSynchronize());
