@@ -1821,7 +1821,7 @@ enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
 #ifdef NTRU_STAMPS
 #define STAMP_SLOTS 24
 #define STAMP_BLOCKS 6
-__device__ unsigned long long g_stamps[1024][4][STAMP_BLOCKS][STAMP_SLOTS];
+__device__ unsigned long long g_stamps[1024][8][STAMP_BLOCKS][STAMP_SLOTS];     // [workgroup][wave: 8 in the lock-step kernels]
 #define STAMP(slot)                                                                                          \
   do {                                                                                                       \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024 && stamp_iter < STAMP_BLOCKS)                           \

@@ -22,13 +22,13 @@ r = torch.randint(0, 3, (B, N), dtype=torch.uint8, device=dev); m = torch.randin
 e = torch.empty((B, N), dtype=torch.int16, device=dev); qe = torch.empty_like(e)
 v = torch.empty((B, N), dtype=torch.uint8, device=dev); q2 = torch.empty_like(v); q1 = torch.empty_like(e); r1 = torch.empty_like(e)
 SLOTS, BLK = 24, 6
-buf = np.zeros((1024, 4, BLK, SLOTS), np.uint64)
+buf = np.zeros((1024, 8, BLK, SLOTS), np.uint64)
 def read():
     torch.cuda.synchronize()
     assert lib.ntru_debug_read_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
     return buf.copy()
-def report(name, st, labels, nblocks):
-    st = st[:nblocks].astype(np.int64)
+def report(name, st, labels, nblocks, waves=slice(0, 4)):
+    st = st[:nblocks, waves].astype(np.int64)
     print("==", name, "(median over workgroups x waves, iterations 2..4; cycles)")
     for it in (2, 3, 4):
         row = []
@@ -61,3 +61,20 @@ st = read()
 report("k_decrypt_m", st, [(0, 1, "wait b1"), (1, 2, "stage"), (2, 3, "wait b2"), (3, 4, "P1 loops s1"), (4, 5, "P1 epi s1"), (5, 6, "P1 loops s2"),
                            (6, 7, "P1 epi s2"), (7, 8, "wait b3"), (8, 9, "expand"), (9, 10, "wait b4"), (10, 11, "P2 loops s1"), (11, 12, "P2 epi s1"),
                            (12, 13, "P2 loops s2"), (13, 14, "P2 epi s2")], 512)
+
+# the lock-step kernel: one workgroup of two four-wave groups per CU; per group (group 1 runs one phase behind)
+eng.set_kernel_path(5)
+for _ in range(2):
+    eng.decrypt_batch_dev(N, q, 3, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr(), q1.data_ptr(), r1.data_ptr(), q2.data_ptr())
+st = read()
+lab8 = [(0, 1, "wait b1"), (1, 2, "stage"), (2, 3, "wait b2"), (3, 4, "P1 loops s1"), (4, 5, "P1 (phase barrier) epi s1"), (5, 6, "(barrier) P1 loops s2"),
+        (6, 7, "P1 (barrier) epi s2"), (7, 8, "wait b3"), (8, 9, "expand"), (9, 10, "wait b4"), (10, 11, "P2 loops s1"), (11, 12, "P2 (barrier) epi s1"),
+        (12, 13, "(barrier) P2 loops s2"), (13, 14, "P2 (barrier) epi s2")]
+report("k_decrypt_m8 group 0", st, lab8, 256, slice(0, 4))
+report("k_decrypt_m8 group 1", st, lab8, 256, slice(4, 8))
+eng.set_kernel_path(8)
+for _ in range(2):
+    eng.decrypt_batch_dev(N, q, 3, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr(), q1.data_ptr(), r1.data_ptr(), q2.data_ptr())
+st = read()
+report("k_decrypt_m8d group 0 (rows by direct-to-LDS loads)", st, lab8, 256, slice(0, 4))
+report("k_decrypt_m8d group 1", st, lab8, 256, slice(4, 8))
