@@ -2,7 +2,11 @@
 """Headline benchmark: NTRU encrypt+decrypt round trips per second at N=821, q=4096 (BASELINE.json).
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (no RANK in the environment: bench.py starts the N ranks itself, as
+                                                          a CHILD `python -m torch.distributed.run`, before anything touches HIP)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Every rank checks WORLD_SIZE == --gpus and refuses to run otherwise.
 
 One "step" = one pass of the hot path over one batch of B synthetic plaintexts that are already resident in
 HBM: ntru_encrypt_batch_dev (encryptBits, index.js:87-110) followed by ntru_decrypt_batch_dev of the fresh
@@ -13,6 +17,8 @@ B per GPU is fixed).  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -29,7 +35,7 @@ DOT8_PEAK_T = 302.0            # measured v_dot8_u32_u4 roof: 37.9 T lane-instr/
 ADD_PEAK_T = 134.0             # measured v_add_u32 roof 67 T lane-adds/s x 2 packed 16-bit coefficients per add
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -51,12 +57,62 @@ def parse_args():
     ap.add_argument("--sample-r", action="store_true",
                     help="draw r with the engine's on-device sampler (generateCustomArray on a ChaCha20 stream) "
                          "instead of torch; the timed region is unchanged")
-    ap.add_argument("--gather", action="store_true", help="after timing, all_gather the decrypted values (RCCL)")
+    ap.add_argument("--gather", action="store_true",
+                    help="after timing, gather the decrypted values of every rank onto rank 0 (one gather-to-root, RCCL over "
+                         "xGMI; with gloo through host memory); reported under `gather`")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the timing all_reduce / barrier / gather even with ONE rank "
                          "(RCCL refuses two ranks on one device, so this is how the RCCL code path is exercised on a 1-GPU box)")
     ap.add_argument("--check-rows", type=int, default=1 << 14, help="rows of the batch verified against the CPU oracle")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launcher_command(args, argv, environ, port=None):
+    """`python bench.py --gpus N` outside a launcher (no RANK in the environment) -> the command line of the child that
+    starts the N ranks, else None.  One process per GPU over torch.distributed.run, rendezvous on 127.0.0.1."""
+    if args.gpus <= 1 or "RANK" in environ:
+        return None
+    if port is None:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def pick_result_line(text):
+    """The one JSON line of rank 0 among whatever else the ranks printed on stdout."""
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if isinstance(d, dict) and ("metric" in d or "ABLATION_NOT_A_RESULT" in d):
+                return line
+    return None
+
+
+def spawn_ranks(cmd):
+    """Runs the launcher as a CHILD process (this process has not imported torch or touched HIP, and never replaces
+    itself: an exec from a GPU-initialised process is refused on the pool), relays rank 0's JSON line, returns its rc."""
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE)
+    line = pick_result_line(proc.stdout.decode("utf-8", "replace"))
+    if line is not None:
+        sys.stdout.write(line + "\n"); sys.stdout.flush()
+    elif proc.returncode == 0:
+        sys.stderr.write("bench: the ranks exited 0 without a result line\n")
+        return 1
+    return proc.returncode
+
+
+def check_world(args, environ):
+    """WORLD_SIZE must be what --gpus says: a mismatch means the launch is not the one the caller asked for."""
+    world = int(environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d: start the ranks with `python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d` or let `python bench.py --gpus %d` do it"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    return world
 
 
 def load_key(profile):
@@ -167,6 +223,10 @@ def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
 
 def main():
     args = parse_args()
+    cmd = launcher_command(args, sys.argv[1:], os.environ)
+    if cmd is not None:
+        raise SystemExit(spawn_ranks(cmd))
+    world = check_world(args, os.environ)
     # Rank 0 prints ONE JSON line on stdout.  RCCL prints a version banner to stdout when the process group starts, so
     # file descriptor 1 is pointed at stderr for the duration of the run and the line goes to the real stdout at the end.
     sys.stdout.flush()
@@ -178,7 +238,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     dev_index = local_rank if args.device is None else args.device
@@ -267,16 +326,23 @@ def main():
     bad = []
 
     def check(lo, hi):
-        e_o, qe_o = orc.encrypt_batch(N, q, h_np, r_h[lo:hi], m_h[lo:hi])
-        v_o, q1_o, r1_o, q2_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)
-        want = {"e": e_o, "value": v_o, "quotE": qe_o, "quot1": q1_o, "rem1": r1_o, "quot2": q2_o}
-        for k, a in got.items():
-            if not np.array_equal(a[lo:hi], want[k]):
-                bad.append(k)
+        try:
+            e_o, qe_o = orc.encrypt_batch(N, q, h_np, r_h[lo:hi], m_h[lo:hi])
+            v_o, q1_o, r1_o, q2_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)
+            want = {"e": e_o, "value": v_o, "quotE": qe_o, "quot1": q1_o, "rem1": r1_o, "quot2": q2_o}
+            for k, a in got.items():
+                if not np.array_equal(a[lo:hi], want[k]):
+                    bad.append(k)
+            done.append(hi - lo)
+        except BaseException as exc:        # a worker that dies must not read as "nothing differed"
+            bad.append("check(%d, %d) raised %r" % (lo, hi, exc))
 
+    done = []
     cuts = np.linspace(0, len(r_h), n_thr + 1).astype(int)
     ths = [threading.Thread(target=check, args=(int(cuts[i]), int(cuts[i + 1]))) for i in range(n_thr) if cuts[i] < cuts[i + 1]]
     [t.start() for t in ths]; [t.join() for t in ths]
+    if sum(done) != len(r_h) and not bad:
+        bad.append("only %d of %d rows were compared" % (sum(done), len(r_h)))
     ok = not bad
     ablation = bool(os.environ.get("NTRU_ENGINE_LIB")) and os.environ.get("NTRU_BENCH_ABLATION") == "1"
     if not ok and not ablation:
@@ -284,12 +350,24 @@ def main():
 
     gathered = None
     if args.gather and dist:
-        torch.cuda.synchronize(); tg = time.perf_counter()
-        allv = sh.gather_rows(value if args.dist_backend == "nccl" else value.cpu(), dist, always=args.force_dist)
-        torch.cuda.synchronize()
-        gathered = {"rows": int(allv.shape[0]), "bytes_per_rank": int(value.numel()), "seconds": time.perf_counter() - tg,
-                    "backend": args.dist_backend, "ranks": world,
-                    "rows_equal_local_shard": bool(torch.equal(allv[rank * B:(rank + 1) * B].to(value.device), value))}
+        # The final gather: every rank's decrypted values onto rank 0, once (gather-to-root; nccl = RCCL over xGMI, GPU
+        # memory to GPU memory; gloo = through host memory).  Outside the timed region; its time is reported, not hidden.
+        on_dev = args.dist_backend == "nccl"
+        local = value if on_dev else value.cpu()
+        sums = sh.shard_checksums(local, dist, always=args.force_dist)
+        torch.cuda.synchronize(); dist.barrier(); tg = time.perf_counter()
+        allv = sh.gather_rows(local, dist, always=args.force_dist, root=0)
+        torch.cuda.synchronize(); dist.barrier(); tgather = time.perf_counter() - tg
+        if rank == 0:
+            per = [sh.shard_checksums(allv[k * B:(k + 1) * B], None)[0].item() for k in range(world)]
+            gathered = {"kind": "gather_to_root", "root": 0, "consumed_on": "GPU 0 (HBM)" if on_dev else "host memory of rank 0",
+                        "rows": int(allv.shape[0]), "bytes_per_rank": int(value.numel()), "seconds": tgather,
+                        "backend": args.dist_backend, "ranks": world,
+                        "rows_equal_local_shard": bool(torch.equal(allv[:B].to(value.device), value)),
+                        "every_shard_checksum_matches_its_owner": per == [int(x) for x in sums.tolist()]}
+            if not (gathered["rows_equal_local_shard"] and gathered["every_shard_checksum_matches_its_owner"]):
+                raise SystemExit("bench: gathered rows differ from what the ranks computed")
+        del allv
 
     if rank == 0:
         total = world * B * args.steps

@@ -4001,7 +4001,13 @@ extern "C" int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
     }
     // The default: the operands reach LDS by direct-to-LDS loads, r of the next row block ahead of the last epilogue's stores:
     // 1.49-1.51 ms against 1.57-1.62 ms per 2^20 at N = 821 on the same device (profiles/r02_ab_direct_to_lds_rows.txt).
-    if (lds && (eng->path == 0 || eng->path == 8) && lds <= 160 * 1024) {
+    // One direct-to-LDS instruction moves 64 x 16 bytes from the dword at or below a row, and eight of them per thread the m
+    // image: a row of (its byte phase) + N > 1024 bytes, or an image of (phase) + 32 ld > 32768 bytes, would lose its last 1-3
+    // bytes.  Those shapes (N >= 1022, or ld = 1024, with rows that are not dword-aligned) take k_encrypt_m, whose register
+    // staging fetches the extra dword.
+    const bool rows_dword_aligned = (ld & 3) == 0 && ((uintptr_t)d_r & 3) == 0, img_dword_aligned = (ld & 3) == 0 && ((uintptr_t)d_m & 3) == 0;
+    const bool dma_fits = (N + 3 <= 1024 || (rows_dword_aligned && N <= 1024)) && (32 * ld + 3 <= 32768 || (img_dword_aligned && 32 * ld <= 32768));
+    if (lds && (eng->path == 0 || eng->path == 8) && lds <= 160 * 1024 && dma_fits) {
       if (int rc = resident_grid(eng, k_encrypt_md, lds, (long)((B + 31) / 32), &L.grid)) return rc;
       snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_encrypt_md");
       hipLaunchKernelGGL(k_encrypt_md, L.grid, dim3(BLOCK_THREADS), lds, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B,

@@ -48,11 +48,34 @@ def timed_region(run_steps, sync, dist=None, device=None, always=False):
     return max_over_ranks(time.perf_counter() - t0, dist, device, always)
 
 
-def gather_rows(local, dist, always=False):
-    """Final gather of per-rank output rows ([b_rank, N] each, equal b_rank) onto every rank, in rank order."""
+def gather_rows(local, dist, always=False, root=0):
+    """The final gather (BASELINE north_star: "RCCL over xGMI only for the final gather"): per-rank output rows
+    ([b_rank, N] each, equal b_rank) travel ONCE, onto `root`, in rank order -- a gather-to-root, not an all_gather: every
+    other rank only sends, so the receive volume is (world - 1) shards on one GPU instead of on all of them (root's inbound
+    xGMI links bound it).  Returns the concatenation on `root`, None elsewhere; `local` itself without a process group."""
     import torch
     if not _active(dist, always):
         return local
-    outs = [torch.empty_like(local) for _ in range(dist.get_world_size())]
-    dist.all_gather(outs, local.contiguous())
-    return torch.cat(outs, dim=0)
+    local = local.contiguous()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    outs = [torch.empty_like(local) for _ in range(world)] if rank == root else None
+    dist.gather(local, outs, dst=root)
+    return torch.cat(outs, dim=0) if rank == root else None
+
+
+def shard_checksums(local, dist, always=False):
+    """One int64 checksum per rank (a position-weighted sum of the rank's rows), all_gathered: 8 bytes per rank, so root can
+    check every gathered shard against what its owner computed without a second copy of the data."""
+    import torch
+    flat = local.reshape(-1)
+    mine = torch.zeros(1, dtype=torch.int64, device=flat.device)
+    step = 1 << 24                                             # bounded temporaries: a shard may be gigabytes
+    for o in range(0, flat.numel(), step):
+        part = flat[o:o + step].to(torch.int64)
+        w = (torch.arange(o, o + part.numel(), device=flat.device, dtype=torch.int64) % 65521) + 1
+        mine += (part * w).sum()
+    if not _active(dist, always):
+        return mine
+    outs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, mine)
+    return torch.cat(outs)

@@ -251,7 +251,7 @@ def test_kernel_families_agree(eng):
 
 @pytest.mark.parametrize("N,q,d", [(17, 32, 2), (31, 64, 5), (32, 128, 6), (33, 32, 7), (64, 8192, 20), (65, 4096, 21),
                                    (167, 128, 18), (509, 2048, 169), (701, 8192, 233), (821, 4096, 273),
-                                   (1024, 8192, 300)])
+                                   (1021, 4096, 300), (1022, 2048, 300), (1023, 8192, 300), (1024, 8192, 300)])
 @pytest.mark.parametrize("path", [4, 5, 6, 7, 8])
 def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
     """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step groups; 6: role-split encrypt), including sizes the
@@ -270,8 +270,8 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8",), 6: ("k_encrypt_m2",),
-                                         7: ("k_encrypt_mc",) if N < 1024 else ("k_encrypt_m",),   # 7: result chunks, when two workgroups' LDS fits
-                                         8: ("k_encrypt_md",)}[path]                               # 8: direct-to-LDS loads of the operands
+                                         7: ("k_encrypt_mc",) if (N + 31) // 32 < 32 else ("k_encrypt_m",),   # 7: result chunks, when two workgroups' LDS fits
+                                         8: ("k_encrypt_md",) if N + 3 <= 1024 else ("k_encrypt_md", "k_encrypt_m")}[path]   # 8: direct-to-LDS loads of the operands (rows that fit one 1024-byte instruction)
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -280,8 +280,9 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             ein[-1] = rng.integers(0, q, N)
             ein[0, :4] = (q - 1, 0, q // 2, q // 2 + 1)
             got = eng.decrypt_batch(N, q, p, f, fp, ein)
-            assert eng.last_kernel() == ("k_decrypt_m8" if path == 5 and N < 1024 else
-                                         "k_decrypt_m8d" if path == 8 and N < 1024 else "k_decrypt_m")   # N = 1024: 160 KB of LDS do not hold two groups
+            two_groups_fit = (N + 31) // 32 < 32                                                        # 32 column tiles: 160 KB of LDS do not hold two groups
+            assert eng.last_kernel() == ("k_decrypt_m8" if path == 5 and two_groups_fit else
+                                         "k_decrypt_m8d" if path == 8 and two_groups_fit else "k_decrypt_m")
             want = orc.decrypt_batch(N, q, p, f, fp, ein)
             for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
                 assert np.array_equal(g_, w_), (B, name)
@@ -355,7 +356,7 @@ def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
 
 
 @pytest.mark.parametrize("path", [0, 8])                   # 8: decrypt's rows arrive by direct-to-LDS loads (dword-aligned pieces + a shift)
-@pytest.mark.parametrize("N,q", [(821, 4096), (167, 128), (701, 8192)])
+@pytest.mark.parametrize("N,q", [(821, 4096), (167, 128), (701, 8192), (1021, 2048), (1022, 4096), (1023, 8192), (1024, 1024)])   # N >= 1022: a row + its byte phase exceeds one 1024-byte direct-to-LDS instruction
 def test_device_pointers_at_any_alignment(eng, N, q, path):
     """The *_dev entry points take any pointer: the matrix-core kernels read rows through aligned chunks + shifts and
     write through byte/short stores, so buffers that start at odd byte offsets must give the same results."""

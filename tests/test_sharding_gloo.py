@@ -1,5 +1,6 @@
 """N>1 path on CPU: two processes over gloo exercise the sharding, max-over-ranks timing and final gather that
 bench.py uses on RCCL.  The product kernels need a GPU, so the CPU oracle stands in as the per-shard compute."""
+import json
 import os
 import socket
 
@@ -42,10 +43,15 @@ def _worker(rank, world, port, q_out):
         e_local, _ = orc.encrypt_batch(N, q, h, r[lo:hi], m[lo:hi])
         elapsed = sh.timed_region(lambda: None, lambda: None, dist, None)
         slow = sh.max_over_ranks(1.0 + rank, dist, None)
-        allrows = sh.gather_rows(torch.from_numpy(e_local.astype(np.int32)), dist)
+        local = torch.from_numpy(e_local.astype(np.int32))
+        sums = sh.shard_checksums(local, dist)
+        allrows = sh.gather_rows(local, dist, root=0)               # gather-to-root: only rank 0 receives
         if rank == 0:
             e_full, _ = orc.encrypt_batch(N, q, h, r, m)
-            q_out.put((bool(np.array_equal(allrows.numpy(), e_full)), slow, elapsed >= 0.0, (lo, hi)))
+            per = [int(sh.shard_checksums(allrows[a:b], None)[0]) for a, b in (sh.shard_range(total, k, world) for k in range(world))]
+            q_out.put((bool(np.array_equal(allrows.numpy(), e_full)) and per == sums.tolist(), slow, elapsed >= 0.0, (lo, hi)))
+        else:
+            assert allrows is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -62,3 +68,43 @@ def test_two_rank_shard_and_gather_matches_single_process():
     assert all(p.exitcode == 0 for p in procs)
     same, slow, ok, span = res
     assert same and slow == 2.0 and ok and span == (0, 5)
+
+
+# ---- bench.py's own launch logic (no GPU, no torch.distributed needed) -------------------------------------------------
+import bench
+
+
+def test_bench_gpus_flag_spawns_a_child_launcher_only_outside_one():
+    args = bench.parse_args(["--gpus", "4", "--steps", "2"])
+    cmd = bench.launcher_command(args, ["--gpus", "4", "--steps", "2"], {}, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    # inside a launcher (RANK set) or with one GPU nothing is spawned: `rocprofv3 -- python3 bench.py` makes no hop
+    assert bench.launcher_command(args, [], {"RANK": "0", "WORLD_SIZE": "4"}) is None
+    assert bench.launcher_command(bench.parse_args([]), [], {}) is None
+    assert bench.launcher_command(bench.parse_args(["--gpus", "1"]), [], {}) is None
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    assert bench.check_world(bench.parse_args(["--gpus", "2"]), {"WORLD_SIZE": "2", "RANK": "1"}) == 2
+    assert bench.check_world(bench.parse_args([]), {}) == 1
+    with pytest.raises(SystemExit):
+        bench.check_world(bench.parse_args(["--gpus", "8"]), {"WORLD_SIZE": "1", "RANK": "0"})
+    with pytest.raises(SystemExit):
+        bench.check_world(bench.parse_args(["--gpus", "1"]), {"WORLD_SIZE": "2", "RANK": "0"})
+
+
+def test_bench_relays_exactly_the_result_line():
+    noise = "RCCL version 2.26\n{\"not\": \"it\"}\n" + '{"metric": "x", "value": 1.0, "n_gpus": 2}' + "\ntrailing\n"
+    assert json.loads(bench.pick_result_line(noise))["n_gpus"] == 2
+    assert bench.pick_result_line("nothing here\n") is None
+
+
+def test_bench_launcher_runs_the_child_and_returns_its_code(tmp_path, capsys):
+    child = tmp_path / "child.py"
+    child.write_text("import sys\nprint('banner')\nprint('{\"metric\": \"m\", \"n_gpus\": 2}')\nsys.exit(int(sys.argv[1]))\n")
+    import sys as _sys
+    assert bench.spawn_ranks([_sys.executable, str(child), "0"]) == 0
+    assert json.loads(capsys.readouterr().out.strip())["n_gpus"] == 2
+    assert bench.spawn_ranks([_sys.executable, str(child), "3"]) == 3
