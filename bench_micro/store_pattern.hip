@@ -68,20 +68,98 @@ __global__ __launch_bounds__(256) void k(unsigned short* out, long nrb, int N) {
   }
 }
 
+// pattern 5: pattern 1 on rows at a pitch of 832 elements (1664 bytes = 13 cache lines): every instruction is one whole line
+template <int PAT>
+__global__ __launch_bounds__(256) void k5(unsigned short* out, long nrb, int N, int LD) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    unsigned short* blk = out + rb * 32 * LD;
+    for (int strip = wave; strip < 8; strip += 4) {
+      const int kb0 = strip * 3 + (strip < 2 ? strip : 2), nt = strip < 2 ? 4 : 3;
+      for (int ro = 0; ro < 32; ro++)
+        for (int t = 0; t < nt; t += 2) {
+          const int col = 32 * (kb0 + t) + lane;
+          if (col < N && (t + 1 < nt || lane < 32)) blk[ro * LD + col] = (unsigned short)(rb + col);
+        }
+    }
+  }
+}
+
+// patterns 6 / 7: the TRANSPOSED accumulator layout (matrix instruction with its operands swapped: lane & 31 = row of the row block,
+// registers = columns (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile).  A lane owns 4 consecutive columns per register group;
+// 6: after one v_permlane32_swap per dword the lower half-wave holds columns 0-7 / 16-23 of its row and the upper half columns
+//    8-15 / 24-31: one 16-byte store per lane, 32 rows x 32 contiguous bytes per instruction (2-byte aligned addresses);
+// 7: without the swap: one 8-byte store per lane, 32 rows x 2 pieces of 8 bytes per instruction.
+template <int PAT>
+__global__ __launch_bounds__(256) void k6(unsigned short* out, long nrb, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    unsigned short* row = out + (rb * 32 + r) * N;
+    for (int strip = wave; strip < 8; strip += 4) {
+      const int kb0 = strip * 3 + (strip < 2 ? strip : 2), nt = strip < 2 ? 4 : 3;
+      for (int t = 0; t < nt; t++) {
+        if (PAT == 6) {
+          for (int g2 = 0; g2 < 2; g2++) {
+            const int col = 32 * (kb0 + t) + 16 * g2 + 8 * h;
+            if (col + 8 <= N) *(uint4*)(row + col) = make_uint4((unsigned)rb, col, r, t);
+            else for (int c = col; c < N; c++) row[c] = (unsigned short)c;
+          }
+        } else {
+          for (int k = 0; k < 4; k++) {
+            const int col = 32 * (kb0 + t) + 8 * k + 4 * h;
+            if (col + 4 <= N) *(uint2*)(row + col) = make_uint2((unsigned)rb, col);
+            else for (int c = col; c < N; c++) row[c] = (unsigned short)c;
+          }
+        }
+      }
+    }
+  }
+}
+
+static void launch(int pat, int cus, unsigned short* d, long nrb, int N) {
+  if (pat == 6) { k6<6><<<cus * 2, 256>>>(d, nrb, N); return; }
+  if (pat == 7) { k6<7><<<cus * 2, 256>>>(d, nrb, N); return; }
+  if (pat == 0) k<0><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 1) k<1><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 2) k<2><<<cus * 2, 256>>>(d, nrb, N);
+  else if (pat == 3) k<3><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 4) k<4><<<cus * 2, 256>>>(d, nrb, N); else k5<5><<<cus * 2, 256>>>(d, nrb, N, 832);
+}
+static const char* pat_name(int pat) {
+  return pat == 0 ? "2 rows x 64 B per instruction" : pat == 1 ? "1 row x 128 B per instruction" : pat == 2 ? "8 rows x 64 B per instruction (8 B per lane)"
+       : pat == 3 ? "aligned 16 B pieces + 2 B edges per row segment" : pat == 4 ? "whole row block, aligned 16 B pieces" : pat == 5 ? "1 row x 128 B per instruction, rows pitched to 832 elements"
+       : pat == 6 ? "transposed layout: 32 rows x 32 B per instruction (16 B per lane, 2-byte aligned)" : "transposed layout: 32 rows x 2 x 8 B per instruction (8 B per lane)";
+}
+
+// store_pattern [N]                  -> every pattern once (GB/s)
+// store_pattern N pattern seconds    -> that pattern in a loop for `seconds` (for tools/power_sample.py: J per GB)
 int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  char pci[64] = ""; (void)hipDeviceGetPCIBusId(pci, sizeof pci, 0);
+  printf("pci_bus_id %s\n", pci); fflush(stdout);
   const int cus = prop.multiProcessorCount; const int N = argc > 1 ? atoi(argv[1]) : 821;
   const long nrb = 32768;
-  unsigned short* d; CK(hipMalloc(&d, (size_t)nrb * 32 * N * 2));
+  unsigned short* d; CK(hipMalloc(&d, (size_t)nrb * 32 * 832 * 2));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int pat = 0; pat < 5; pat++)
-    for (int rep = 0; rep < 3; rep++) {
+  if (argc > 3) {
+    const int pat = atoi(argv[2]); const double secs = atof(argv[3]);
+    launch(pat, cus, d, nrb, N); CK(hipDeviceSynchronize());
+    double total_ms = 0; long n = 0;
+    while (total_ms < secs * 1e3) {
       CK(hipEventRecord(e0));
-      if (pat == 0) k<0><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 1) k<1><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 2) k<2><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 3) k<3><<<cus * 2, 256>>>(d, nrb, N); else k<4><<<cus * 2, 256>>>(d, nrb, N);
+      for (int i = 0; i < 50; i++) launch(pat, cus, d, nrb, N);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      if (rep == 2) printf("pattern %d (%s): %.3f ms  %.0f GB/s\n", pat, pat == 0 ? "2 rows x 64 B per instruction" : pat == 1 ? "1 row x 128 B per instruction" : pat == 2 ? "8 rows x 64 B per instruction (8 B per lane)" : pat == 3 ? "aligned 16 B pieces + 2 B edges per row segment" : "whole row block, aligned 16 B pieces", ms,
-                           (double)nrb * 32 * N * 2 / ms * 1e-6);
+      total_ms += ms; n += 50;
+    }
+    printf("pattern %d (%s): %ld launches, %.3f ms each, %.0f GB/s, %.3f GB per launch\n", pat, pat_name(pat), n, total_ms / n,
+           (double)nrb * 32 * N * 2 / (total_ms / n) * 1e-6, (double)nrb * 32 * N * 2 * 1e-9);
+    return 0;
+  }
+  for (int pat = 0; pat < 8; pat++)
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipEventRecord(e0));
+      launch(pat, cus, d, nrb, N);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep == 2) printf("pattern %d (%s): %.3f ms  %.0f GB/s\n", pat, pat_name(pat), ms, (double)nrb * 32 * N * 2 / ms * 1e-6);
     }
   return 0;
 }

@@ -90,8 +90,16 @@ __device__ int g_multiply(Poly &out, const Poly &a, const Poly &b, i64 p, int ca
   if (rl > cap) return ST_CAPACITY;
   for (int k = lane(); k < rl; k += 64) {
     const int lo = k - (b.len - 1) > 0 ? k - (b.len - 1) : 0, hi = k < a.len - 1 ? k : a.len - 1;
+    // |term| < 2^52 (check_generic: |coefficients| <= 2^26), so 256 terms stay below 2^60; every run of 256 is reduced before it
+    // joins the total (|run % p| < 2^26, <= 16 runs): the int64 sum can no longer wrap at lengths up to 4096, and the residue of
+    // the exact sum -- what the reference's rounded FFT product reduces -- is unchanged.
     i64 s = 0;
-    for (int i = lo; i <= hi; i++) s += a.c[i] * b.c[k - i];
+    for (int i0 = lo; i0 <= hi; i0 += 256) {
+      const int i1 = i0 + 255 < hi ? i0 + 255 : hi;
+      i64 t = 0;
+      for (int i = i0; i <= i1; i++) t += a.c[i] * b.c[k - i];
+      s += t % p;
+    }
     out.c[k] = ((s % p) + p) % p;
   }
   out.len = rl;

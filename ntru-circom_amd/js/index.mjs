@@ -17,7 +17,8 @@
 // on the engine's generic family (ntru_generic_*: the reference's own algorithms, one item per wavefront), which also
 // serves the f that are not units, so that loadPrivateKeyF behaves like the reference there too.
 import { createRequire } from 'module';
-import { randomFillSync } from 'crypto';
+import nodeCrypto from 'crypto';
+const { randomFillSync } = nodeCrypto;
 
 const require = createRequire(import.meta.url);
 let addon = null;
@@ -88,16 +89,20 @@ export function generateCustomArray(length, numOnes, numNegOnes) {
   const array = new Array(length).fill(0);
   array.fill(1, 0, numOnes);
   array.fill(-1, numOnes, numOnes + numNegOnes);
-  // The reference draws one u32 per step from the global WebCrypto (index.js:481-482).  When a caller has installed one
-  // (e.g. a seeded one, to replay), it is called exactly like that; otherwise the length - 1 draws come from Node's CSPRNG
-  // in ONE call (same count, same distribution, ~0.4 ms less per encryptBits at N = 821).
-  const webcrypto = typeof globalThis !== 'undefined' && globalThis.crypto && globalThis.crypto.getRandomValues
-    ? globalThis.crypto : null;
-  const u = new Uint32Array(webcrypto || length < 2 ? 1 : length - 1);
-  if (!webcrypto && length > 1) randomFillSync(u);
+  // The reference draws one u32 per step from the global WebCrypto (index.js:481-482).  A WebCrypto the CALLER installed
+  // (e.g. a seeded one, to replay) is called exactly like that.  Node's own CSPRNG -- no global at all (Node 12), or the
+  // built-in global of Node >= 19, which IS crypto.webcrypto -- delivers the length - 1 draws in ONE call: same count, same
+  // distribution, ~0.4 ms less per encryptBits at N = 821 (length - 1 <= 16384 draws stay under WebCrypto's 65536-byte quota).
+  const g = typeof globalThis !== 'undefined' && globalThis.crypto && globalThis.crypto.getRandomValues ? globalThis.crypto : null;
+  const builtin = g !== null && nodeCrypto.webcrypto !== undefined && g === nodeCrypto.webcrypto;
+  const perStep = g !== null && !builtin;
+  const u = new Uint32Array(perStep || length < 2 ? 1 : length - 1);
+  if (!perStep && length > 1) {
+    if (builtin && u.byteLength <= 65536) g.getRandomValues(u); else randomFillSync(u);
+  }
   for (let i = length - 1, k = 0; i > 0; i--, k++) {
-    if (webcrypto) webcrypto.getRandomValues(u);
-    const j = u[webcrypto ? 0 : k] % (i + 1);
+    if (perStep) g.getRandomValues(u);
+    const j = u[perStep ? 0 : k] % (i + 1);
     const t = array[i]; array[i] = array[j]; array[j] = t;
   }
   return array;
@@ -332,7 +337,7 @@ export default class NTRU {
   loadPrivateKeyF(fArr) {
     const { N, p, q } = this;
     const ternary = fArr.length <= N && fArr.every(x => x === 0 || x === 1 || x === -1);
-    if (ternary && p === 3 && fastModulus(N, q) && (q & (q - 1)) === 0) {
+    if (ternary && p === 3 && N >= 2 && N <= 1920 && fastModulus(N, q) && (q & (q - 1)) === 0) {   // the engine's N range, as in polyInv
       const fq = new Uint16Array(N), fp = new Uint8Array(N), flags = new Uint8Array(1);
       engine().invertKeyBatch(N, q, p, Int8Array.from(expandArray(fArr, N, 0)), 1, fq, fp, flags);
       if (!(flags[0] & 24)) {

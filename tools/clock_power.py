@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=5.0)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-smi", action="store_true")
+    ap.add_argument("--kernel-path", type=int, default=0, help="ntru_engine_set_kernel_path for the encrypt / decrypt loops")
+    ap.add_argument("--row-pitch", type=int, default=0, help="row pitch in elements (0 = dense)")
     ap.add_argument("--loads", default="all", help="comma list of: idle,mfma,encrypt,decrypt,decrypt_value,verify (default all); with "
                                                    "NTRU_ENGINE_LIB pointing at a timing-only build (tools/ablate.sh) this prices its energy")
     args = ap.parse_args()
@@ -134,7 +136,9 @@ def main():
     kflags = torch.empty(Bk, dtype=torch.uint8, device=dev)
     vk = lambda: eng.verify_keys_batch_dev(N, q, p, kf.data_ptr(), kg.data_ptr(), kfq.data_ptr(), kfp.data_ptr(), kh.data_ptr(), Bk,
                                            *[t.data_ptr() for t in kouts], kflags.data_ptr())
-    enc(); dec(); vk(); torch.cuda.synchronize()
+    eng.set_kernel_path(args.kernel_path)
+    enc(); dec(); torch.cuda.synchronize()
+    eng.set_kernel_path(0); vk(); torch.cuda.synchronize(); eng.set_kernel_path(args.kernel_path)
 
     clk = torch.zeros(4, dtype=torch.int64, device=dev)
     spin_out = torch.zeros(3 * 4096, dtype=torch.int64, device=dev)
@@ -181,7 +185,11 @@ def main():
             ghz = a[:, 0] / a[:, 1] * 0.1
             out = {"shader_clock_GHz_from_memtime": {"mean": float(ghz.mean()), "min": float(ghz.min()), "max": float(ghz.max())},
                    "real_seconds": float(a[:, 1].mean() / 100e6)}
-            if mode == 1:
+            if mode >= 3:
+                ins = a[:, 2].astype(np.float64) * 256 * (threads // 64)     # wave-instructions per workgroup
+                out["wave_instr_per_s_G"] = float((ins / (a[:, 1] / 100e6)).sum() / 1e9)
+                out["clocks_per_instr_per_simd"] = float((a[:, 0] / (a[:, 2] * 256.0 * max(1, threads // 256))).mean())
+            elif mode >= 1:
                 mf = a[:, 2].astype(np.float64) * 256 * (threads // 64)      # matrix instructions per workgroup
                 secs = a[:, 1] / 100e6
                 out["mfma_per_s_G"] = float((mf / secs).sum() / 1e9)
@@ -212,13 +220,19 @@ def main():
         return body
 
     cus = props.multi_processor_count
-    want = lambda k: args.loads == "all" or k in args.loads.split(",")
+    want = lambda k: (args.loads == "all" and k != "kinds") or k in args.loads.split(",")
     if os.environ.get("NTRU_ENGINE_LIB"):
         print(json.dumps({"engine_lib": os.environ["NTRU_ENGINE_LIB"]}))
     if want("idle"): sampled("idle_one_wave", spin(0, 1, 64))
     if want("mfma"):
         sampled("mfma_i8_all_simds_1_wave_each", spin(1, cus, 256))
         sampled("mfma_i8_all_simds_2_waves_each", spin(1, cus, 512))
+        sampled("mfma_fp4_k64_all_simds_1_wave_each", spin(2, cus, 256))
+    if want("kinds"):
+        # energy per instruction class: 256 instructions of one kind per loop iteration and wave, 2 waves per SIMD
+        for mode, name in ((9, "s_nop"), (3, "v_perm_b32"), (4, "v_add_u32"), (5, "ds_read_b128"), (6, "ds_read_u8_scattered"),
+                           (7, "ds_write_b16"), (8, "ds_write_b64")):
+            sampled("kind_" + name, spin(mode, cus, 512))
     if want("encrypt"): sampled("encrypt_loop", loop(enc, B))
     if want("decrypt"): sampled("decrypt_loop_full_witness", loop(dec, B))
     if want("decrypt_value"): sampled("decrypt_loop_value_only", loop(dec_v, B))
