@@ -46,8 +46,10 @@ def parse_args(argv=None):
                     help="witness: every array the reference returns; value: ciphertext / plaintext only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix", "lockstep", "rolesplit", "chunk", "dma"], default="auto",
-                    help="kernel family: packed-u16 MAC, ternary add path, matrix cores as two workgroups per CU / lock-step groups / role-split encrypt, or the engine's choice (same results)")
+    ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix", "lockstep", "rolesplit", "chunk", "dma", "lockstep-encrypt"], default="auto",
+                    help="kernel family: packed-u16 MAC, ternary add path, matrix cores as two workgroups per CU / with the lock-step "
+                         "decrypt, or the engine's choice (same results); rolesplit, chunk, dma, lockstep-encrypt need the library "
+                         "built with `make experiments` (NTRU_ENGINE_LIB)")
     ap.add_argument("--row-pitch", type=int, default=0,
                     help="row pitch of the batch arrays in elements (0 = dense rows of N elements; -1 = N rounded up to "
                          "a multiple of 64, i.e. rows on cache-line boundaries: ntru_*_batch_pitched_dev)")
@@ -282,7 +284,7 @@ def main():
             raise SystemExit("bench: --sample-r writes dense rows; use it with --row-pitch 0")
         eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
         torch.cuda.synchronize()
-    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4, "lockstep": 5, "rolesplit": 6, "chunk": 7, "dma": 8}[args.kernel_path])
+    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4, "lockstep": 5, "rolesplit": 6, "chunk": 7, "dma": 8, "lockstep-encrypt": 9}[args.kernel_path])
 
     names = {}
 

@@ -79,13 +79,17 @@ int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
  * kernels, 2 = the ternary add path wherever it applies, 3 = the add path without its dot8 product, 4 = the int8
  * matrix-core path wherever it applies (encrypt / decrypt: shared key, q <= 8192, N <= 1024; verify_keys: q <= 8192,
  * p == 3, 64 <= N <= 1024), even for small N, as two independent four-wave workgroups per CU (k_encrypt_m, k_decrypt_m),
- * 5 = the same as ONE workgroup of two four-wave groups whose matrix-loop and epilogue phases are interleaved by barriers
- * (k_encrypt_m8, k_decrypt_m8; falls back to 4 where 160 KB of LDS do not hold two groups), 6 = 4 with the role-split encrypt
- * kernel (k_encrypt_m2: matrix waves + io waves, needs 16-byte aligned batch arrays), 7 = 4 with the encrypt results leaving
- * through per-wave LDS chunks as aligned 16-byte stores (k_encrypt_mc; where two workgroups' LDS fits), 8 = the batch operands by
- * direct-to-LDS loads, the next row block's rows ahead of the last epilogue's stores (k_encrypt_md = 4 with such loads; k_decrypt_m8d
- * = 5 with them).  0 picks k_encrypt_md and, for N > 512,
- * k_decrypt_m8.  Results are identical. */
+ * 5 = the matrix-core path as auto-selection runs it at large N, for every N: decrypt as ONE workgroup of two four-wave groups
+ * whose matrix-loop and epilogue phases are interleaved by barriers (k_decrypt_m8; k_decrypt_m where 160 KB of LDS do not hold
+ * two groups), encrypt with direct-to-LDS operand loads (k_encrypt_md; k_encrypt_m for rows that do not fit one such
+ * instruction).  0 picks k_encrypt_md and, for N > 512 with every witness array, k_decrypt_m8.  Results are identical on every
+ * path.  Paths 6-9 (role-split / chunked-store / lock-step encrypt, direct-to-LDS decrypt: built, bit-exact, measured slower)
+ * exist only in a library built with -DNTRU_EXPERIMENTS (`make -C ntru-circom_amd/csrc experiments`); this call refuses them
+ * otherwise.
+ * Streams: the *_dev calls that need temporaries (key inversion, the generic family) share one engine-owned scratch buffer.
+ * Calls on one stream are ordered by the stream; after ntru_engine_set_stream a call first makes the new stream wait (on the
+ * device) for the previous stream's use of that buffer.  The buffer only grows, and growing it frees the old one with hipFree,
+ * which waits for the whole device. */
 int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path);
 /* Name of the kernel the last *_dev call on this engine launched, e.g. "k_decrypt_s<13,13>" (for reports). */
 const char *ntru_engine_last_kernel(ntru_engine_t *eng);

@@ -1,0 +1,523 @@
+// keygen_sampler_pack.hip -- MI355X (gfx950): the rows SURVEY.md 8(f) widens into, each with its *_dev entry point:
+//   key inversion (loadPrivateKeyF / polyInv, index.js:30-49, :491-514): k_invert_key + Newton rounds on the per-item product kernels
+//   on-device ternary sampler (generateCustomArray, index.js:461-488) on a ChaCha20 stream: k_sample_ternary
+//   BN254 field packing (packOutput / unpackInput, index.js:572-620): k_pack, k_unpack
+//   elementwise: stand-alone dividePolynomials(., I, mod) and addPolynomials on ciphertexts (index.js:358-401, :235-244)
+#include "kernels_common.h"
+
+// dividePolynomials(a, I, mod) for reduced dividends, elementwise (HBM-bound): a is [B][2N].
+__global__ void k_split_by_I(int N, u32 mod, const u16 *__restrict__ a, long B, u16 *__restrict__ quot,
+                             u16 *__restrict__ rem) {
+  const long total = B * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / N; const int k = (int)(idx - row * N);
+    const u32 lo = a[row * 2 * N + k], hi = a[row * 2 * N + N + k];
+    quot[idx] = (u16)((mod - hi % mod) % mod);
+    rem[idx] = (u16)((lo + hi) % mod);
+  }
+}
+
+// addPolynomials(a, b, mod) on [B][N] rows, elementwise (HBM-bound).  The rows are contiguous, so the batch is one flat
+// array: 16 bytes (8 coefficients) per lane per access when the three base pointers are 16-byte aligned.
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+template <bool POW2>
+__global__ void k_add_mod_vec(u32 mod, const u16x8 *__restrict__ a, const u16x8 *__restrict__ b, long nvec,
+                              u16x8 *__restrict__ out) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nvec; idx += (long)gridDim.x * blockDim.x) {
+    const u16x8 x = a[idx], y = b[idx];
+    u16x8 r;
+    if (POW2) {
+      r = (x + y) & (u16)(mod - 1);                     // q | 2^16: wrapped 16-bit sums are exact mod q
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[k] = (u16)(((u32)x[k] + (u32)y[k]) % mod);
+    }
+    out[idx] = r;
+  }
+}
+__global__ void k_add_mod(u32 mod, const u16 *__restrict__ a, const u16 *__restrict__ b, long first, long total,
+                          u16 *__restrict__ out) {
+  for (long idx = first + (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+    out[idx] = (u16)(((u32)a[idx] + (u32)b[idx]) % mod);
+}
+
+
+// ---- on-device ternary sampler: generateCustomArray (index.js:461-488) for one item per LANE ---------------------
+// Same procedure as the reference: [1]*n1 ++ [other]*n2 ++ [0]*..., then for i = N-1 .. 1: j = u32 % (i+1), swap.
+// The u32 of step t of item b is word t of the ChaCha20 keystream (RFC 8439 block function) under the caller's key with
+// nonce (b_lo, b_hi, "NTRU"), so any host can replay it with a stock ChaCha20.  The Fisher-Yates chain is inherently
+// sequential per item, so items are spread over lanes.  A lane's row lives in LDS as 2-bit symbols (0, 1, 2 = `other`),
+// 16 per dword, pitch = odd number of dwords (the lock-step accesses of all lanes hit distinct banks): 13 KB per wave
+// instead of 52 KB as bytes, i.e. 12 waves per CU instead of 3.  i is wave-uniform, so u32 % (i+1) is a multiply by a
+// per-step reciprocal from an LDS table (floor(2^32 / d), one correction) instead of a 35-instruction division.
+struct ChaChaKey { u32 k[8]; };
+
+#define CHACHA_QR(a, b, c, d)                                                          \
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 16); c += d; b ^= c; b = __builtin_rotateleft32(b, 12); \
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 8);  c += d; b ^= c; b = __builtin_rotateleft32(b, 7);
+
+__global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u32 other, ChaChaKey key,
+                                                       unsigned long long first_item, long B,
+                                                       uint8_t *__restrict__ out, int pd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  u32 *recip = (u32 *)lds;                               // [N + 1]: floor(2^32 / d)
+  u32 *rows = recip + ((N + 2) & ~1);                    // [64][pd] dwords of 16 symbols
+  const int lane = threadIdx.x;
+  for (int d = lane; d <= N; d += 64) recip[d] = d >= 2 ? (u32)(0x100000000ULL / (unsigned)d) : 0u;
+  for (long base = (long)blockIdx.x * 64; base < B; base += (long)gridDim.x * 64) {
+    // all 64 rows start identical: fill them cooperatively, one dword at a time
+    for (int idx = lane; idx < 64 * pd; idx += 64) {
+      const int c = (idx % pd) * 16;
+      u32 w = 0;
+#pragma unroll
+      for (int b = 0; b < 16; b++) {
+        const int k = c + b;
+        w |= (k < n1 ? 1u : (k < n1 + n2 ? 2u : 0u)) << (2 * b);
+      }
+      rows[idx] = w;
+    }
+    wave_lds_fence();
+    u32 *row = rows + (size_t)lane * pd;
+    const unsigned long long item = first_item + (unsigned long long)(base + lane);
+    const u32 n0 = (u32)item, nn1 = (u32)(item >> 32), nn2 = 0x4e545255u;
+    int i = N - 1;
+    for (u32 ctr = 0; i >= 1; ctr++) {                  // i is the same in every lane: uniform loop
+      u32 x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+      u32 x4 = key.k[0], x5 = key.k[1], x6 = key.k[2], x7 = key.k[3], x8 = key.k[4], x9 = key.k[5], x10 = key.k[6],
+          x11 = key.k[7], x12 = ctr, x13 = n0, x14 = nn1, x15 = nn2;
+      for (int r = 0; r < 10; r++) {
+        CHACHA_QR(x0, x4, x8, x12) CHACHA_QR(x1, x5, x9, x13) CHACHA_QR(x2, x6, x10, x14) CHACHA_QR(x3, x7, x11, x15)
+        CHACHA_QR(x0, x5, x10, x15) CHACHA_QR(x1, x6, x11, x12) CHACHA_QR(x2, x7, x8, x13) CHACHA_QR(x3, x4, x9, x14)
+      }
+      const u32 ks[16] = {x0 + 0x61707865u, x1 + 0x3320646eu, x2 + 0x79622d32u, x3 + 0x6b206574u,
+                          x4 + key.k[0], x5 + key.k[1], x6 + key.k[2], x7 + key.k[3], x8 + key.k[4], x9 + key.k[5],
+                          x10 + key.k[6], x11 + key.k[7], x12 + ctr, x13 + n0, x14 + nn1, x15 + nn2};
+#pragma unroll
+      for (int w = 0; w < 16; w++) {
+        if (i >= 1) {
+          const u32 d = (u32)(i + 1);
+          u32 j = ks[w] - __umulhi(ks[w], recip[d]) * d;               // in [0, 2d)
+          j = j >= d ? j - d : j;
+          const int wi = i >> 4, si = 2 * (i & 15), wj = (int)(j >> 4), sj = 2 * (int)(j & 15);
+          const u32 a = row[wi], b = row[wj];
+          const u32 x = ((a >> si) ^ (b >> sj)) & 3u;                    // swap two 2-bit fields by their difference
+          const u32 na = a ^ (x << si);
+          row[wi] = na;
+          row[wj] = (wi == wj ? na : b) ^ (x << sj);                     // same dword: the second store wins
+          i--;
+        }
+      }
+    }
+    wave_lds_fence();
+    // rows -> row-major byte output, coalesced: the wave walks one row at a time
+    for (int rr = 0; rr < 64; rr++) {
+      if (base + rr >= B) break;
+      uint8_t *dst = out + (size_t)(base + rr) * N;
+      const u32 *src = rows + (size_t)rr * pd;
+      for (int k = lane; k < N; k += 64) {
+        const u32 sym = (src[k >> 4] >> (2 * (k & 15))) & 3u;
+        dst[k] = (uint8_t)(sym == 2u ? other : sym);
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+
+// ---- key inversion: polyInv / loadPrivateKeyF (index.js:30-49, 491-514) for one key per LANE --------
+// f^-1 in Z_P[x]/(x^N - 1), P = 2 or 3, by 2N - 1 Bernstein-Yang division steps on the reversed polynomials: the control
+// flow is the same for every key (a conditional swap and two multiply-accumulates by per-lane scalars per step), which is
+// what 64 keys in lock-step need; the reference's Euclidean algorithm returns the same polynomial because the inverse is
+// unique.  f is not a unit iff the gcd left in `ff` is not a constant: reported in `flags` (the reference's own `&&`
+// checks accept some non-units and return garbage for them: tests/golden/keygen_cases.json).  Polynomials are bit
+// planes in LDS, [array][word][lane]; GF(3) uses two planes per polynomial (plane 0: coefficient == 1, plane 1: == 2).
+
+// NWC > 0: the planes are NWC words per polynomial held in REGISTERS (every word loop is unrolled, so all indices are
+// compile-time): no LDS traffic and 8 waves per CU instead of 3; NWC = 0: any N, planes in LDS.
+template <int P, int NWC>
+__global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restrict__ f, long B, u16 *__restrict__ out16,
+                                                   uint8_t *__restrict__ out8, uint8_t *__restrict__ flags, u32 flag_bit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PL = P == 2 ? 1 : 2;                      // bit planes per polynomial
+  constexpr int UNR = NWC ? 64 : 1;                       // word loops: fully unrolled for register planes
+  const int lane = threadIdx.x;
+  const int NW = NWC ? NWC : (N + 1 + 31) >> 5;            // N + 1 coefficients: the reversed modulus has degree N
+  u32 *base = (u32 *)lds;
+  u32 regs[NWC ? 4 * PL * NWC : 1];
+  auto at = [&](int arr, int pl, int w) -> u32 & {
+    if constexpr (NWC > 0) return regs[(arr * PL + pl) * NWC + w];
+    else return base[((arr * PL + pl) * NW + w) * 64 + lane];
+  };
+  enum { AF = 0, AG = 1, AV = 2, AW = 3 };
+  for (long k0 = (long)blockIdx.x * 64; k0 < B; k0 += (long)gridDim.x * 64) {
+    const long key = k0 + lane;
+    const bool have = key < B;
+    const int8_t *fk = f + (have ? key : 0) * N;
+    // ff = rev(x^N - 1) = 1 - x^N, gg = rev_{N-1}(f), vv = 0, ww = 1
+#pragma unroll UNR
+    for (int w = 0; w < NW; w++) {
+      u32 g1 = 0, g2 = 0;
+      for (int b = 0; b < 32; b++) {
+        const int i = 32 * w + b;                         // coefficient i of gg is f[N-1-i]
+        if (i < N && have) {
+          int c = fk[N - 1 - i];
+          c = c < 0 ? c + P : c;
+          c %= P;
+          g1 |= (u32)(c == 1) << b;
+          g2 |= (u32)(c == 2) << b;
+        }
+      }
+      const u32 top = (32 * w <= N && N < 32 * w + 32) ? 1u << (N & 31) : 0u;   // coefficient N of ff is -1
+      if (P == 2) {
+        at(AF, 0, w) = (w == 0 ? 1u : 0u) | top; at(AG, 0, w) = g1;
+        at(AV, 0, w) = 0; at(AW, 0, w) = w == 0 ? 1u : 0u;
+      } else {
+        at(AF, 0, w) = w == 0 ? 1u : 0u; at(AF, 1, w) = top;
+        at(AG, 0, w) = g1; at(AG, 1, w) = g2;
+        at(AV, 0, w) = 0; at(AV, 1, w) = 0; at(AW, 0, w) = w == 0 ? 1u : 0u; at(AW, 1, w) = 0;
+      }
+    }
+    int delta = 1;
+    // GF(3) helpers on (is-one, is-two) plane pairs
+    auto add3 = [](u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
+      const u32 az = ~(a0 | a1), bz = ~(b0 | b1);
+      r0 = (a0 & bz) | (az & b0) | (a1 & b1);
+      r1 = (a1 & bz) | (az & b1) | (a0 & b0);
+    };
+    for (int step = 0; step < 2 * N - 1; step++) {
+      const u32 f0w0 = at(AF, 0, 0), g0w0 = at(AG, 0, 0);
+      const u32 f0w1 = P == 3 ? at(AF, 1, 0) : 0u, g0w1 = P == 3 ? at(AG, 1, 0) : 0u;
+      const int fc = (int)(f0w0 & 1u) + 2 * (int)(f0w1 & 1u), gc = (int)(g0w0 & 1u) + 2 * (int)(g0w1 & 1u);   // constant terms
+      const bool swap = delta > 0 && gc != 0;
+      const u32 sm = swap ? ~0u : 0u;
+      delta = (swap ? -delta : delta) + 1;
+      const int c1 = swap ? gc : fc;                      // new f(0): multiplies g and w
+      const int c2 = (P - (swap ? fc : gc)) % P;           // -(new g(0)): multiplies f and v
+      const u32 c2m1 = c2 == 1 ? ~0u : 0u;
+      // GF(3): g and w are scaled by the unit 1 / f(0) every step (they stay consistent with each other, and the inverse
+      // is unique), so ONE scalar multiplies f and v: new g = (g - (g(0) / f(0)) f) / x, and 1 / f(0) = f(0) in GF(3)
+      const int cm = P == 3 ? (9 - (swap ? fc : gc) * c1) % 3 : 0;
+      const bool k1 = cm == 1, k2 = cm == 2;
+      u32 vcar[PL], gprev[PL];
+#pragma unroll
+      for (int pl = 0; pl < PL; pl++) { vcar[pl] = 0; gprev[pl] = 0; }
+#pragma unroll UNR
+      for (int w = 0; w < NW; w++) {
+        u32 F[PL], G[PL], V[PL], W[PL];
+#pragma unroll
+        for (int pl = 0; pl < PL; pl++) {
+          F[pl] = at(AF, pl, w); G[pl] = at(AG, pl, w); W[pl] = at(AW, pl, w);
+          const u32 v = at(AV, pl, w);
+          V[pl] = (v << 1) | vcar[pl];                    // v = x v
+          vcar[pl] = v >> 31;
+          if (P == 2) {
+            u32 t = sm & (F[pl] ^ G[pl]); F[pl] ^= t; G[pl] ^= t;    // conditional swaps
+            t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
+          } else {                                                    // ... as selects: the condition is per lane, not per bit
+            const u32 f_ = F[pl], v_ = V[pl];
+            F[pl] = swap ? G[pl] : f_; G[pl] = swap ? f_ : G[pl];
+            V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
+          }
+        }
+        u32 NG[PL], NWW[PL];
+        if (P == 2) {                                     // c1 = 1; c2 = g(0)
+          NG[0] = G[0] ^ (c2m1 & F[0]);
+          NWW[0] = W[0] ^ (c2m1 & V[0]);
+        } else {
+          const u32 b0 = k1 ? F[0] : (k2 ? F[1] : 0u), b1 = k1 ? F[1] : (k2 ? F[0] : 0u);      // cm * f
+          add3(G[0], G[1], b0, b1, NG[0], NG[1]);
+          const u32 d0 = k1 ? V[0] : (k2 ? V[1] : 0u), d1 = k1 ? V[1] : (k2 ? V[0] : 0u);      // cm * v
+          add3(W[0], W[1], d0, d1, NWW[0], NWW[1]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < PL; pl++) {
+          at(AF, pl, w) = F[pl]; at(AV, pl, w) = V[pl]; at(AW, pl, w) = NWW[pl];
+          if (w > 0) at(AG, pl, w - 1) = (gprev[pl] >> 1) | (NG[pl] << 31);      // g = g / x, one word behind
+          gprev[pl] = NG[pl];
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < PL; pl++) at(AG, pl, NW - 1) = gprev[pl] >> 1;
+    }
+    // unit iff the gcd (in ff) is a non-zero constant
+    u32 rest = 0;
+#pragma unroll UNR
+    for (int w = 0; w < NW; w++)
+#pragma unroll
+      for (int pl = 0; pl < PL; pl++) rest |= at(AF, pl, w) & (w == 0 ? ~1u : ~0u);
+    const int fc = (int)(at(AF, 0, 0) & 1u) + (P == 3 ? 2 * (int)(at(AF, 1, 0) & 1u) : 0);
+    const bool unit = rest == 0 && fc != 0;
+    if (have) {
+      if (!unit) flags[key] = (uint8_t)(flags[key] | flag_bit);
+      // inverse[i] = fc^-1 * vv[N-1-i]; in GF(3) fc^-1 = fc
+#pragma unroll UNR
+      for (int w = 0; w < NW; w++) {
+        const u32 p0 = at(AV, 0, w), p1 = P == 3 ? at(AV, 1, w) : 0u;
+        for (int b = 0; b < 32; b++) {
+          const int i = N - 1 - (32 * w + b);
+          if (i < 0) break;
+          int c = (int)((p0 >> b) & 1u) + 2 * (int)((p1 >> b) & 1u);
+          if (P == 3 && fc == 2) c = (2 * c) % 3;
+          c = unit ? c : 0;
+          if (out16) out16[key * N + i] = (u16)c;
+          if (out8) out8[key * N + i] = (uint8_t)c;
+        }
+      }
+    }
+  }
+}
+
+// f in {-1,0,1} -> its residue mod q as u16 (elementwise)
+__global__ void k_signed_to_u16(const int8_t *__restrict__ f, long n, u32 q, u16 *__restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int v = f[i];
+    out[i] = (u16)(v < 0 ? (u32)(v + (int)q) : (u32)v);
+  }
+}
+// one Newton round of polyInv (index.js:499-506): v <- (2 v - u) mod q, u = f * v * v
+__global__ void k_newton_combine(u16 *__restrict__ v, const u16 *__restrict__ u, long n, u32 q) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    v[i] = (u16)((2u * v[i] - u[i]) & (q - 1));
+}
+
+// ---- BN254 field-element packing (index.js:572-620): elementwise, HBM-bound ---------------------------------------
+// One thread per 64-bit limb of the output: out[b][o] = sum_j data[b][o*per + j] << (j*bits), four LE limbs per element.
+__global__ void k_pack(int bits, int per, int data_len, int out_size, const u16 *__restrict__ data, long B,
+                       unsigned long long *__restrict__ out) {
+  const long total = B * out_size * 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(idx & 3);
+    const long eo = idx >> 2;
+    const long b = eo / out_size;
+    const int o = (int)(eo - b * out_size);
+    const int lo_bit = 64 * l;
+    int j0 = lo_bit / bits, j1 = (lo_bit + 63) / bits;
+    if (j1 >= per) j1 = per - 1;
+    unsigned long long limb = 0;
+    for (int j = j0; j <= j1; j++) {
+      const int i = o * per + j;
+      const unsigned long long v = i < data_len ? data[b * data_len + i] : 0ull;
+      const int sh = j * bits - lo_bit;
+      limb |= sh >= 0 ? v << sh : v >> (-sh);
+    }
+    out[idx] = limb;
+  }
+}
+
+// unpackInput before trimming: out[b][i*per + j] = (in[b][i] >> (j*bits)) & mask.
+__global__ void k_unpack(int bits, int per, int packed_size, const unsigned long long *__restrict__ in, long B,
+                         u16 *__restrict__ out) {
+  const long total = B * packed_size * per;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long e = idx / per;
+    const int j = (int)(idx - e * per);
+    const unsigned long long *l = in + e * 4;
+    const int pos = j * bits, w = pos >> 6, sft = pos & 63;
+    unsigned long long v = l[w] >> sft;
+    if (sft + bits > 64 && w + 1 < 4) v |= l[w + 1] << (64 - sft);
+    out[idx] = (u16)(v & ((1u << bits) - 1u));
+  }
+}
+
+// ---- host side: *_dev entry points ------------------------------------------------------------------------------------------
+
+static int check_elementwise(const ntru_engine *eng, int N, int mod, long B) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  if (N < 1 || mod < 2 || mod > 65536) return fail(NTRU_ERR_UNSUPPORTED, "need N >= 1 and 2 <= mod <= 65536");
+  return NTRU_OK;
+}
+
+extern "C" int ntru_split_by_I_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, int64_t B,
+                                   uint16_t *d_quot, uint16_t *d_rem) {
+  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!d_a || !d_quot || !d_rem) return fail(NTRU_ERR_ARG, "ntru_split_by_I: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_split_by_I, elementwise_grid(eng, B * N), dim3(256), 0, eng->stream, N, (u32)mod, d_a, (long)B,
+                     d_quot, d_rem);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_add_batch_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b,
+                                  int64_t B, uint16_t *d_out) {
+  if (int rc = check_elementwise(eng, N, mod, B)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!d_a || !d_b || !d_out) return fail(NTRU_ERR_ARG, "ntru_add_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  const long total = (long)B * N;
+  const bool aligned = (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_out) & 15) == 0;
+  const long nvec = aligned ? total / 8 : 0;
+  if (nvec) {
+    if (is_pow2(mod))
+      hipLaunchKernelGGL(k_add_mod_vec<true>, elementwise_grid(eng, nvec), dim3(256), 0, eng->stream, (u32)mod,
+                         (const u16x8 *)d_a, (const u16x8 *)d_b, nvec, (u16x8 *)d_out);
+    else
+      hipLaunchKernelGGL(k_add_mod_vec<false>, elementwise_grid(eng, nvec), dim3(256), 0, eng->stream, (u32)mod,
+                         (const u16x8 *)d_a, (const u16x8 *)d_b, nvec, (u16x8 *)d_out);
+  }
+  if (nvec * 8 < total)
+    hipLaunchKernelGGL(k_add_mod, elementwise_grid(eng, total - nvec * 8), dim3(256), 0, eng->stream, (u32)mod, d_a, d_b,
+                       nvec * 8, total, d_out);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+// ---- key inversion, sampler, field packing: *_dev entry points (the host-pointer forms are in ntru_host.hip) --------
+
+static const int64_t INVERT_CHUNK = 1 << 16;   // keys per set of Newton temporaries
+
+template <int P, int NWC>
+static int launch_invert_nw(ntru_engine *eng, int N, const int8_t *d_f, long B, uint16_t *d16, uint8_t *d8, uint8_t *d_flags,
+                            unsigned bit) {
+  const size_t lds = NWC ? 0 : (size_t)(P == 2 ? 4 : 8) * ((N + 32) / 32) * 64 * 4;
+  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the inversion kernel's LDS planes");
+  int per_cu = 0;
+  if (int rc = ntru_blocks_per_cu(eng, (const void *)k_invert_key<P, NWC>, 64, lds, &per_cu)) return rc;
+  long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((k_invert_key<P, NWC>), dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, d_f, B, (u16 *)d16, d8,
+                     d_flags, (u32)bit);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+// Register-resident planes for the word counts below (N + 1 bits rounded up to the next size), LDS planes otherwise.
+template <int P>
+static int launch_invert(ntru_engine *eng, int N, const int8_t *d_f, long B, uint16_t *d16, uint8_t *d8, uint8_t *d_flags,
+                         unsigned bit) {
+  const int nw = (N + 32) / 32;
+#define INV_CASE(W) if (nw <= W) return launch_invert_nw<P, W>(eng, N, d_f, B, d16, d8, d_flags, bit);
+  INV_CASE(2) INV_CASE(6) INV_CASE(12) INV_CASE(16) INV_CASE(22) INV_CASE(26)
+  if constexpr (P == 2) { INV_CASE(32) }
+#undef INV_CASE
+  return launch_invert_nw<P, 0>(eng, N, d_f, B, d16, d8, d_flags, bit);
+}
+
+extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, int64_t B,
+                                         uint16_t *d_fq, uint8_t *d_fp, uint8_t *d_flags) {
+  if (int rc = ntru_check_common(eng, N, q, B)) return rc;
+  if (p != 3) return fail(NTRU_ERR_UNSUPPORTED, "key inversion implements p = 3 (and q a power of two)");
+  if (B == 0) return NTRU_OK;
+  if (!d_f || (!d_fq && !d_fp) || !d_flags) return fail(NTRU_ERR_ARG, "ntru_invert_key_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipMemsetAsync(d_flags, 0, (size_t)B, eng->stream));
+  if (!d_fq) {                                     // only the inverse modulo p was asked for (polyInv(f, I, 3))
+    if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
+    snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");
+    return NTRU_OK;
+  }
+  // mod 2 inverse straight into d_fq (as 0/1 coefficients), then Newton rounds v <- 2v - f v^2 mod q (index.js:499-506;
+  // the reference runs log2(q) - 1 of them, the unique inverse mod q is reached once 2^rounds >= log2(q))
+  if (int rc = launch_invert<2>(eng, N, d_f, (long)B, d_fq, nullptr, d_flags, NTRU_FLAG_NOT_UNIT_MOD2)) return rc;
+  int k = 0;
+  while ((1 << k) < q) k++;
+  int rounds = 0;
+  while ((1 << rounds) < k) rounds++;
+  if (rounds > 0) {
+    const int64_t C = B < INVERT_CHUNK ? B : INVERT_CHUNK;     // temporaries for C keys at a time
+    const size_t row = (size_t)N * 2, part = ((size_t)C * row + 255) & ~(size_t)255;
+    char *sc = nullptr;                                                    // engine-owned, grown on demand, never per call
+    if (int rc = ntru_scratch_acquire(eng, 4 * part, &sc)) return rc;
+    struct { void *p; } f16{sc}, t{sc + part}, u{sc + 2 * part}, qs{sc + 3 * part};
+    for (int64_t o = 0; o < B; o += C) {
+      const int64_t n = B - o < C ? B - o : C;
+      uint16_t *v = d_fq + o * N;
+      hipLaunchKernelGGL(k_signed_to_u16, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, d_f + o * N, (long)(n * N),
+                         (u32)q, (u16 *)f16.p);
+      for (int r = 0; r < rounds; r++) {
+        // Hensel lifting: round r only has to be right modulo 2^(2^(r+1)); the early rounds therefore run modulo 4, 16,
+        // 256 (single int8 digit planes on the matrix cores), the last one modulo q.  The inverse modulo q is unique.
+        const int mr = (2 << r) >= k ? q : 1 << (2 << r);
+        if (int rc = ntru_polymul_split_dev(eng, N, mr, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p)) return rc;
+        if (ntru_product_tern_matrix_applies(eng, N, mr)) {         // f * t with f ternary: per-item product on the matrix cores
+          if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, (const uint16_t *)t.p, d_f + o * N, (long)n, nullptr, (uint16_t *)u.p)) return rc;
+        } else if (int rc = ntru_polymul_split_dev(eng, N, mr, (const uint16_t *)f16.p, (const uint16_t *)t.p, n,
+                                                   (uint16_t *)qs.p, (uint16_t *)u.p)) return rc;
+        hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, (u16 *)v,
+                           (const u16 *)u.p, (long)(n * N), (u32)mr);
+      }
+      HIP_TRY(hipGetLastError());                          // the next chunk reuses the temporaries in stream order
+    }
+    if (int rc = ntru_scratch_release(eng)) return rc;
+  }
+  if (d_fp) if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");
+  return NTRU_OK;
+}
+
+static int sampler_pitch(int N) { int pd = (N + 15) / 16; if ((pd & 1) == 0) pd++; return pd; }   // dwords of 16 symbols
+
+extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
+                                       uint64_t first_item, int64_t B, uint8_t *d_out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0 || N < 1 || n1 < 0 || n2 < 0) return fail(NTRU_ERR_ARG, "negative size");
+  if (n1 + n2 > N) return fail(NTRU_ERR_ARG, "The total of 1s and -1s cannot exceed the array length.");   // index.js:463
+  if (other < 0 || other > 255) return fail(NTRU_ERR_ARG, "`other` must fit a byte");
+  if (!key) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: key is NULL");
+  if (B == 0) return NTRU_OK;
+  if (!d_out) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: NULL buffer");
+  const int pitch = sampler_pitch(N);
+  const size_t lds = (size_t)64 * pitch * 4 + (size_t)((N + 2) & ~1) * 4;
+  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the sampler's LDS rows");
+  HIP_TRY(hipSetDevice(eng->device));
+  ChaChaKey ck;
+  memcpy(ck.k, key, 32);
+  int per_cu = 0;
+  if (int rc = ntru_blocks_per_cu(eng, (const void *)k_sample_ternary, 64, lds, &per_cu)) return rc;
+  long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
+  if (blocks > cap) blocks = cap;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_sample_ternary");
+  hipLaunchKernelGGL(k_sample_ternary, dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, n1, n2, (u32)other, ck,
+                     (unsigned long long)first_item, (long)B, d_out, pitch);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_pack_params(int max_val, int data_len, int *bits, int *per_output, int *arr_len, int *output_size) {
+  if (max_val < 1 || max_val > 65535 || data_len < 0 || !bits || !per_output || !arr_len || !output_size)
+    return fail(NTRU_ERR_ARG, "ntru_pack_params: need 1 <= max_val <= 65535, data_len >= 0 and non-NULL outputs");
+  int b = 0;
+  while ((max_val >> b) != 0) b++;                    // floor(log2(maxVal) + 1), index.js:573
+  const int n = 252 / b;                              // index.js:574
+  int al = ((data_len + n - 1) / n) * n;              // index.js:575-578
+  if (al < 3 * n) al = 3 * n;
+  int os = (al + n - 1) / n;                          // index.js:580
+  if (os < 3) os = 3;
+  *bits = b; *per_output = n; *arr_len = al; *output_size = os;
+  return NTRU_OK;
+}
+
+extern "C" int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *d_data, int64_t B,
+                                   uint64_t *d_out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  int bits, per, al, os;
+  if (int rc = ntru_pack_params(max_val, data_len, &bits, &per, &al, &os)) return rc;
+  if (B == 0) return NTRU_OK;
+  if ((!d_data && data_len) || !d_out) return fail(NTRU_ERR_ARG, "ntru_pack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_pack, elementwise_grid(eng, B * os * 4), dim3(256), 0, eng->stream, bits, per, data_len, os, d_data,
+                     (long)B, (unsigned long long *)d_out);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+extern "C" int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *d_in,
+                                     int packed_size, int64_t B, uint16_t *d_out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0 || packed_size < 0) return fail(NTRU_ERR_ARG, "negative size");
+  if (max_val < 1 || max_val > 65535) return fail(NTRU_ERR_ARG, "need 1 <= max_val <= 65535");
+  int bits = 0;
+  while ((max_val >> bits) != 0) bits++;
+  const int per = packed_bits / bits;
+  if (per < 1 || per * bits > 256) return fail(NTRU_ERR_ARG, "packed_bits does not hold a whole number of values within 256 bits");
+  if (B == 0 || packed_size == 0) return NTRU_OK;
+  if (!d_in || !d_out) return fail(NTRU_ERR_ARG, "ntru_unpack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_unpack, elementwise_grid(eng, B * packed_size * per), dim3(256), 0, eng->stream, bits, per,
+                     packed_size, (const unsigned long long *)d_in, (long)B, d_out);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}

@@ -1,0 +1,582 @@
+// matrix_peritem.hip -- MI355X (gfx950), family 4 with PER-ITEM operands: verifyKeysInputs (index.js:141-197), the generic product
+// multiplyPolynomials + dividePolynomials by I (index.js:319-401) and products with a ternary operand (public key, Newton rounds of
+// the key inversion), one item per wavefront on the int8 matrix cores.  tools/peritem_mfma_model.py is the executable specification.
+#include "matrix_common.h"
+
+// ---- family 4 for PER-ITEM operands: verifyKeysInputs (index.js:141-197) on the matrix cores ---------------------
+// No matrix is shared by the batch, but one product c = a * s is itself a 32-row matrix product per tile distance
+// d = kb - ib (tools/peritem_mfma_model.py): C[kb][k'] += sum_i' F[kb - d][i'] G_d[i'][k'] with F the 32-coefficient chunks
+// of a (rows = output tiles, read as aligned 16-byte pieces of a zero-padded natural-order byte array) and G_d the
+// Toeplitz tile of s (fragments of the reversed cyclic array, as above).  One accumulator pair (low / high) holds the whole
+// product of an item; a 13-bit operand contributes two digit planes with SEPARATE accumulators (value = acc0 + 128 acc1),
+// so nothing is scaled.  2 NT - 1 (+1 for the split diagonal) matrix instructions per plane.  One item per wave, all LDS
+// regions private to the wave, no workgroup barrier.
+constexpr int PI_PAD = 32;          // zero chunks on either side of the chunk matrix: rows 0..31, distances +-(NT-1)
+constexpr int PI_WAVES = 2;         // waves per workgroup (LDS, not registers, bounds the residency: ~15 KB per wave)
+struct PGeom { int N, NT, tpitch; };
+static __host__ __device__ inline size_t pi_fa_bytes(const PGeom &g) { return (size_t)32 * (g.NT + 2 * PI_PAD); }
+static __host__ __device__ inline size_t pi_nat_bytes(const PGeom &g) { return ((size_t)3 * g.N + 64 + 15) & ~(size_t)15; }
+// per wave: the two chunk matrices, then the reversed array.  The three natural-order periods the array is built from
+// are staged OVER the chunk matrices (2 fa >= nat for every N <= 1024) and wiped again before the digits go in.
+static __host__ __device__ inline size_t pi_wave_bytes(const PGeom &g) { return 2 * pi_fa_bytes(g) + (size_t)16 * g.tpitch; }
+
+// Reversed cyclic array (4 byte-shifted copies) of the 16 bytes per lane in sv (coefficients 16 lane .. 16 lane + 15 of a
+// ternary operand, zero at and beyond N): three periods in natural order (period k starts at byte k N, any alignment:
+// unaligned LDS stores), then T[c][w] = bytes rev[4w + c + j], rev[y] = s[(Y0 - y) mod N], as byte-swapped unaligned reads.
+static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T, const PGeom &g, int lane, v4i sv) {
+  const int N = g.N, Y0 = 32 * g.NT - 1;
+  if (16 * lane < N) {
+    union { v4i v; unsigned char c[16]; } u; u.v = sv;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (16 * lane + 16 <= N) *(v4i *)(nat + k * N + 16 * lane) = sv;
+      else for (int j = 0; j < 16; j++) if (16 * lane + j < N) nat[k * N + 16 * lane + j] = u.c[j];
+    }
+    if (lane < 4) *(v4i *)(nat + 3 * N + 16 * lane) = sv;                 // N >= 64
+  }
+  wave_lds_fence();
+  // Word w of copy c holds bytes nat[A .. A+3] reversed, A = E - c, E = Y0 + 2N - 3 - 4w.  E & 3 is the same for every
+  // lane, so the four copies of a word come from three ALIGNED dwords around E >> 2 with one byte permute each
+  // (an unaligned LDS dword read costs several aligned ones: the build was 28 % of a product in the probe).
+  const u32 *D = (const u32 *)nat;
+  const int e = __builtin_amdgcn_readfirstlane((Y0 + 2 * N - 3) & 3);
+  u32 sel[4]; int dk[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int al = c <= e ? e - c : e - c + 4;                            // byte offset of A inside its dword
+    dk[c] = c <= e ? 0 : -1;                                              // ... which is dword K or K - 1
+    sel[c] = 0x00010203u + 0x01010101u * (u32)al;                         // bytes al+3, al+2, al+1, al of the pair (reversed)
+  }
+  for (int w = lane; w < g.tpitch; w += 64) {
+    int K = (Y0 + 2 * N - 3 - 4 * w) >> 2;
+    K = K < 1 ? 1 : K;                                                    // pad words of a copy are never read
+    const u32 dm = D[K - 1], d0 = D[K], dp = D[K + 1];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      T[c * g.tpitch + w] = dk[c] == 0 ? __builtin_amdgcn_perm(dp, d0, sel[c]) : __builtin_amdgcn_perm(d0, dm, sel[c]);
+  }
+  wave_lds_fence();
+  for (int i = 16 * lane; i < (int)pi_nat_bytes(g); i += 16 * 64) *(v4i *)(nat + i) = (v4i){0, 0, 0, 0};   // nat lies over the
+  wave_lds_fence();                                                       // chunk matrices: their pads are zero again
+}
+
+// Digit planes of 16 values (u16 pairs in x[8], element i0 + j; zero at and beyond N) -> natural-order int8 bytes, on
+// packed 16-bit pairs.  mul: the operand is (mul v) mod q (p fq of index.js:155; 1 otherwise).  q > 256: v = d0 + 128 d1 with
+// d0 = v & 127, d1 = v >> 7 <= 63 (the two planes have SEPARATE accumulators, so nothing needs a signed representative).
+// q <= 256: ONE plane, the centred representative in [-q/2, q/2) (d1 = 0; the callers skip that plane's matrix instructions).
+static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 mul, int i0, int N, v4i &o0, v4i &o1) {
+  const u32 qm2 = (q - 1) * 0x00010001u;
+  u32 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const int left = N - (i0 + 2 * c);                     // valid elements of this pair
+    const u32 keep = left >= 2 ? 0xFFFFFFFFu : (left == 1 ? 0x0000FFFFu : 0u);
+    const u32 t = mul == 1u ? x[c] : as_u32(as_pair(x[c]) * (u16x2){(u16)mul, (u16)mul});
+    v[c] = t & qm2 & keep;
+  }
+  if (q <= 256) {
+    const u32 h2 = (q >> 1) * 0x00010001u;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const u32 a = as_u32(as_pair((as_u32(as_pair(v[2 * c]) + as_pair(h2)) & qm2)) - as_pair(h2));           // two's complement low bytes
+      const u32 b = as_u32(as_pair((as_u32(as_pair(v[2 * c + 1]) + as_pair(h2)) & qm2)) - as_pair(h2));
+      o0[c] = (int)__builtin_amdgcn_perm(b, a, 0x06040200u);
+      o1[c] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const u32 a = v[2 * c], b = v[2 * c + 1];
+      o0[c] = (int)__builtin_amdgcn_perm(b & 0x007F007Fu, a & 0x007F007Fu, 0x06040200u);
+      o1[c] = (int)__builtin_amdgcn_perm((b >> 7) & 0x007F007Fu, (a >> 7) & 0x007F007Fu, 0x06040200u);
+    }
+  }
+}
+
+// One plane-pair product: acc{L,H}{0,1} += chunk matrices fa0 / fa1 (x) Toeplitz fragments of T.  TWO = false: one plane.
+// A step (tile distance d) is one or two matrix instructions on operands that are used once, so the loop lives on its
+// LDS reads: they are requested TWO steps ahead into three rotating register sets (unrolled by three, no register moves;
+// one step ahead left the wave waiting on LDS latency at the top of every iteration: 64 matrix clocks per step against
+// ~130 of latency).  The first instruction of every accumulator takes C = 0.
+template <bool TWO>
+static __device__ __forceinline__ void pi_product(const unsigned char *pa0, const unsigned char *pa1, const u32 *tb, int NT,
+                                                  const u32 (&mlow)[4], v16i &L0, v16i &L1, v16i &H0, v16i &H1) {
+  struct Ops { v4i a0, a1, w; };
+  auto ld = [&](int d, Ops &o) {                          // distance d: fragment 8 d dwords below the lane's base, rows shifted by d
+    d = d < NT ? d : NT;                                  // requests past the last step read pad bytes (never used)
+    const u32 *p = tb - 8 * d;
+    o.w = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+    o.a0 = *(const v4i *)(pa0 - 32 * d);
+    if (TWO) o.a1 = *(const v4i *)(pa1 - 32 * d);
+  };
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto step = [&](int d, const Ops &o) {                  // d < 0: high, d > 0: low, d == 0: split by the diagonal mask
+    if (d < 0) {
+      H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, o.w, H0, 0, 0, 0);
+      if (TWO) H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, o.w, H1, 0, 0, 0);
+    } else if (d > 0) {
+      L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, o.w, L0, 0, 0, 0);
+      if (TWO) L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, o.w, L1, 0, 0, 0);
+    } else {
+      const v4i wl = and4(o.w, mlow);
+      const v4i wh = {(int)((u32)o.w[0] & ~mlow[0]), (int)((u32)o.w[1] & ~mlow[1]), (int)((u32)o.w[2] & ~mlow[2]), (int)((u32)o.w[3] & ~mlow[3])};
+      L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, wl, zero, 0, 0, 0);          // the first term of `low`
+      H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, wh, H0, 0, 0, 0);
+      if (TWO) {
+        L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, wl, zero, 0, 0, 0);
+        H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, wh, H1, 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 16; i++) { H0[i] = 0; H1[i] = 0; }   // NT = 1 has no d < 0 step; otherwise folded into the first step below
+  Ops A, Bq, C;
+  int d = -(NT - 1);
+  ld(d, A); ld(d + 1, Bq);
+  // high part: steps d = -(NT-1) .. -1, three per trip
+  for (; d + 2 < 0; d += 3) {
+    ld(d + 2, C); step(-1, A);
+    ld(d + 3, A); step(-1, Bq);
+    ld(d + 4, Bq); step(-1, C);
+  }
+  // 0, 1 or 2 steps of the high part are left; then the diagonal; then the low part.  The rotation continues with moves
+  // for these few steps (at most two high steps + the diagonal), after which the low part runs three per trip again.
+  for (; d < 0; d++) {
+    ld(d + 2, C); step(-1, A);
+    A = Bq; Bq = C;
+  }
+  ld(2, C); step(0, A);                                   // d == 0
+  A = Bq; Bq = C;
+  d = 1;
+  for (; d + 2 < NT; d += 3) {
+    ld(d + 2, C); step(1, A);
+    ld(d + 3, A); step(1, Bq);
+    ld(d + 4, Bq); step(1, C);
+  }
+  for (; d < NT; d++) {
+    ld(d + 2, C); step(1, A);
+    A = Bq; Bq = C;
+  }
+  if (!TWO) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) { L1[i] = 0; H1[i] = 0; }
+  }
+}
+
+static __device__ __forceinline__ int wave_max(int v) {
+  // the lane index is re-materialised here: otherwise the six permute addresses are hoisted out of the item loop and,
+  // at the register limit of three waves per SIMD, spilled to scratch
+  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int o = __builtin_amdgcn_ds_bpermute((l ^ off) << 2, v);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_verify_keys_m(
+    PGeom g, u32 q, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
+    const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
+    u16 *__restrict__ rem_fq, uint8_t *__restrict__ quot_fp, uint8_t *__restrict__ rem_fp, u16 *__restrict__ quot_h,
+    u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T = (u32 *)(fa1 + pi_fa_bytes(g));
+  const int N = g.N, NT = g.NT;
+  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  const int y0 = 32 * NT - 1 - r + 16 * hh;
+  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
+  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
+  u32 mlow[4];
+  diag_low_mask(lane, mlow);
+  const bool stager = 16 * lane < 32 * NT;                                 // lanes that hold a 16-coefficient chunk of a row
+  const v4i cmask = col_mask16(16 * lane, N);                              // bytes of this lane's chunk that are below N
+  const int kl = 128 * hh + r;                                             // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + kl
+  wave_lds_fence();
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
+    const long row = item * N, left = (B - item) * N;
+    u32 fl = 0;
+    // Every operand row is requested one product ahead of its use (rows at any alignment: aligned chunks + a wave-uniform
+    // byte shift at use): fq, f and fp at the top, g and fq again (an L2 hit) before product 2, h before product 3.  A fetch
+    // right where each product needs it left the wave idle for a round trip to HBM three times per item.
+    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_g = aligned_src(gg + row, left),
+                     s_fp = aligned_src(fp + row, left);
+    RawChunks<2> r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * lane, 0);
+    const RawChunks<1> r_f = load_raw<1>(s_f, s_f.a0 + 16 * lane, 0);
+    const RawChunks<1> r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * lane, 0);
+    auto bytes_of = [&](const RawChunks<1> &rw, const AlignedSrc &sr) {
+      v4i v[1];
+      shift_raw<1>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
+      return v[0];
+    };
+    auto fq_pairs = [&](u32 (&x)[8]) {                                    // 16 coefficients per lane as u16 pairs
+      v4i v[2];
+      shift_raw<2>(r_fq, __builtin_amdgcn_readfirstlane(s_fq.a0), v);
+#pragma unroll
+      for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
+    };
+    // ternary operands: any negative byte is -1 (ValTernary), bytes at and beyond N are zero -- four bytes at a time
+    auto ternary = [&](v4i v) {
+      v4i o;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const u32 w = (u32)(v[c] & cmask[c]);
+        u32 neg = (w >> 7) & 0x01010101u;                                  // 1 in every negative byte ...
+        neg |= neg << 1; neg |= neg << 2; neg |= neg << 4;                 // ... spread to 0xFF
+        o[c] = (int)(w | neg);
+      }
+      return o;
+    };
+    // ---- product 1: fq * f mod q (index.js:158-160)
+    {
+      u32 xq[8];
+      fq_pairs(xq);
+      const v4i tf = ternary(bytes_of(r_f, s_f));
+      pi_build_array(nat, T, g, lane, tf);
+      if (stager) {
+        v4i o0, o1;
+        pi_digits(xq, q, 1u, 16 * lane, N, o0, o1);
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
+      }
+      wave_lds_fence();
+    }
+    v16i L0, L1, H0, H1;
+    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      // stores through one-row descriptors: index k = 32 kb + r is a per-lane offset (128 hh + r) plus a compile-time
+      // one per register, indices >= N fall outside the descriptor and are dropped -- no address arithmetic per store
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fq + row, 2L * N), rs_q = rows_rsrc(quot_fq + row, 2L * N);
+      bool nz_hi = false, first_not_one = false;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        const u32 rv = (u32)(lo + hi) & (q - 1);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        nz_hi |= k >= 1 && k < N && rv != 0;
+        first_not_one |= k == 0 && rv != 1;
+      }
+      if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
+    }
+    wave_lds_fence();
+    // ---- product 2: fp * f mod p (index.js:161-163): the array of f serves again, one plane of fp mod 3
+    {
+      const v4i vfp = bytes_of(r_fp, s_fp);
+      union { v4i v; unsigned char c[16]; } u; u.v = vfp & cmask;
+#pragma unroll
+      for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
+      if (stager) *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = u.v;
+    }
+    wave_lds_fence();
+    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * lane, 0);                       // for product 3, in flight during product 2
+    const RawChunks<1> r_g = load_raw<1>(s_g, s_g.a0 + 16 * lane, 0);
+    pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
+      bool nz_hi = false, first_not_one = false;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        // |L + H|, |H| <= 127 N (f is an int8, fp < 3): a multiple of 3 above that keeps the dividend non-negative
+        const u32 x = (u32)(L0[i] + H0[i] + 3 * 131072), y = (u32)(3 * 131072 - H0[i]);
+        const u32 rv = x % 3u, qv = y % 3u;
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
+        nz_hi |= k >= 1 && k < N && rv != 0;
+        first_not_one |= k == 0 && rv != 1;
+      }
+      if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
+    }
+    wave_lds_fence();
+    // ---- product 3: ((p fq) mod q) * g mod q, compared with h below its trimmed length (index.js:155,164-166)
+    {
+      u32 xq[8];
+      fq_pairs(xq);
+      const v4i tg = ternary(bytes_of(r_g, s_g));
+      pi_build_array(nat, T, g, lane, tg);
+      if (stager) {
+        v4i o0, o1;
+        pi_digits(xq, q, 3u, 16 * lane, N, o0, o1);
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
+      }
+      wave_lds_fence();
+    }
+    // h is requested before the product whose remainder it is compared with, as a row chunk (16 coefficients per lane);
+    // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
+    const AlignedSrc s_h = aligned_src(h + row, 2 * left);
+    const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * lane, 0);
+    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
+      u16 *remx = (u16 *)nat;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
+        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        const u32 rv = (u32)(lo + hi) & (q - 1);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        remx[ko + kl] = (u16)rv;                                          // ko + kl < 32 NT <= (3 N + 64) / 2
+      }
+      wave_lds_fence();
+      // index.js:165: h[k] must equal the remainder for every k below h's trimmed length
+      v4i hc[2];
+      shift_raw<2>(r_h, __builtin_amdgcn_readfirstlane(s_h.a0), hc);
+      const int i0 = 16 * lane;
+      u32 nz = 0, df = 0;                                                 // bit j: h[i0 + j] != 0 / != remainder[i0 + j]
+      if (stager) {
+        const v4i rc0 = *(const v4i *)(nat + 32 * lane), rc1 = *(const v4i *)(nat + 32 * lane + 16);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const int lf = N - (i0 + 2 * c);
+          const u32 keep = lf >= 2 ? 0xFFFFFFFFu : (lf == 1 ? 0x0000FFFFu : 0u);
+          const u32 hx = (u32)(c < 4 ? hc[0][c] : hc[1][c - 4]) & keep, rx = (u32)(c < 4 ? rc0[c] : rc1[c - 4]) & keep;
+          const u32 x = hx ^ rx;
+          nz |= ((hx & 0xFFFFu) ? 1u : 0u) << (2 * c) | ((hx >> 16) ? 2u : 0u) << (2 * c);
+          df |= ((x & 0xFFFFu) ? 1u : 0u) << (2 * c) | ((x >> 16) ? 2u : 0u) << (2 * c);
+        }
+      }
+      const int top = nz ? i0 + 31 - __builtin_clz(nz) : -1;
+      const int wtop = wave_max(top);
+      const int hl = wtop >= 0 ? wtop + 1 : 1;                          // trimmed length of h (1 for the zero polynomial)
+      const int nv = hl - i0 < 0 ? 0 : (hl - i0 > 16 ? 16 : hl - i0);   // this lane's indices below hl
+      if (__ballot((df & ((1u << nv) - 1u)) != 0) != 0) fl |= NTRU_FLAG_INVALID_H;
+    }
+    if (lane == 0) flags[item] = (uint8_t)fl;
+    wave_lds_fence();
+  }
+}
+
+// One per-item product on the matrix cores: rem (and quot) of ((mul a) mod q) * s split by 1 - x^N, a < 2^16 per item,
+// s ternary per item: generatePublicKeyH (index.js:72-79, mul = p) and the f * t product of polyInv's Newton rounds
+// (index.js:499-506, mul = 1).  Same machinery as k_verify_keys_m.
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_product_tern_m(
+    PGeom g, u32 q, u32 mul, const u16 *__restrict__ a, const int8_t *__restrict__ s, long B, u16 *__restrict__ quot,
+    u16 *__restrict__ rem) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T = (u32 *)(fa1 + pi_fa_bytes(g));
+  const int N = g.N, NT = g.NT;
+  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  const int y0 = 32 * NT - 1 - r + 16 * hh;
+  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
+  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
+  u32 mlow[4];
+  diag_low_mask(lane, mlow);
+  const bool stager = 16 * lane < 32 * NT;
+  const v4i cmask = col_mask16(16 * lane, N);
+  const bool want_q = quot != nullptr;
+  wave_lds_fence();
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
+    const long row = item * N, left = (B - item) * N;
+    {
+      const AlignedSrc sa = aligned_src(a + row, 2 * left), ss = aligned_src(s + row, left);
+      const RawChunks<2> ra = load_raw<2>(sa, sa.a0 + 32 * lane, 0);
+      const RawChunks<1> rs = load_raw<1>(ss, ss.a0 + 16 * lane, 0);
+      v4i va[2], vs[1];
+      shift_raw<2>(ra, __builtin_amdgcn_readfirstlane(sa.a0), va);
+      shift_raw<1>(rs, __builtin_amdgcn_readfirstlane(ss.a0), vs);
+      u32 xa[8];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { xa[c] = (u32)va[0][c]; xa[4 + c] = (u32)va[1][c]; }
+      union { v4i v; signed char c[16]; } u; u.v = vs[0] & cmask;        // any negative byte is -1 (ValTernary)
+#pragma unroll
+      for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
+      pi_build_array(nat, T, g, lane, u.v);
+      if (stager) {
+        v4i o0, o1;
+        pi_digits(xa, q, mul, 16 * lane, N, o0, o1);
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
+      }
+      wave_lds_fence();
+    }
+    v16i L0, L1, H0, H1;
+    if (q <= 256) pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);   // one digit plane (early Newton rounds, small q)
+    else pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    {
+      const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
+      const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quot + row : nullptr, want_q ? 2L * N : 0L);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
+        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+// Generic per-item product on the matrix cores: both operands < q <= 8192 (multiplyPolynomials + dividePolynomials by I,
+// index.js:319-401, with q a power of two; the v * v product of polyInv's Newton rounds).  With a = a0 + 128 a1 and
+// b = b0 + 128 b1 the product is a0 b0 + 128 (a0 b1 + a1 b0) + 16384 a1 b1, and 16384 = 0 mod q: three plane products, two
+// accumulator groups, two reversed arrays (the digit planes of b) per item.
+static __host__ __device__ inline size_t pi_wave_bytes2(const PGeom &g) { return pi_wave_bytes(g) + (size_t)16 * g.tpitch; }
+
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_polymul_m(
+    PGeom g, u32 q, const u16 *__restrict__ a, const u16 *__restrict__ b, long B, u16 *__restrict__ quot,
+    u16 *__restrict__ rem) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes2(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T0 = (u32 *)(fa1 + pi_fa_bytes(g)), *T1 = T0 + 4 * g.tpitch;
+  const int N = g.N, NT = g.NT;
+  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  const int y0 = 32 * NT - 1 - r + 16 * hh;
+  const u32 *tb0 = T0 + (y0 & 3) * g.tpitch + (y0 >> 2), *tb1 = tb0 + 4 * g.tpitch;
+  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
+  u32 mlow[4];
+  diag_low_mask(lane, mlow);
+  const bool stager = 16 * lane < 32 * NT;
+  const bool one = q <= 256;                               // single int8 plane per operand (pi_digits)
+  wave_lds_fence();
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
+    const long row = item * N, left = (B - item) * N;
+    {
+      auto fetch = [&](const u16 *base, u32 (&x)[8]) {
+        const AlignedSrc sr = aligned_src(base + row, 2 * left);
+        const RawChunks<2> rw = load_raw<2>(sr, sr.a0 + 32 * lane, 0);
+        v4i v[2];
+        shift_raw<2>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
+#pragma unroll
+        for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
+      };
+      u32 xa[8], xb[8];
+      fetch(a, xa); fetch(b, xb);
+      v4i a0, a1, b0, b1;
+      pi_digits(xa, q, 1u, 16 * lane, N, a0, a1);
+      pi_digits(xb, q, 1u, 16 * lane, N, b0, b1);
+      pi_build_array(nat, T0, g, lane, b0);
+      if (!one) pi_build_array(nat, T1, g, lane, b1);
+      if (stager) {
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = a0;
+        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
+      }
+      wave_lds_fence();
+    }
+    v16i L0, L1, H0, H1;                                   // group 0: a0 b0; group 1: a0 b1 + a1 b0
+#pragma unroll
+    for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
+    auto ld = [&](int d, v4i &x0, v4i &x1, v4i &w0, v4i &w1) {
+      const u32 *p0 = tb0 - 8 * d, *p1 = tb1 - 8 * d;
+      w0 = (v4i){(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3]};
+      w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+      x0 = *(const v4i *)(pa0 - 32 * d);
+      x1 = *(const v4i *)(pa1 - 32 * d);
+    };
+    auto mm3 = [&](v16i &X0, v16i &X1, v4i x0, v4i x1, v4i w0, v4i w1) {
+      X0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w0, X0, 0, 0, 0);
+      if (!one) {                                          // q <= 256: both operands are single planes
+        X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w1, X1, 0, 0, 0);
+        X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1, w0, X1, 0, 0, 0);
+      }
+    };
+    v4i x0, x1, w0, w1;
+    ld(-(NT - 1), x0, x1, w0, w1);
+    for (int d = -(NT - 1); d < 0; d++) {
+      v4i n0, n1, m0, m1;
+      ld(d + 1, n0, n1, m0, m1);
+      mm3(H0, H1, x0, x1, w0, w1);
+      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+    }
+    {
+      v4i n0, n1, m0, m1;
+      ld(1, n0, n1, m0, m1);
+      u32 mhigh[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
+      mm3(L0, L1, x0, x1, and4(w0, mlow), and4(w1, mlow));
+      mm3(H0, H1, x0, x1, and4(w0, mhigh), and4(w1, mhigh));
+      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+    }
+    for (int d = 1; d < NT; d++) {
+      v4i n0, n1, m0, m1;
+      ld(d + 1, n0, n1, m0, m1);
+      mm3(L0, L1, x0, x1, w0, w1);
+      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+    }
+    {
+      const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N), rs_q = rows_rsrc(quot + row, 2L * N);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
+        const u32 lo = (u32)L0[i] + 128u * (u32)L1[i], hi = (u32)H0[i] + 128u * (u32)H1[i];
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((0u - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+static PGeom make_pgeom(int N) {
+  PGeom pg;
+  pg.N = N; pg.NT = (N + 31) / 32; pg.tpitch = ((16 * pg.NT + 31) / 32) * 32 + 8;
+  return pg;
+}
+// The per-item matrix kernels: modulus a power of two <= 8192 (two int8 digit planes), 64 <= N <= 1024; automatic from N = 128.
+static bool peritem_applies(const ntru_engine *eng, int N, int q) {
+  return (eng->path == 0 || eng->path >= 4) && is_pow2(q) && q <= 8192 && N <= 1024 && N >= (eng->path >= 4 ? 64 : 128);
+}
+template <class Kern>
+static int peritem_grid(ntru_engine *eng, Kern kern, size_t lds, long B, dim3 *grid) {
+  int per_cu = 0;
+  if (int rc = ntru_blocks_per_cu(eng, (const void *)kern, 64 * PI_WAVES, lds, &per_cu)) return rc;
+  long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
+  if (blocks > work) blocks = work;
+  *grid = dim3((unsigned)blocks);
+  return NTRU_OK;
+}
+
+int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B, uint16_t *d_quot,
+                               uint16_t *d_rem) {
+  if (!peritem_applies(eng, N, mod)) return NTRU_NOT_TAKEN;
+  const PGeom pg = make_pgeom(N);
+  const size_t lds = PI_WAVES * pi_wave_bytes2(pg);
+  dim3 grid;
+  if (int rc = peritem_grid(eng, k_polymul_m, lds, (long)B, &grid)) return rc;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
+  hipLaunchKernelGGL(k_polymul_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b, (long)B, d_quot, d_rem);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q) { return peritem_applies(eng, N, q); }
+
+int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s, long B,
+                                    uint16_t *d_quot, uint16_t *d_rem) {
+  const PGeom pg = make_pgeom(N);
+  const size_t lds = PI_WAVES * pi_wave_bytes(pg);
+  dim3 grid;
+  if (int rc = peritem_grid(eng, k_product_tern_m, lds, B, &grid)) return rc;
+  hipLaunchKernelGGL(k_product_tern_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, (u32)mul, d_a, d_s, B, d_quot, d_rem);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const int8_t *d_g, const uint16_t *d_fq,
+                                   const uint8_t *d_fp, const uint16_t *d_h, int64_t B, uint16_t *d_quot_fq, uint16_t *d_rem_fq,
+                                   uint8_t *d_quot_fp, uint8_t *d_rem_fp, uint16_t *d_quot_h, uint16_t *d_rem_h, uint8_t *d_flags) {
+  if (p != 3 || !peritem_applies(eng, N, q)) return NTRU_NOT_TAKEN;
+  const PGeom pg = make_pgeom(N);
+  const size_t lds = PI_WAVES * pi_wave_bytes(pg);
+  dim3 grid;
+  if (int rc = peritem_grid(eng, k_verify_keys_m, lds, (long)B, &grid)) return rc;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_verify_keys_m");
+  hipLaunchKernelGGL(k_verify_keys_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, d_f, d_g, d_fq, d_fp, d_h, (long)B,
+                     d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h, d_flags);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}

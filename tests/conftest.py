@@ -29,3 +29,21 @@ def pure_golden():
 @pytest.fixture(scope="session", params=PROFILES)
 def scheme_golden(request):
     return load_golden("scheme_%s.json" % request.param)
+
+
+def has_experiments(eng):
+    """True when the loaded library was built with -DNTRU_EXPERIMENTS (`make -C ntru-circom_amd/csrc experiments`, then
+    NTRU_ENGINE_LIB=ntru-circom_amd/lib/libntru_engine_experiments.so): kernel paths 6-9 exist only there."""
+    try:
+        eng.set_kernel_path(6)
+    except Exception:
+        return False
+    eng.set_kernel_path(0)
+    return True
+
+
+def set_path_or_skip(eng, path):
+    """ntru_engine_set_kernel_path(path); the measured-slower variants (paths 6-9) are skipped on the default library."""
+    if path >= 6 and not has_experiments(eng):
+        pytest.skip("kernel path %d needs the -DNTRU_EXPERIMENTS library (make experiments + NTRU_ENGINE_LIB)" % path)
+    eng.set_kernel_path(path)

@@ -19,6 +19,9 @@ CONFIGS = [  # (N, q, d) -- the BASELINE.json parameter sets first
 ]
 
 
+from conftest import has_experiments, set_path_or_skip
+
+
 @pytest.fixture(scope="module")
 def eng():
     return pkg.Engine(0)
@@ -237,7 +240,7 @@ def test_kernel_families_agree(eng):
         f = ternary_rows(rng, 1, N, d, d - 1, two=-1)[0]
         r = ternary_rows(rng, 9, N, d, d); m = rng.integers(0, 2, (9, N))
         outs, names = [], []
-        for path in (1, 2, 3, 4, 5, 6, 0):
+        for path in (1, 2, 3, 4, 5, 0) + ((6, 7, 8, 9) if has_experiments(eng) else ()):
             eng.set_kernel_path(path)
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             names.append(eng.last_kernel() if False else None)
@@ -252,14 +255,16 @@ def test_kernel_families_agree(eng):
 @pytest.mark.parametrize("N,q,d", [(17, 32, 2), (31, 64, 5), (32, 128, 6), (33, 32, 7), (64, 8192, 20), (65, 4096, 21),
                                    (167, 128, 18), (509, 2048, 169), (701, 8192, 233), (821, 4096, 273),
                                    (1021, 4096, 300), (1022, 2048, 300), (1023, 8192, 300), (1024, 8192, 300)])
-@pytest.mark.parametrize("path", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("path", [4, 5, 6, 7, 8, 9])
 def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
-    """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step groups; 6: role-split encrypt), including sizes the
+    """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step decrypt; 6-9: the variants of the experiments build), including sizes the
     automatic choice leaves to other families, batches that do not fill a 32-row block, and h at the corners of the
     digit-plane range."""
     rng = np.random.default_rng(N * 31 + q)
     p = 3
-    eng.set_kernel_path(path)
+    set_path_or_skip(eng, path)
+    two_groups_fit = (N + 31) // 32 < 32                   # 32 column tiles: 160 KB of LDS do not hold two groups / two chunked workgroups
+    dma = ("k_encrypt_md",) if N + 3 <= 1024 else ("k_encrypt_md", "k_encrypt_m")   # direct-to-LDS loads: rows that fit one 1024-byte instruction
     try:
         for B in (1, 31, 33, 70):
             h = rng.integers(0, q, N)
@@ -269,9 +274,9 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             r = ternary_rows(rng, B, N, d, d)
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
-            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8",), 6: ("k_encrypt_m2",),
-                                         7: ("k_encrypt_mc",) if (N + 31) // 32 < 32 else ("k_encrypt_m",),   # 7: result chunks, when two workgroups' LDS fits
-                                         8: ("k_encrypt_md",) if N + 3 <= 1024 else ("k_encrypt_md", "k_encrypt_m")}[path]   # 8: direct-to-LDS loads of the operands (rows that fit one 1024-byte instruction)
+            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: dma, 6: ("k_encrypt_m2",),
+                                         7: ("k_encrypt_mc",) if two_groups_fit else dma, 8: dma,
+                                         9: ("k_encrypt_m8",)}[path]                       # (two encrypt groups fit 160 KB at every N <= 1024)
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -280,8 +285,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             ein[-1] = rng.integers(0, q, N)
             ein[0, :4] = (q - 1, 0, q // 2, q // 2 + 1)
             got = eng.decrypt_batch(N, q, p, f, fp, ein)
-            two_groups_fit = (N + 31) // 32 < 32                                                        # 32 column tiles: 160 KB of LDS do not hold two groups
-            assert eng.last_kernel() == ("k_decrypt_m8" if path == 5 and two_groups_fit else
+            assert eng.last_kernel() == ("k_decrypt_m8" if path in (5, 9) and two_groups_fit else
                                          "k_decrypt_m8d" if path == 8 and two_groups_fit else "k_decrypt_m")
             want = orc.decrypt_batch(N, q, p, f, fp, ein)
             for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
@@ -292,13 +296,13 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
         eng.set_kernel_path(0)
 
 
-@pytest.mark.parametrize("path", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("path", [4, 5, 6, 7, 8, 9])
 def test_matrix_core_path_random_parameter_sweep(eng, path):
     """Differential sweep: 40 random (N, q, B) with N in [2, 1024] (odd and even, around the 32-tile boundaries), q any
     power of two up to 8192, ragged B; matrix-core family (forced) against the CPU oracle, all outputs."""
     rng = np.random.default_rng(20240)
     p = 3
-    eng.set_kernel_path(path)
+    set_path_or_skip(eng, path)
     try:
         for trial in range(40):
             N = int(rng.choice([rng.integers(2, 1025), 32 * rng.integers(1, 33) + rng.integers(-1, 2)]))
@@ -312,8 +316,9 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
             r = ternary_rows(rng, B, N, d, d)
             m = rng.integers(0, 256, (B, N))
             e, quot = eng.encrypt_batch(N, q, h, r, m)
-            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_m8", "k_encrypt_m"), 6: ("k_encrypt_m2",),
-                                         7: ("k_encrypt_mc", "k_encrypt_m"), 8: ("k_encrypt_md",)}[path]
+            assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_md", "k_encrypt_m"), 6: ("k_encrypt_m2",),
+                                         7: ("k_encrypt_mc", "k_encrypt_md", "k_encrypt_m"), 8: ("k_encrypt_md", "k_encrypt_m"),
+                                         9: ("k_encrypt_m8", "k_encrypt_md", "k_encrypt_m")}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
             ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])
@@ -340,8 +345,10 @@ def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
     m = rng.integers(0, 3, (B, N))
     e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
     want = orc.decrypt_batch(N, q, p, f, fp, e_o)
-    for path, ename, dname in ((5, "k_encrypt_m8", "k_decrypt_m8"), (6, "k_encrypt_m2", "k_decrypt_m"),
-                               (8, "k_encrypt_md", "k_decrypt_m8d")):     # 8: every trip but the first works on rows loaded straight into LDS
+    variants = ((5, "k_encrypt_md", "k_decrypt_m8"),)       # every trip of k_encrypt_md but the first works on rows loaded straight into LDS
+    if has_experiments(eng):
+        variants += ((6, "k_encrypt_m2", "k_decrypt_m"), (8, "k_encrypt_md", "k_decrypt_m8d"), (9, "k_encrypt_m8", "k_decrypt_m8"))
+    for path, ename, dname in variants:
         eng.set_kernel_path(path)
         try:
             e, quot = eng.encrypt_batch(N, q, h, r, m)
@@ -368,8 +375,8 @@ def test_device_pointers_at_any_alignment(eng, N, q, path):
     r = ternary_rows(rng, B, N, d, d); m = rng.integers(0, 256, (B, N))
     e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
     want = orc.decrypt_batch(N, q, p, f, fp, e_o)
+    set_path_or_skip(eng, path)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_kernel_path(path)
     try:
         for off in (1, 2, 3, 5, 14, 15):
             def place(a, dtype, elt):                    # copy `a` into a byte buffer at byte offset off * elt' (u16 stays 2-aligned)
@@ -437,8 +444,8 @@ def test_pitched_rows_equal_oracle(eng, N, q, ld, path):
     dfp = torch.from_numpy(fp.astype(np.uint8)).to(dev)
     dr = pitched(r, np.uint8, 256); dm = pitched(m, np.uint8, 256)
     de = outbuf(torch.int16, 0x5A5A); dq = outbuf(torch.int16, 0x5A5A)
+    set_path_or_skip(eng, path)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_kernel_path(path)
     try:
         eng.encrypt_batch_dev(N, q, dh.data_ptr(), dr.data_ptr(), dm.data_ptr(), B, de.data_ptr(), dq.data_ptr(), ld=ld)
         torch.cuda.synchronize()
@@ -1088,8 +1095,8 @@ def test_chunked_result_stores_at_every_base_alignment(eng, N, q):
     d = N // 3
     h = rng.integers(0, q, N)
     dh = torch.from_numpy(h.astype(np.int16)).to(dev)
+    set_path_or_skip(eng, 7)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_kernel_path(7)
     try:
         for phase in range(8):
             B = (1, 31, 45, 64, 77, 33, 96, 5)[phase]

@@ -52,10 +52,12 @@ def _worker(rank, world, port, q_out):
         # every rank hands rank 0 the INPUT rows of a strided sample so that rank 0 can replay them on the oracle
         rows = torch.arange(0, B, 1021, device=dev)
         sample = torch.cat([r[rows], m[rows]], dim=1).cpu()
-        sums = sh.shard_checksums(e.cpu(), dist)
-        all_e = sh.gather_rows(e.cpu(), dist, root=0)
+        e_host = e.cpu().view(torch.uint8)                   # gloo moves bytes (it has no 16-bit integer type); RCCL takes any dtype
+        sums = sh.shard_checksums(e_host, dist)
+        all_e = sh.gather_rows(e_host, dist, root=0)
         all_in = sh.gather_rows(sample, dist, root=0)
         if rank == 0:
+            all_e = all_e.view(torch.int16)
             from oracle import ntru_oracle as orc
             ok = True
             for k in range(world):
@@ -63,7 +65,7 @@ def _worker(rank, world, port, q_out):
                 want, _ = orc.encrypt_batch(N, q, h_np, ins[:, :N], ins[:, N:])
                 got = all_e[k * B:(k + 1) * B][rows.cpu()].numpy().view(np.uint16)
                 ok = ok and bool(np.array_equal(got, want))
-                ok = ok and int(sh.shard_checksums(all_e[k * B:(k + 1) * B], None)[0]) == int(sums[k])
+                ok = ok and int(sh.shard_checksums(all_e[k * B:(k + 1) * B].view(torch.uint8), None)[0]) == int(sums[k])
             distinct = not bool(torch.equal(all_e[:B], all_e[B:2 * B]))          # the ranks really own different shards
             q_out.put((ok, distinct, kernel, int(all_e.shape[0]), elapsed > 0.0, len(rows) * world))
         else:
@@ -80,7 +82,17 @@ def test_two_ranks_on_the_hip_kernels_gather_to_root_matches_the_oracle():
     q_out = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(rk, 2, port, q_out)) for rk in range(2)]
     [p.start() for p in procs]
-    res = q_out.get(timeout=600)
+    import queue
+    res, waited = None, 0
+    while res is None:                                      # a rank that dies must fail the test at once, not after a silent timeout
+        try:
+            res = q_out.get(timeout=5)
+        except queue.Empty:
+            waited += 5
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or waited > 300:
+                [p.kill() for p in procs if p.is_alive()]
+                pytest.fail("ranks exited with %r before rank 0 reported (waited %d s)" % (dead, waited))
     [p.join(timeout=120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     ok, distinct, kernel, rows, timed, checked = res
@@ -94,7 +106,7 @@ def _run_bench(extra, env_extra=None):
         env.pop(k, None)
     env.update(env_extra or {})
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                           "--check-rows", "512"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+                           "--check-rows", "512"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
     assert proc.returncode == 0, proc.stderr.decode()[-2000:]
     lines = [l for l in proc.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines                     # ONE JSON line, whatever the ranks and RCCL print

@@ -14,7 +14,7 @@ for N, q in ((509, 2048), (701, 8192), (821, 4096), (167, 128), (1024, 8192)):
     e = torch.empty((B, N), dtype=torch.int16, device=dev); qe = torch.empty_like(e)
     out = {}
     for rnd in range(2):
-        for path in (4, 8):
+        for path in (4, 5):
             for wit in (True, False):
                 eng.set_kernel_path(path)
                 args = (N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e.data_ptr(), qe.data_ptr() if wit else None)

@@ -11,10 +11,7 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
   mkdir -p ntru-circom_amd/lib/ab
   for a in ${ABL_SET:-1 2 3}; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -DNTRU_ABLATE=$a -c \
-      -o ntru-circom_amd/lib/ab/engine_abl$a.o ntru-circom_amd/csrc/ntru_engine.hip
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ntru-circom_amd/lib/ab/libntru_abl$a.so \
-      ntru-circom_amd/lib/ab/engine_abl$a.o ntru-circom_amd/lib/obj/ntru_host.o ntru-circom_amd/lib/obj/ntru_generic.o -lpthread
+    make -s -C ntru-circom_amd/csrc EXTRA=-DNTRU_ABLATE=$a OBJDIR=../lib/ab/obj_abl$a OUT=../lib/ab/libntru_abl$a.so
   done
 else
   shift || true

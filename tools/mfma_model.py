@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Executable specification of the int8 matrix-core path (kernel family 4, `k_*_m` in csrc/ntru_engine.hip).
+"""Executable specification of the int8 matrix-core path (kernel family 4, `k_*_m` in csrc/matrix_encrypt.hip / matrix_decrypt.hip / matrix_common.h).
 
 A product of a batch operand X[b][i] with a SHARED key operand s is a matrix product with the Toeplitz matrix of s:
     low [b][k] = sum_{i <= k} X[b][i] s[k-i]            (coefficients 0..N-1 of the linear product)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Executable specification of a per-item product on the int8 matrix cores (`k_verify_keys_m`, `k_product_tern_m`,
-`k_polymul_m` in csrc/ntru_engine.hip).
+`k_polymul_m` in csrc/matrix_peritem.hip).
 
 Family 4 (tools/mfma_model.py) needs a key shared by the batch.  A product with per-item operands (verifyKeysInputs,
 index.js:141-197; the Newton rounds of polyInv, index.js:491-514) has no shared matrix, but one product c = a * s in
