@@ -66,6 +66,9 @@ def parse_args(argv=None):
                     help="initialise torch.distributed and run the timing all_reduce / barrier / gather even with ONE rank "
                          "(RCCL refuses two ranks on one device, so this is how the RCCL code path is exercised on a 1-GPU box)")
     ap.add_argument("--check-rows", type=int, default=1 << 14, help="rows of the batch verified against the CPU oracle")
+    ap.add_argument("--power-seconds", type=float, default=1.5,
+                    help="after the timed region, keep stepping for this long while socket power and shader clock are sampled "
+                         "from sysfs (reported under `power`; 0 = skip)")
     return ap.parse_args(argv)
 
 
@@ -177,6 +180,63 @@ def pmc_traffic(kernel, mode, batch_log2):
         return k["hbm_bytes_per_launch"], "rocprofv3 PMC passes %s on these sources (git %s)" % (d.get("tag"), d.get("git_sha"))
     except (OSError, ValueError, KeyError):
         return None, "profiles/pmc_hbm_latest.json missing or unreadable"
+
+
+def device_sysfs_dir(index):
+    """/sys/class/drm/cardK/device of HIP device `index` (matched by PCI address), or None.  Reading it needs no HIP call."""
+    import ctypes
+    import glob
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) != 0:
+            return None
+        want = buf.value.decode().lower()
+    except OSError:
+        return None
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if os.path.basename(os.path.realpath(d)).lower() == want:
+            return d
+    return None
+
+
+class PowerSampler(threading.Thread):
+    """Socket power, power cap and shader clock of one device from its amdgpu hwmon files, every 20 ms (the kernels run AT the
+    power cap: profiles/r03_clock_power.txt -- their speed is their energy, so the line carries what the driver reports)."""
+
+    def __init__(self, dev_dir):
+        super().__init__(daemon=True)
+        import glob
+        hw = sorted(glob.glob(os.path.join(dev_dir, "hwmon", "hwmon*"))) if dev_dir else []
+        self.hw = hw[0] if hw else None
+        self.rows, self.stop_flag = [], threading.Event()
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def run(self):
+        while self.hw and not self.stop_flag.is_set():
+            pw = self._rd(os.path.join(self.hw, "power1_average")) or self._rd(os.path.join(self.hw, "power1_input"))
+            self.rows.append((time.perf_counter(), pw, self._rd(os.path.join(self.hw, "freq1_input"))))
+            time.sleep(0.02)
+
+    def summary(self, t0, t1):
+        self.stop_flag.set()
+        if self.is_alive():
+            self.join(timeout=2)
+        mid = [r for r in self.rows if t0 + 0.3 * (t1 - t0) <= r[0] <= t1]
+        pw = [r[1] / 1e6 for r in mid if r[1]]
+        fq = [r[2] / 1e6 for r in mid if r[2]]
+        cap = self._rd(os.path.join(self.hw, "power1_cap")) if self.hw else None
+        if not pw:
+            return None
+        return {"socket_W": sum(pw) / len(pw), "cap_W": cap / 1e6 if cap else None, "sclk_MHz": sum(fq) / len(fq) if fq else None,
+                "samples": len(pw), "window_s": t1 - t0}
 
 
 def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
@@ -312,6 +372,24 @@ def main():
     enc_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events]))
     dec_ms = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in events]))
 
+    # ---- what limits the kernels: socket power against its cap and the shader clock, over a sustained run of the same steps
+    # (outside the timed region; the 40 ms of the timed steps are shorter than the driver's averaging window)
+    power = None
+    if rank == 0 and args.power_seconds > 0:
+        sampler = PowerSampler(device_sysfs_dir(dev_index))
+        sampler.start()
+        tp0 = time.perf_counter(); n_sus = 0
+        while time.perf_counter() - tp0 < args.power_seconds:
+            for _ in range(20):
+                step(); n_sus += 1
+            torch.cuda.synchronize()
+        tp1 = time.perf_counter()
+        power = sampler.summary(tp0, tp1)
+        if power:
+            power["sustained_ms_per_step"] = (tp1 - tp0) / n_sus * 1e3
+            power["note"] = ("encrypt + decrypt steps back to back; both kernels run against the socket power cap with the shader clock "
+                             "pulled below its 2.4 GHz top (profiles/r03_clock_power.txt, r03_power_ablations.txt)")
+
     # ---- bit-exact check of a strided sample against the CPU oracle (outside the timed region): every output array ---
     from oracle import ntru_oracle as orc
     n_chk = max(1, min(B, args.check_rows))
@@ -417,6 +495,22 @@ def main():
             valu = {"kernel": dname, "achieved": 2.0 * N * N * B / dec_s / 1e12, "peak": PK_MAC_PEAK_T,
                     "unit": "T MAC/s", "note": "2*N^2 MACs per decrypt; peak = measured v_pk_mad_u16 issue roof"}
         valu["frac"] = valu["achieved"] / valu["peak"]
+        # The HBM side (BASELINE.json asks for it on every line): algorithmic bytes of the dominant kernel over its HIP-event time.
+        hbm_roof = {"bound": "hbm", "kernel": dname, "achieved": dec_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                    "algorithmic_bytes_per_item": dec_bytes, "algorithmic_bytes_per_launch": dec_bytes * B}
+        if mfma:
+            # Matrix-core path: value-only decrypt writes 3N instead of 8N bytes and is only 25 % faster, so HBM is not what binds it;
+            # the executed int8 matrix rate is the primary roof, the HBM fraction stays beside it (roofline_hbm), and `power` says
+            # what actually limits both: the kernels run at the socket power cap.
+            roofline = {"bound": "mfma", "kernel": dname, "achieved": mfma["achieved"], "peak": MFMA_I8_PEAK_T, "unit": "TFLOP/s",
+                        "frac": mfma["frac"], "traffic": traffic, "traffic_source": traffic_note,
+                        "unit_note": "int8 TOP/s executed (2 x 32768 per v_mfma_i32_32x32x32_i8), against the dense int8 peak",
+                        "instructions_per_launch": mfma["instructions_per_launch"],
+                        "note": "measured issue roof of this instruction: 75.4 G/s = 4.94 POP/s at 2.38 GHz and 1160 W "
+                                "(profiles/r03_clock_power.txt); HBM side in roofline_hbm"}
+        else:
+            roofline = dict(hbm_roof, note="the path is VALU/scalar-issue bound (O(N^2) integer work on O(N) bytes); see `valu`")
         valu["mac_equivalent_T_per_s"] = 2.0 * N * N * B / dec_s / 1e12
         out = {
             "metric": "NTRU encrypt+decrypt round trips per second at N=%d, q=%d" % (N, q),
@@ -434,12 +528,9 @@ def main():
             "verified_bit_exact_rows": int(rows.numel()),
             "verified_arrays": sorted(got.keys()),
             "kernels_ms": {names.get("encrypt", "k_encrypt"): enc_ms, dname: dec_ms},
-            "roofline": {"bound": "hbm", "kernel": dname, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                         "algorithmic_bytes_per_item": dec_bytes, "algorithmic_bytes_per_launch": dec_bytes * B,
-                         "note": ("matrix-core path: HBM traffic and int8 MFMA issue are within a factor of two of each "
-                                  "other; the MFMA side is reported in `mfma`") if mfma else
-                                 "the path is VALU/scalar-issue bound (O(N^2) integer work on O(N) bytes); see `valu`"},
+            "roofline": roofline,
+            "roofline_hbm": hbm_roof,
+            "power": power,
             "valu": valu,
             "mfma": mfma,
             "hbm_gbs_round_trip": (dec_bytes + enc_bytes) * B / ((dec_ms + enc_ms) * 1e-3) / 1e9,
@@ -473,9 +564,9 @@ def main():
             eng.set_kernel_path(0)
         if world == 1 and args.kernel_path == "auto" and not ablation:
             # The other function of the path with per-item operands, verifyKeysInputs (index.js:141-197, BASELINE config 5),
-            # outside the timed region: 2^16 synthetic key pairs, kernel time of 3 launches (tools/bench_configs.py is the
-            # full secondary table).
-            Bk = 1 << 16
+            # outside the timed region: 2^18 synthetic key pairs (config 5's size), kernel time of 3 launches
+            # (tools/bench_configs.py is the full secondary table).
+            Bk = 1 << 18
             gk = torch.Generator(device=dev); gk.manual_seed(5)
             tern = lambda: (torch.randint(0, 3, (Bk, N), device=dev, generator=gk) - 1).to(torch.int8)
             kf, kg = tern(), tern()

@@ -32,13 +32,7 @@ struct MGeom {
   int pitchA;   // bytes per row of an operand stage: 32 NT + 16
   int tpitch;   // dwords per byte-shifted copy of a reversed key array (= 8 mod 32: the 4 copies use disjoint banks)
   int ld;       // row pitch of every batch array in ELEMENTS (>= N; N for the dense layout of the plain entry points)
-  int scr2;     // decrypt: byte offset (from a group's LDS base) of the per-wave transposition scratch of product 2's epilogue
-  int gextra;   // decrypt: bytes a group's LDS area grows by when that scratch does not fit into the dead e_hi stage
 };
-
-// Transposition scratch of one wave: 32 rows x <= 128 result bytes at a pitch of 144 bytes (36 dwords: the 16-byte writes of 16
-// consecutive rows and the 16-byte reads of 8 pieces x 2 rows land in distinct banks, up to one 2-way overlap per read).
-constexpr int SCR_PITCH = 144, SCR_WAVE = 32 * SCR_PITCH;
 
 enum { M_ENC = 0, M_DEC1 = 1, M_DEC2 = 2 };
 
@@ -99,13 +93,7 @@ struct NoPause { __device__ __forceinline__ void operator()() const {} };
 // pause / pause_ib: pause() is called exactly once, before the first contraction step ib >= pause_ib is touched (at a
 // block boundary, so possibly a few steps early; after the loops when no such step exists).  The role-split decrypt
 // kernel waits there for the operand columns that are still being produced.
-// TR ("transposed accumulators"): the two operands of every matrix instruction change places, C^T = G^T A^T.  The fragments are
-// the same registers (the A and B lane maps of v_mfma_i32_32x32x32_i8 are mirror images), the loops are the same instructions;
-// what changes is the meaning of the result: lane & 31 = ROW of the row block (item), register i = COLUMN (i & 3) + 8 (i >> 2) +
-// 4 (lane >> 5) of the tile.  A lane then owns 4 consecutive coefficients of one item per register group, which is what the
-// epilogues need to leave as 8- and 16-byte stores instead of 1- and 2-byte ones (profiles/r03_power_*: a store instruction costs
-// ~16 nJ whatever it carries, and the kernels run at the 1400 W cap, so their speed is their energy).
-template <int MODE, int NT_S, bool TR = false, class Epi, class Pause = NoPause>
+template <int MODE, int NT_S, class Epi, class Pause = NoPause>
 static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__restrict__ st0,
                                                       const unsigned char *__restrict__ st1,
                                                       const u32 *__restrict__ tb0, const u32 *__restrict__ tb1,
@@ -150,17 +138,14 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
       a1 = a0;
     }
   };
-  auto mfma = [&](v4i a, v4i w, v16i c) {
-    return TR ? __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a, c, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, c, 0, 0, 0);
-  };
   auto mm = [&](v16i &acc, v4i a0, v4i a1, v4i w0, v4i w1) {
-    acc = mfma(a0, w0, acc);
-    if (TWO) acc = mfma(a1, w1, acc);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w0, acc, 0, 0, 0);
+    if (TWO) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w1, acc, 0, 0, 0);
   };
   auto mm_first = [&](v16i &acc, v4i a0, v4i a1, v4i w0, v4i w1) {       // first touch of an accumulator
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc = mfma(a0, w0, zero);
-    if (TWO) acc = mfma(a1, w1, acc);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, w0, zero, 0, 0, 0);
+    if (TWO) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, w1, acc, 0, 0, 0);
   };
   // Fragment window: at a step boundary slot t holds the fragment of tile t ("canonical").  A block of NT_S steps
   // rotates through the slots with compile-time indices (no register moves) and ends canonical again: at sub-step u tile t
@@ -374,8 +359,6 @@ static inline bool make_mgeom(const ntru_engine *eng, int N, int q, int ld, MGeo
   g->NT = (N + 31) / 32;
   g->pitchA = 32 * g->NT + 16;
   g->tpitch = ((16 * g->NT + 31) / 32) * 32 + 8;
-  g->scr2 = 0;
-  g->gextra = 0;
   return true;
 }
 

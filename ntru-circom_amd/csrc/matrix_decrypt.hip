@@ -4,10 +4,6 @@
 // strip loop; tools/mfma_model.py is the executable specification.
 #include "matrix_common.h"
 
-#ifndef NTRU_TRANSPOSED_PRODUCT2
-#define NTRU_TRANSPOSED_PRODUCT2 1      // 0: the column-per-lane epilogue of rounds 1-2 (1-byte stores), for same-device A/B runs
-#endif
-
 // decryptBits on the matrix cores.  Product 1: a = f * e, e = lo7 + 128 hi (both digits non-negative, q <= 8192), planes
 // [e_lo | 2 e_hi] x [f ; 64 f]; centred lift (index.js:117 verbatim); product 2: c = fp * lifted, one plane.  The lifted
 // message goes from the accumulator layout (column per lane) to the operand stage (row per lane) through a 2-bit packed
@@ -34,13 +30,7 @@ static __host__ __device__ inline int dec_dma_m3_bytes(int N, int p) {
   return (((span + 4) & ~3) + span + 1 + 15) & ~15;
 }
 
-// TR2: product 2 runs with TRANSPOSED accumulators (toeplitz_strip: lane = item row, registers = columns).  Its two byte arrays
-// (value, quotient2) were leaving as 1-byte stores, 64 bytes per store instruction; a store instruction costs ~16 nJ whatever it
-// carries and adjacent lanes must write adjacent addresses to share a request (profiles/r03_power_*, r03_ab_transposed_*), and the
-// kernel runs at the power cap.  Now a lane packs 16 columns of its row into 16 bytes (4 table lookups per dword, two
-// v_permlane32_swap), the wave transposes the strip through a private LDS scratch (rows x <= 128 bytes: the e_hi stage is dead during
-// product 2) and stores it as 8 rows x 128 contiguous bytes per instruction: 4 store instructions per strip and array instead of 64.
-template <int GROUPS, bool DMA = false, bool TR2 = false>
+template <int GROUPS, bool DMA = false>
 static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
                                                       const uint8_t *__restrict__ fp,
                                                       const u16 *__restrict__ e, long B,
@@ -58,10 +48,9 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
   // LDS layout: per group [e_hi stage][e_lo stage][packed image], then the shared key arrays and the lift table.  Group 0's
   // e_hi stage is at LDS address 0: the mod-p tables of product 2 are overlaid on it and their lookups need no base add.
   static_assert(!DMA || GROUPS == 2, "the direct-to-LDS variant is the lock-step kernel");
-  static_assert(!(DMA && TR2), "the direct-to-LDS variant keeps the column-per-lane epilogues");
   const int RP = DMA ? dec_dma_row_pitch(g.NT) : g.pitchA;                       // row pitch of the operand stage(s)
   const int m3b = DMA ? dec_dma_m3_bytes(g.N, (int)p) : 0;
-  const int gbytes = (DMA ? 32 * RP : 64 * g.pitchA) + 256 * g.NT + g.gextra;
+  const int gbytes = (DMA ? 32 * RP : 64 * g.pitchA) + 256 * g.NT;
   unsigned char *stHi = DMA ? lds + m3b + group * gbytes + g.pitchA : lds + group * gbytes;   // DMA: the high plane of row R at slot R + pitchA
   unsigned char *stLo = DMA ? lds + m3b + group * gbytes : stHi + 32 * g.pitchA;
   unsigned char *blp = DMA ? stLo + 32 * RP : stLo + 32 * g.pitchA;              // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
@@ -360,65 +349,7 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
           constexpr int S = 16 * NTS * (decltype(wq)::value ? 2 : 1), K = S < 63 ? S : 63;
           if (DMA && dma_now) __builtin_amdgcn_s_waitcnt((K & 15) | (7 << 4) | (15 << 8) | ((K >> 4) << 14));
         };
-        // TR2: lane = row R of the row block; register i of a tile = column (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
-        auto out_tr = [&](auto wq) {
-          const int R = lane & 31, hh = lane >> 5;
-          unsigned char *scr = lds + m3b + group * gbytes + g.scr2 + wave * SCR_WAVE;
-          constexpr int PPR = 2 * NTS, RPI = 64 / PPR, NI = (32 + RPI - 1) / RPI;      // 16-byte pieces per strip row, rows per store instruction
-          const int prow = lane / PPR, piece = lane - prow * PPR;
-          const int col = 32 * kb0 + 16 * piece;                     // first column of this lane's piece
-          const bool row_end = 32 * (kb0 + NTS) > N;                 // (wave-uniform) the strip holds the end of the rows
-          auto one = [&](auto is_q, const __amdgpu_buffer_rsrc_t &rs) {
-#pragma unroll
-            for (int t = 0; t < NTS; t++) {
-              u32 G[4];
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                u32 b[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                  b[j] = decltype(is_q)::value ? (u32)m3_lut[(u32)hi[t][4 * k + j]] : (u32)m3_lut[(u32)(lo[t][4 * k + j] + hi[t][4 * k + j] + M3V)];
-                G[k] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-              }
-              // v_permlane32_swap(a, b): a = [a.lower | b.lower], b = [a.upper | b.upper]: lower lanes get columns 0..15 of the
-              // tile as (G0, G2', G1, G3'), upper lanes columns 16..31
-              const auto s02 = __builtin_amdgcn_permlane32_swap(G[0], G[2], false, false);
-              const auto s13 = __builtin_amdgcn_permlane32_swap(G[1], G[3], false, false);
-              *(v4i *)(scr + R * SCR_PITCH + 32 * t + 16 * hh) = (v4i){(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
-            }
-            wave_lds_fence();
-            v4i d[NI];
-#pragma unroll
-            for (int n = 0; n < NI; n++) {
-              const int row = RPI * n + prow;
-              d[n] = *(const v4i *)(scr + (row < 32 ? row : 31) * SCR_PITCH + 16 * piece);
-            }
-#pragma unroll
-            for (int n = 0; n < NI; n++) {
-              const int row = RPI * n + prow;
-              const bool act = lane < RPI * PPR && row < 32;
-              const int vo = act && col + 16 <= N ? row * LD + col : (int)0x80000000;        // (rows past the batch end: beyond the descriptor)
-              if (1 ABL_STORE(lo[0][0])) __builtin_amdgcn_raw_buffer_store_b128(d[n], rs, vo, 0, ST_AUX);   // scalar offset 0: r02_hazard_store_x4_soffset
-            }
-            if (row_end) {                                          // the pieces that straddle column N leave byte by byte
-#pragma unroll
-              for (int n = 0; n < NI; n++) {
-                const int row = RPI * n + prow;
-                const bool part = lane < RPI * PPR && row < 32 && col < N && col + 16 > N;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                  const int vo = part && col + j < N ? row * LD + col + j : (int)0x80000000;
-                  if (1 ABL_STORE(lo[0][0])) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((u32)d[n][j >> 2] >> (8 * (j & 3))), rs, vo, 0, ST_AUX);
-                }
-              }
-            }
-            wave_lds_fence();                                       // the scratch is free for the next array
-          };
-          one(std::false_type{}, rs_v);
-          if (decltype(wq)::value) one(std::true_type{}, rs_q2);
-        };
-        if (TR2) { if (want_q2) out_tr(std::true_type{}); else out_tr(std::false_type{}); }
-        else if (want_q2) out(std::true_type{}); else out(std::false_type{});
+        if (want_q2) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
         case 0:                                          // no strip this round: the phase barrier -- and this wave's rows of the next row block
@@ -428,10 +359,10 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
             __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));                       // vmcnt(0): it stores nothing behind them
           }
           break;
-        case 1: toeplitz_strip<M_DEC2, 1, TR2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
-        case 2: toeplitz_strip<M_DEC2, 2, TR2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
-        case 3: toeplitz_strip<M_DEC2, 3, TR2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
-        default: toeplitz_strip<M_DEC2, 4, TR2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 2: toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 3: toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        default: toeplitz_strip<M_DEC2, 4>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
       }
       sidx++;
       if (sidx < rounds) phase(8);
@@ -445,7 +376,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, 
                                                              const u16 *__restrict__ e, long B,
                                                              uint8_t *__restrict__ value, u16 *__restrict__ quot1,
                                                              u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
-  decrypt_m_body<1, false, NTRU_TRANSPOSED_PRODUCT2>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
+  decrypt_m_body<1>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
 }
 
 __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
@@ -453,7 +384,7 @@ __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8(MGeom g, u3
                                                                   const u16 *__restrict__ e, long B,
                                                                   uint8_t *__restrict__ value, u16 *__restrict__ quot1,
                                                                   u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
-  decrypt_m_body<2, false, NTRU_TRANSPOSED_PRODUCT2>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
+  decrypt_m_body<2>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
 }
 
 #ifdef NTRU_EXPERIMENTS
@@ -478,14 +409,7 @@ int ntru_launch_decrypt_matrix(ntru_engine *eng, int N, int q, int p, int ld, co
                                int64_t B, uint8_t *d_value, uint16_t *d_quot1, uint16_t *d_rem1, uint8_t *d_quot2) {
   MGeom mg;
   if (p != 3 || !make_mgeom(eng, N, q, ld, &mg)) return NTRU_NOT_TAKEN;
-  // Product 2's transposition scratch (4 waves x SCR_WAVE bytes per group): behind the mod-p tables inside the e_hi stage, which is
-  // dead during product 2, where the stage is large enough for both (N >= ~740); otherwise a region of its own behind the group's image.
-  if (NTRU_TRANSPOSED_PRODUCT2) {
-    const int m3v = (((p - 1) * (p - 1)) * N + 4) & ~3, m3_end = (m3v + (p - 1) * (p - 1) * N + 1 + 15) & ~15;
-    if (32 * mg.pitchA >= m3_end + WAVES_PER_BLOCK * SCR_WAVE) { mg.scr2 = m3_end; mg.gextra = 0; }
-    else { mg.scr2 = 64 * mg.pitchA + 256 * mg.NT; mg.gextra = WAVES_PER_BLOCK * SCR_WAVE; }
-  }
-  const size_t lds = (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT + mg.gextra + (((size_t)q + 15) & ~(size_t)15);
+  const size_t lds = (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT + (((size_t)q + 15) & ~(size_t)15);
   const long nrb = (long)((B + 31) / 32);
   dim3 grid;
 #ifdef NTRU_EXPERIMENTS
@@ -495,9 +419,7 @@ int ntru_launch_decrypt_matrix(ntru_engine *eng, int N, int q, int p, int ld, co
     if (ldsd <= 160 * 1024) {
       if (int rc = resident_grid(eng, k_decrypt_m8d, ldsd, (nrb + 1) / 2, &grid, 2 * BLOCK_THREADS)) return rc;
       snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_decrypt_m8d");
-      MGeom md = mg;
-      md.scr2 = md.gextra = 0;                             // (this variant keeps the column-per-lane epilogues: no scratch)
-      hipLaunchKernelGGL(k_decrypt_m8d, grid, dim3(2 * BLOCK_THREADS), ldsd, eng->stream, md, (u32)q, (u32)p, d_f, d_fp, d_e,
+      hipLaunchKernelGGL(k_decrypt_m8d, grid, dim3(2 * BLOCK_THREADS), ldsd, eng->stream, mg, (u32)q, (u32)p, d_f, d_fp, d_e,
                          (long)B, d_value, d_quot1, d_rem1, d_quot2);
       HIP_TRY(hipGetLastError());
       return NTRU_OK;
@@ -505,7 +427,7 @@ int ntru_launch_decrypt_matrix(ntru_engine *eng, int N, int q, int p, int ld, co
   }
 #endif
   if (eng->path == 5 || eng->path == 9 || (eng->path == 0 && mg.NT > 16 && d_quot1 && d_rem1 && d_quot2)) {
-    const size_t lds8 = 2 * ((size_t)64 * mg.pitchA + (size_t)256 * mg.NT + mg.gextra) + (size_t)32 * mg.tpitch + (((size_t)q + 15) & ~(size_t)15);
+    const size_t lds8 = 2 * ((size_t)64 * mg.pitchA + (size_t)256 * mg.NT) + (size_t)32 * mg.tpitch + (((size_t)q + 15) & ~(size_t)15);
     if (lds8 <= 160 * 1024) {
       if (int rc = resident_grid(eng, k_decrypt_m8, lds8, (nrb + 1) / 2, &grid, 2 * BLOCK_THREADS)) return rc;
       snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_decrypt_m8");

@@ -4,13 +4,6 @@
 // tile geometry and the strip loop; tools/mfma_model.py is the executable specification.
 #include "matrix_common.h"
 
-#ifndef NTRU_TR_BURST
-#define NTRU_TR_BURST 1
-#endif
-#ifndef NTRU_TRANSPOSED_EPILOGUE
-#define NTRU_TRANSPOSED_EPILOGUE 0      // 1: lane = item row (see encrypt_m_body): measured SLOWER without a cross-lane transposition (profiles/r03_ab_transposed_encrypt_*)
-#endif
-
 // encryptBits on the matrix cores: e = (r * h + m) split by 1 - x^N; r in {0..3} bytes, h < q <= 8192.
 // h is taken in the representative hs = d0 + 128 d1, d0 in [-64,63], 4 d1 in [-128,124]; planes [r | 32 r] x [d0 ; 4 d1].
 // MAXT: widest strip.  8 (one workgroup per CU, 512 registers per wave, one strip per wave and row block) was measured at
@@ -26,18 +19,13 @@ constexpr int OC_PITCH = 272, OC_BYTES = 8 * OC_PITCH;
 // come back 8-9 k cycles later) -- and brought into operand form (shift to byte 0, columns >= N zeroed) in place by the wave that
 // owns the row; m is requested straight into the m image at the top of a trip and only waited for before the first epilogue.
 // Two more barriers per row block, all of them LDS-only.
-// TR: transposed accumulators (toeplitz_strip): lane = item row, registers = columns.  The epilogue packs 8 coefficients of one row
-// into 16 bytes (one v_permlane32_swap per dword brings the two half-waves' 4-column groups together) and stores them with ONE
-// instruction per 32 rows x 16 columns: 2 store instructions per tile and array instead of 16, and the plaintext comes out of the
-// m image as dwords (two aligned reads + one byte-align per 4 coefficients) instead of bytes.
-template <int MAXT, int GROUPS, bool CHUNK = false, bool DMA = false, bool TR = false>   // GROUPS = 2: the lock-step schedule of decrypt_m_body (k_encrypt_m8)
+template <int MAXT, int GROUPS, bool CHUNK = false, bool DMA = false>   // GROUPS = 2: the lock-step schedule of decrypt_m_body (k_encrypt_m8)
 static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 *__restrict__ h,
                                                       const uint8_t *__restrict__ r,
                                                       const uint8_t *__restrict__ m, long B,
                                                       u16 *__restrict__ e, u16 *__restrict__ quotE) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   static_assert(!DMA || (GROUPS == 1 && !CHUNK), "the direct-to-LDS variant is built on the plain two-workgroup kernel");
-  static_assert(!TR || !CHUNK, "the chunked stores belong to the column-per-lane layout");
   auto wg_barrier = [&]() {                                // DMA: LDS-only (with such loads in flight __syncthreads() waits for vmcnt(0): every store)
     if (DMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
@@ -333,87 +321,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
           one(g_e, rs_e, std::true_type{}, [&](int t, int i, u32 mm) { return (u32)(lo[t][i] + hi[t][i] + (int)mm) & (q - 1); });
           if (decltype(wq)::value) one(g_q, rs_q, std::false_type{}, [&](int t, int i, u32) { return (u32)(0 - hi[t][i]) & (q - 1); });
         };
-        // TR: this lane holds row R = lane & 31 of the row block; register i of a tile is column (i & 3) + 8 (i >> 2) + 4 (lane >> 5).
-        auto out_tr = [&](auto wq) {
-          const int R = lane & 31, hh = lane >> 5;
-          const u32 qm2 = (q - 1) * 0x00010001u;
-          const int row_b = 2 * R * LD + 16 * hh;                  // byte offset of this lane's 16-byte pieces inside a tile's row segment
-          const int m_b = a0m + R * LD + 4 * hh + 32 * kb0;        // byte offset in the m image of this lane's first column of the strip
-          // All results of the strip are formed first and then stored in ONE burst, a row's tiles back to back: a store instruction
-          // touches 32 rows, so every cache line of the strip's 32 x 256 bytes stays partially written until the last store of the
-          // burst -- spread over the whole epilogue (stores issued tile by tile as the results were formed) the chip held more
-          // open lines than its L2 keeps and the kernel ran 20 % SLOWER than with 2-byte stores (profiles/r03_ab_transposed_*).
-          u32 E[NTS][4][2], Q[NTS][4][2];
-#pragma unroll
-          for (int t = 0; t < NTS; t++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {                          // group k: columns c0 + 8 k + 4 hh .. + 3
-              const int mo = m_b + 32 * t + 8 * k;
-              const u32 *ma = (const u32 *)(mimg + (mo & ~3));
-              const u32 mb = __builtin_amdgcn_alignbyte(ma[1], ma[0], (u32)(mo & 3));      // the 4 plaintext bytes of the group
-              u32 sv[4], hv[4];
-#pragma unroll
-              for (int j = 0; j < 4; j++) { sv[j] = (u32)(lo[t][4 * k + j] + hi[t][4 * k + j]); hv[j] = (u32)hi[t][4 * k + j]; }
-              const u32 m0 = __builtin_amdgcn_perm(0u, mb, 0x0c010c00u), m1 = __builtin_amdgcn_perm(0u, mb, 0x0c030c02u);
-              E[t][k][0] = as_u32(as_pair(__builtin_amdgcn_perm(sv[1], sv[0], 0x05040100u)) + as_pair(m0)) & qm2;
-              E[t][k][1] = as_u32(as_pair(__builtin_amdgcn_perm(sv[3], sv[2], 0x05040100u)) + as_pair(m1)) & qm2;
-              if (decltype(wq)::value) {
-                Q[t][k][0] = as_u32(as_pair(0u) - as_pair(__builtin_amdgcn_perm(hv[1], hv[0], 0x05040100u))) & qm2;
-                Q[t][k][1] = as_u32(as_pair(0u) - as_pair(__builtin_amdgcn_perm(hv[3], hv[2], 0x05040100u))) & qm2;
-              }
-            }
-          }
-#if NTRU_TR_BURST
-          __builtin_amdgcn_sched_barrier(0);                       // keep the burst together
-#endif
-#pragma unroll
-          for (int t = 0; t < NTS; t++) {
-            const int c0 = 32 * (kb0 + t);
-            if (c0 + 32 <= N) {                                    // whole tile inside the row (wave-uniform)
-              // v_permlane32_swap(a, b): a = [a.lower | b.lower], b = [a.upper | b.upper].  Groups 2p, 2p + 1 of both half-waves
-              // -> lower lanes: columns 16 p .. 16 p + 7, upper lanes: columns 16 p + 8 .. 16 p + 15, 16 bytes per lane.
-              // The scalar offset of these 16-byte stores is 0 (hazard: profiles/r02_hazard_store_x4_soffset.txt).
-#pragma unroll
-              for (int pr = 0; pr < 2; pr++) {
-                const auto e0 = __builtin_amdgcn_permlane32_swap(E[t][2 * pr][0], E[t][2 * pr + 1][0], false, false);
-                const auto e1 = __builtin_amdgcn_permlane32_swap(E[t][2 * pr][1], E[t][2 * pr + 1][1], false, false);
-#ifdef NTRU_TR_FAKE_QUADS      // timing only (wrong values): the address pattern of 16 rows x 64 contiguous bytes per instruction, 4 adjacent lanes per row
-#if NTRU_TR_FAKE_QUADS == 2    // 4 rows x 256 contiguous bytes per instruction (16 adjacent lanes per row of the strip)
-                const int vo = 2 * ((4 * (2 * t + pr) + (lane >> 4)) * LD + 32 * kb0) + 16 * (lane & 15);
-#else
-                const int vo = 2 * (((lane >> 2) + 16 * pr) * LD + c0) + 16 * (lane & 3);
-#endif
-#else
-                const int vo = row_b + 2 * c0 + 32 * pr;
-#endif
-                if (1 ABL_STORE(lo[t][0])) {
-                  __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)e0[0], (int)e1[0], (int)e0[1], (int)e1[1]}, rs_e, vo, 0, ST_AUX);
-                  if (decltype(wq)::value) {
-                    const auto q0 = __builtin_amdgcn_permlane32_swap(Q[t][2 * pr][0], Q[t][2 * pr + 1][0], false, false);
-                    const auto q1 = __builtin_amdgcn_permlane32_swap(Q[t][2 * pr][1], Q[t][2 * pr + 1][1], false, false);
-                    __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)q0[0], (int)q1[0], (int)q0[1], (int)q1[1]}, rs_q, vo, 0, ST_AUX);
-                  }
-                }
-              }
-            } else {                                               // the row's last, partial tile: coefficient by coefficient
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                  const int col = c0 + 8 * k + 4 * hh + j;
-                  const int vo = col < N ? 2 * (R * LD + col) : (int)0x80000000;
-                  if (1 ABL_STORE(lo[t][0])) {
-                    __builtin_amdgcn_raw_buffer_store_b16((u16)(E[t][k][j >> 1] >> (16 * (j & 1))), rs_e, vo, 0, ST_AUX);
-                    if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)(Q[t][k][j >> 1] >> (16 * (j & 1))), rs_q, vo, 0, ST_AUX);
-                  }
-                }
-            }
-          }
-          constexpr int S = 2 * NTS * (decltype(wq)::value ? 2 : 1), K = S < 63 ? S : 63;      // at least the 16-byte stores are behind the row loads
-          if (DMA && dma_now && sidx == rounds - 1) __builtin_amdgcn_s_waitcnt((K & 15) | (7 << 4) | (15 << 8) | ((K >> 4) << 14));
-        };
-        if (TR) { if (want_q) out_tr(std::true_type{}); else out_tr(std::false_type{}); }
-        else if (CHUNK) { if (want_q) out_chunk(std::true_type{}); else out_chunk(std::false_type{}); }
+        if (CHUNK) { if (want_q) out_chunk(std::true_type{}); else out_chunk(std::false_type{}); }
         else if (want_q) out(std::true_type{}); else out(std::false_type{});
       };
       switch (nt) {
@@ -421,10 +329,10 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
           phase(); epi_sync();
           if (DMA && sidx == rounds - 1) __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0): nothing of its own is stored after them
           break;
-        case 1: toeplitz_strip<M_ENC, 1, TR>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
-        case 2: toeplitz_strip<M_ENC, 2, TR>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
-        case 3: toeplitz_strip<M_ENC, 3, TR>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
-        case 4: toeplitz_strip<M_ENC, 4, TR>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 1: toeplitz_strip<M_ENC, 1>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 2: toeplitz_strip<M_ENC, 2>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 3: toeplitz_strip<M_ENC, 3>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
+        case 4: toeplitz_strip<M_ENC, 4>(st0, st0, tb0, tb1, g, kb0, mlow, epi, stamp_iter, 4 + 2 * sidx); break;
         default: break;                                  // MAXT = 4
       }
       sidx++;
@@ -438,7 +346,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_m(MGeom g, u32 q, 
                                                              const uint8_t *__restrict__ r,
                                                              const uint8_t *__restrict__ m, long B,
                                                              u16 *__restrict__ e, u16 *__restrict__ quotE) {
-  encrypt_m_body<4, 1, false, false, NTRU_TRANSPOSED_EPILOGUE>(g, q, h, r, m, B, e, quotE);
+  encrypt_m_body<4, 1>(g, q, h, r, m, B, e, quotE);
 }
 
 #ifdef NTRU_EXPERIMENTS
@@ -454,7 +362,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_encrypt_md(MGeom g, u32 q,
                                                               const uint8_t *__restrict__ r,
                                                               const uint8_t *__restrict__ m, long B,
                                                               u16 *__restrict__ e, u16 *__restrict__ quotE) {
-  encrypt_m_body<4, 1, false, true, NTRU_TRANSPOSED_EPILOGUE>(g, q, h, r, m, B, e, quotE);
+  encrypt_m_body<4, 1, false, true>(g, q, h, r, m, B, e, quotE);
 }
 
 #ifdef NTRU_EXPERIMENTS

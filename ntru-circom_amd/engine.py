@@ -145,6 +145,17 @@ class Engine:
         except Exception:
             pass
 
+    # ---- launch log (profiling aid) ----------------------------------------------------------------------------
+    # NTRU_LAUNCH_LOG=<path>: every single-kernel *_dev call appends {"kernel", "N", "items", "bytes_per_item"} in launch order;
+    # tools/pmc_summary.py matches the k-th rocprofv3 dispatch of a kernel with the k-th record, so that per-launch counters are
+    # scaled by the size of THAT launch (bench.py and tools/bench_configs.py launch one kernel at several sizes).
+    def _note(self, N, items, bytes_per_item):
+        path = os.environ.get("NTRU_LAUNCH_LOG")
+        if path:
+            with open(path, "a") as fh:
+                fh.write('{"kernel": "%s", "N": %d, "items": %d, "bytes_per_item": %d}\n'
+                         % (self.last_kernel(), int(N), int(items), int(bytes_per_item)))
+
     def set_stream(self, hip_stream):
         self._chk(self._lib.ntru_engine_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
 
@@ -217,6 +228,7 @@ class Engine:
         key = _np(key, np.uint32, (8,))
         self._chk(self._lib.ntru_sample_ternary_dev(self._h, N, n1, n2, other, _ptr(key), int(first_item), B,
                                                     self._dp(d_out)))
+        self._note(N, B, N)
 
     def encrypt_batch(self, N, q, h, r, m, want_quot=True):
         h = _np(h, np.uint16, (N,))
@@ -337,6 +349,7 @@ class Engine:
     def public_key_batch_dev(self, N, q, p, d_fq, d_g, B, d_h):
         dp = self._dp
         self._chk(self._lib.ntru_public_key_batch_dev(self._h, N, q, p, dp(d_fq), dp(d_g), B, dp(d_h)))
+        self._note(N, B, 5 * N)
 
     # ---- device pointers (asynchronous) -------------------------------------------------------------------
     @staticmethod
@@ -346,6 +359,7 @@ class Engine:
     def polymul_split_dev(self, N, mod, d_a, d_b, B, d_quot, d_rem):
         dp = self._dp
         self._chk(self._lib.ntru_polymul_split_dev(self._h, N, mod, dp(d_a), dp(d_b), B, dp(d_quot), dp(d_rem)))
+        self._note(N, B, 8 * N)
 
     def split_by_I_dev(self, N, mod, d_a, B, d_quot, d_rem):
         dp = self._dp
@@ -363,6 +377,7 @@ class Engine:
         else:
             self._chk(self._lib.ntru_encrypt_batch_pitched_dev(self._h, N, q, int(ld), dp(d_h), dp(d_r), dp(d_m), B,
                                                                dp(d_e), dp(d_quotE)))
+        self._note(N, B, (6 if d_quotE else 4) * N)             # r, m in; e (+ quotientE) out
 
     def decrypt_batch_dev(self, N, q, p, d_f, d_fp, d_e, B, d_value, d_quot1=None, d_rem1=None, d_quot2=None, ld=None):
         """ld: row pitch of e, value, quot1, rem1, quot2 in elements (None = dense rows of N)."""
@@ -373,6 +388,7 @@ class Engine:
         else:
             self._chk(self._lib.ntru_decrypt_batch_pitched_dev(self._h, N, q, p, int(ld), dp(d_f), dp(d_fp), dp(d_e), B,
                                                                dp(d_value), dp(d_quot1), dp(d_rem1), dp(d_quot2)))
+        self._note(N, B, (3 + (2 if d_quot1 else 0) + (2 if d_rem1 else 0) + (1 if d_quot2 else 0)) * N)
 
     def verify_keys_batch_dev(self, N, q, p, d_f, d_g, d_fq, d_fp, d_h, B, d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp,
                               d_quot_h, d_rem_h, d_flags):
@@ -380,6 +396,7 @@ class Engine:
         self._chk(self._lib.ntru_verify_keys_batch_dev(self._h, N, q, p, dp(d_f), dp(d_g), dp(d_fq), dp(d_fp), dp(d_h),
                                                        B, dp(d_quot_fq), dp(d_rem_fq), dp(d_quot_fp), dp(d_rem_fp),
                                                        dp(d_quot_h), dp(d_rem_h), dp(d_flags)))
+        self._note(N, B, 17 * N)
 
 
 class MultiEngine:

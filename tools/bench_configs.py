@@ -21,6 +21,20 @@ stream = torch.cuda.current_stream()
 eng.set_stream(stream.cuda_stream)
 
 
+from oracle import ntru_oracle as orc  # noqa: E402  (the checker: every config below compares a strided sample with it)
+
+N_CHECK = 64
+
+
+def sample_rows(B):
+    return torch.tensor(sorted(set(list(range(0, B, max(1, B // N_CHECK))) + [B - 1])), device=dev)
+
+
+def host(t, rows):
+    a = t[rows].contiguous().cpu().numpy()
+    return a.view(np.uint16) if a.dtype == np.int16 else a
+
+
 def timed(fn, steps=5, warmup=2):
     for _ in range(warmup):
         fn()
@@ -42,8 +56,12 @@ def encrypt_config(profile, logB):
     e = torch.empty((B, N), dtype=torch.int16, device=dev)
     quot = torch.empty((B, N), dtype=torch.int16, device=dev)
     ms = timed(lambda: eng.encrypt_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e.data_ptr(), quot.data_ptr()))
+    rows = sample_rows(B)
+    e_o, q_o = orc.encrypt_batch(N, q, h_np, host(r, rows), host(m, rows))
+    ok = bool(np.array_equal(host(e, rows), e_o) and np.array_equal(host(quot, rows), q_o))
     return {"config": "N=%d q=%d batch=2^%d encryptBits (full witness), 1 GPU" % (N, q, logB), "kernel": eng.last_kernel(),
-            "ms": ms, "encrypts_per_s": B / (ms * 1e-3), "hbm_GBps": 6 * N * B / (ms * 1e-3) / 1e9}
+            "ms": ms, "encrypts_per_s": B / (ms * 1e-3), "hbm_GBps": 6 * N * B / (ms * 1e-3) / 1e9,
+            "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
 
 
 def verify_config(profile, logB):
@@ -62,8 +80,13 @@ def verify_config(profile, logB):
     flags = torch.empty(B, dtype=torch.uint8, device=dev)
     ms = timed(lambda: eng.verify_keys_batch_dev(N, q, p, f.data_ptr(), g.data_ptr(), fq.data_ptr(), fp.data_ptr(),
                                                  hh.data_ptr(), B, *[t.data_ptr() for t in outs], flags.data_ptr()))
+    rows = sample_rows(B)
+    want = list(orc.verify_keys_batch(N, q, p, host(f, rows), host(g, rows), host(fq, rows), host(fp, rows), host(hh, rows)).values())
+    got = [host(t, rows) for t in outs] + [host(flags, rows)]
+    ok = all(np.array_equal(a, b) for a, b in zip(got, want))
     return {"config": "N=%d q=%d verifyKeysInputs batch=2^%d synthetic per-item keys, 1 GPU" % (N, q, logB),
-            "kernel": eng.last_kernel(), "ms": ms, "keys_per_s": B / (ms * 1e-3), "hbm_GBps": 17 * N * B / (ms * 1e-3) / 1e9}
+            "kernel": eng.last_kernel(), "ms": ms, "keys_per_s": B / (ms * 1e-3), "hbm_GBps": 17 * N * B / (ms * 1e-3) / 1e9,
+            "rows_equal_oracle": bool(ok), "rows_checked": int(rows.numel())}
 
 
 def sampler_config(profile, logB):
@@ -73,8 +96,12 @@ def sampler_config(profile, logB):
     r = torch.empty((B, N), dtype=torch.uint8, device=dev)
     key = np.arange(8, dtype=np.uint32) + 1
     ms = timed(lambda: eng.sample_ternary_dev(N, d, d, p - 1, key, 0, B, r.data_ptr()))
+    first = orc.sample_ternary_batch(N, d, d, p - 1, key, 0, 8)
+    last = orc.sample_ternary_batch(N, d, d, p - 1, key, B - 8, 8)
+    ok = bool(np.array_equal(r[:8].cpu().numpy(), first) and np.array_equal(r[B - 8:].cpu().numpy(), last))
     return {"config": "N=%d d=%d batch=2^%d on-device generateCustomArray (ChaCha20 draws), 1 GPU" % (N, d, logB),
-            "kernel": eng.last_kernel(), "ms": ms, "samples_per_s": B / (ms * 1e-3), "hbm_GBps": N * B / (ms * 1e-3) / 1e9}
+            "kernel": eng.last_kernel(), "ms": ms, "samples_per_s": B / (ms * 1e-3), "hbm_GBps": N * B / (ms * 1e-3) / 1e9,
+            "rows_equal_oracle": ok, "rows_checked": 16}
 
 
 def keygen_config(profile, logB):
@@ -103,9 +130,16 @@ def keygen_config(profile, logB):
     vms = timed(lambda: eng.verify_keys_batch_dev(N, q, p, f.data_ptr(), g.data_ptr(), fq.data_ptr(), fp.data_ptr(), h.data_ptr(),
                                                   B, *[t.data_ptr() for t in outs], vflags.data_ptr()), steps=3, warmup=1)
     bad = int(((vflags != 0) & (fl == 0)).sum())
+    # the generated keys against the oracle: h = p fq g and the verify_keys witness of a strided sample (which holds f fq = 1, f fp = 1)
+    rows = sample_rows(B)
+    h_o = orc.public_key_batch(N, q, p, host(fq, rows), host(g, rows))
+    want = list(orc.verify_keys_batch(N, q, p, host(f, rows), host(g, rows), host(fq, rows), host(fp, rows), host(h, rows)).values())
+    got = [host(t, rows) for t in outs] + [host(vflags, rows)]
+    ok = bool(np.array_equal(host(h, rows), h_o)) and all(np.array_equal(a, b) for a, b in zip(got, want))
     return {"config": "N=%d q=%d key generation batch=2^%d (sample f, g; invert mod q and mod p; h) then verifyKeysInputs on the "
                       "generated keys, 1 GPU" % (N, q, logB), "keygen_ms": ms, "keys_per_s": B / (ms * 1e-3), "units": units,
-            "verify_ms": vms, "verify_keys_per_s": B / (vms * 1e-3), "verify_flags_on_valid_keys": bad}
+            "verify_ms": vms, "verify_keys_per_s": B / (vms * 1e-3), "verify_flags_on_valid_keys": bad,
+            "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
 
 
 def add_config(N, q, logB):
@@ -133,10 +167,14 @@ def polymul_config(N, q, logB):
         eng.set_kernel_path(path)
         ms = timed(lambda: eng.polymul_split_dev(N, q, a.data_ptr(), b.data_ptr(), B, quot.data_ptr(), rem.data_ptr()))
         out[name] = {"kernel": eng.last_kernel(), "ms": ms, "products_per_s": B / (ms * 1e-3)}
+        if path == 0:
+            rows = sample_rows(B)
+            q_o, r_o = orc.polymul_split_batch(N, q, host(a, rows), host(b, rows))
+            ok = bool(np.array_equal(host(quot, rows), q_o) and np.array_equal(host(rem, rows), r_o))
     eng.set_kernel_path(0)
     return {"config": "N=%d q=%d batch=2^%d multiplyPolynomials + split by I, per-item operands, 1 GPU" % (N, q, logB),
             "kernel": out["auto"]["kernel"], "ms": out["auto"]["ms"], "products_per_s": out["auto"]["products_per_s"],
-            "vector_alu": out["vector ALU (packed MAC)"]}
+            "vector_alu": out["vector ALU (packed MAC)"], "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
 
 
 if __name__ == "__main__":

@@ -8,11 +8,13 @@
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-B="python3 bench.py --no-cpu-baseline --steps 5 --warmup 2"
+B="python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 --power-seconds 0"
 S="python3 tools/bench_configs.py"
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"
 SQ2="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
-run() { d=$1; shift; rm -rf gpurun_out/$d; echo "== $d"; rocprofv3 "$@" > gpurun_out/$d.log 2>&1 || { tail -5 gpurun_out/$d.log; exit 1; }; }
+# NTRU_LAUNCH_LOG: the engine's Python binding appends (kernel, N, items, bytes per item) of every launch, in order, so that
+# tools/pmc_summary.py can scale each dispatch by its own size
+run() { d=$1; shift; rm -rf gpurun_out/$d gpurun_out/${d}_launches.jsonl; export NTRU_LAUNCH_LOG=$PWD/gpurun_out/${d}_launches.jsonl; echo "== $d"; rocprofv3 "$@" > gpurun_out/$d.log 2>&1 || { tail -5 gpurun_out/$d.log; exit 1; }; }
 run prof_stats --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- $B
 run prof_fetch --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_fetch -- $B
 run prof_write --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_write -- $B
