@@ -99,6 +99,25 @@ int ntru_engine_synchronize(ntru_engine_t *eng);
 /* Message describing the last error on this thread ("" if none). */
 const char *ntru_last_error(void);
 
+/* ---- device-resident use from a host language without HIP of its own (the N-API addon) --------------------------------------
+ * ntru_pipeline_batch chains generateCustomArray (index.js:461-488: the r of encryptBits, drawn on the device from a ChaCha20
+ * stream) -> encryptBits (index.js:87-110) -> decryptBits (index.js:111-140) -> packOutput (index.js:572-596) for a batch of HOST
+ * plaintexts m [B][N]; the intermediates stay on the GPU, chunk by chunk through the engine's two streams.
+ *   key != NULL: r is sampled (n1 ones, n2 entries p - 1, item b from stream position first_item + b); else r [B][N] is read.
+ *   f, fp both NULL: encrypt only.
+ *   outputs, each optional (at least one): r_out [B][N] (the sampled r, to replay), e [B][N], value [B][N] (needs f, fp),
+ *   packed [B][output_size][4] = packOutput(max, N, .) of the LAST stage's result: value with max = p - 1 when decrypting, else e
+ *   with max = q - 1 (sizes from ntru_pack_params). */
+int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *h, const int8_t *f, const uint8_t *fp,
+                        const uint32_t *key, uint64_t first_item, int n1, int n2, const uint8_t *r, const uint8_t *m, int64_t B,
+                        uint8_t *r_out, uint16_t *e, uint8_t *value, uint64_t *packed);
+/* Plain device buffers on the engine's device for use with the *_dev entry points.  ntru_dev_upload returns when `src` may be
+ * reused and orders the data before every later call on the engine's stream; ntru_dev_download first waits for that stream. */
+int ntru_dev_alloc(ntru_engine_t *eng, size_t bytes, void **d_ptr);
+int ntru_dev_free(ntru_engine_t *eng, void *d_ptr);
+int ntru_dev_upload(ntru_engine_t *eng, void *d_dst, const void *src, size_t bytes);
+int ntru_dev_download(ntru_engine_t *eng, void *dst, const void *d_src, size_t bytes);
+
 /* 1 if (N, mod) is a parameter set the kernels implement: mod a power of two <= 65536, or a small
  * modulus with N*(mod-1)^2 < 65536 (p = 3 for every NTRU set); 2 <= N <= NTRU_MAX_N. */
 int ntru_engine_supports(int N, int mod);
@@ -276,6 +295,8 @@ int ntru_generic_poly_inv(ntru_engine_t *eng, int la, int lb, int64_t mod, const
 int ntru_pack_params(int max_val, int data_len, int *bits, int *per_output, int *arr_len, int *output_size);
 int ntru_pack_batch(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *data, int64_t B, uint64_t *out);
 int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *d_data, int64_t B, uint64_t *d_out);
+/* packOutput of an array of BYTES (values <= 255: decryptBits' value and quotient2, r, m) without widening it to uint16 first. */
+int ntru_pack_bytes_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint8_t *d_data, int64_t B, uint64_t *d_out);
 int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *in, int packed_size, int64_t B,
                       uint16_t *out);
 int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *d_in, int packed_size,

@@ -282,7 +282,9 @@ __global__ void k_newton_combine(u16 *__restrict__ v, const u16 *__restrict__ u,
 
 // ---- BN254 field-element packing (index.js:572-620): elementwise, HBM-bound ---------------------------------------
 // One thread per 64-bit limb of the output: out[b][o] = sum_j data[b][o*per + j] << (j*bits), four LE limbs per element.
-__global__ void k_pack(int bits, int per, int data_len, int out_size, const u16 *__restrict__ data, long B,
+// T: u16 values (ciphertexts, witness arrays) or bytes (decrypted values, ternary arrays).
+template <class T>
+__global__ void k_pack(int bits, int per, int data_len, int out_size, const T *__restrict__ data, long B,
                        unsigned long long *__restrict__ out) {
   const long total = B * out_size * 4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -498,7 +500,24 @@ extern "C" int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len
   if (B == 0) return NTRU_OK;
   if ((!d_data && data_len) || !d_out) return fail(NTRU_ERR_ARG, "ntru_pack_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
-  hipLaunchKernelGGL(k_pack, elementwise_grid(eng, B * os * 4), dim3(256), 0, eng->stream, bits, per, data_len, os, d_data,
+  hipLaunchKernelGGL(k_pack<u16>, elementwise_grid(eng, B * os * 4), dim3(256), 0, eng->stream, bits, per, data_len, os, d_data,
+                     (long)B, (unsigned long long *)d_out);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+// The same for an array of BYTES (decryptBits' value, quotient2, r, m: values <= 255): packOutput without widening it first.
+extern "C" int ntru_pack_bytes_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint8_t *d_data, int64_t B,
+                                         uint64_t *d_out) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (B < 0) return fail(NTRU_ERR_ARG, "negative batch size");
+  if (max_val > 255) return fail(NTRU_ERR_ARG, "ntru_pack_bytes_batch: max_val must fit a byte");
+  int bits, per, al, os;
+  if (int rc = ntru_pack_params(max_val, data_len, &bits, &per, &al, &os)) return rc;
+  if (B == 0) return NTRU_OK;
+  if ((!d_data && data_len) || !d_out) return fail(NTRU_ERR_ARG, "ntru_pack_bytes_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipLaunchKernelGGL(k_pack<uint8_t>, elementwise_grid(eng, B * os * 4), dim3(256), 0, eng->stream, bits, per, data_len, os, d_data,
                      (long)B, (unsigned long long *)d_out);
   HIP_TRY(hipGetLastError());
   return NTRU_OK;

@@ -33,6 +33,7 @@ struct HArr {
   size_t row = 0;              // bytes per item, or total bytes when `shared`
   bool shared = false;         // the same bytes for every chunk (key rows)
   bool direct = false;         // host memory is pinned: DMA straight from / to it
+  bool temp = false;           // lives on the device only (an intermediate of a multi-stage chunk): no copy either way
   size_t dev_off = 0, pin_off = 0;
 };
 
@@ -82,6 +83,10 @@ struct Pipeline {
     arr[n].dst = p; arr[n].row = row; arr[n].direct = p && is_pinned(p);
     return n++;
   }
+  int tmp(size_t row) {          // device-only rows of a chunk (what one stage hands the next)
+    arr[n].row = row; arr[n].temp = true;
+    return n++;
+  }
 
   int drain(int s) {
     HostSlot &sl = eng->slot[s];
@@ -103,9 +108,9 @@ struct Pipeline {
     for (int i = 0; i < n; i++) {
       HArr &a = arr[i];
       const size_t bytes = a.shared ? a.row : a.row * (size_t)C;
-      if (!a.src && !a.dst) continue;
+      if (!a.src && !a.dst && !a.temp) continue;
       a.dev_off = dev_bytes; dev_bytes += up(bytes);
-      if (!a.direct) { a.pin_off = pin_bytes; pin_bytes += up(bytes); }
+      if (!a.direct && !a.temp) { a.pin_off = pin_bytes; pin_bytes += up(bytes); }
     }
     for (int s = 0; s < 2; s++) {
       HostSlot &sl = eng->slot[s];
@@ -126,7 +131,7 @@ struct Pipeline {
       void *dev[MAX_ARR];
       for (int i = 0; i < n && rc == NTRU_OK; i++) {
         HArr &a = arr[i];
-        dev[i] = (a.src || a.dst) ? (char *)sl.dev.p + a.dev_off : nullptr;
+        dev[i] = (a.src || a.dst || a.temp) ? (char *)sl.dev.p + a.dev_off : nullptr;
         if (!a.src) continue;
         const size_t bytes = a.shared ? a.row : a.row * (size_t)cnt;
         const char *from = (const char *)a.src + (a.shared ? 0 : a.row * (size_t)o);
@@ -360,6 +365,88 @@ extern "C" int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bit
   return P.run(B, chunk_items(B), [&](int64_t, int64_t n, void **d) {
     return ntru_unpack_batch_dev(eng, max_val, packed_bits, (const uint64_t *)d[ii], packed_size, n, (uint16_t *)d[io]);
   });
+}
+
+// ---- device-resident stages for a caller without HIP of its own (Node.js) -------------------------------------------------------
+// ntru_pipeline_batch: sampler -> encryptBits -> decryptBits -> packOutput per chunk, the intermediates (r, e, value) staying in the
+// slot's device arena; only m (and r when the caller supplies it) crosses PCIe upwards and only the outputs asked for come back
+// (index.js:461-488, :87-140, :572-620 chained).  The chunks flow through the same two-slot pipeline as every host-pointer entry
+// point, so the upload of chunk k+1 and the download of chunk k-1 overlap the kernels of chunk k.
+extern "C" int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *h, const int8_t *f, const uint8_t *fp,
+                                   const uint32_t *key, uint64_t first_item, int n1, int n2, const uint8_t *r, const uint8_t *m,
+                                   int64_t B, uint8_t *r_out, uint16_t *e, uint8_t *value, uint64_t *packed) {
+  CHECK_ENGINE();
+  const bool decrypt = f != nullptr || fp != nullptr;
+  if (decrypt && (!f || !fp)) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: the decrypt stage needs both f and fp");
+  if (!decrypt && value) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: `value` needs the decrypt stage (f, fp)");
+  if ((key != nullptr) == (r != nullptr)) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: give either a sampler key or r");
+  if (!e && !value && !packed) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: no output asked for");
+  // parameter checks of every stage (B = 0 calls return after them)
+  if (int rc = ntru_encrypt_batch_dev(eng, N, q, nullptr, nullptr, nullptr, 0, nullptr, nullptr)) return rc;
+  if (decrypt) if (int rc = ntru_decrypt_batch_dev(eng, N, q, p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr)) return rc;
+  if (key) if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, p - 1, key, first_item, 0, nullptr)) return rc;
+  int bits = 0, per = 0, al = 0, os = 0;
+  const int pack_max = decrypt ? p - 1 : q - 1;                    // packOutput of the last stage's result
+  if (packed) if (int rc = ntru_pack_params(pack_max, N, &bits, &per, &al, &os)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!h || !m) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: NULL buffer");
+  Pipeline P(eng);
+  const int ih = P.in(h, (size_t)N * 2, true), im = P.in(m, N);
+  const int jf = decrypt ? P.in(f, N, true) : -1, jfp = decrypt ? P.in(fp, N, true) : -1;
+  const int ir = r ? P.in(r, N) : (r_out ? P.out(r_out, N) : P.tmp(N));
+  const int ie = e ? P.out(e, (size_t)N * 2) : P.tmp((size_t)N * 2);
+  const int iv = !decrypt ? -1 : (value ? P.out(value, N) : P.tmp(N));
+  const int ip = packed ? P.out(packed, (size_t)os * 32) : -1;
+  return P.run(B, chunk_items(B), [&](int64_t o, int64_t n, void **d) {
+    if (key) if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, p - 1, key, first_item + (uint64_t)o, n, (uint8_t *)d[ir])) return rc;
+    if (int rc = ntru_encrypt_batch_dev(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
+                                        (uint16_t *)d[ie], nullptr)) return rc;
+    if (decrypt)
+      if (int rc = ntru_decrypt_batch_dev(eng, N, q, p, (const int8_t *)d[jf], (const uint8_t *)d[jfp], (const uint16_t *)d[ie], n,
+                                          (uint8_t *)d[iv], nullptr, nullptr, nullptr)) return rc;
+    if (packed)
+      return decrypt ? ntru_pack_bytes_batch_dev(eng, pack_max, N, (const uint8_t *)d[iv], n, (uint64_t *)d[ip])
+                     : ntru_pack_batch_dev(eng, pack_max, N, (const uint16_t *)d[ie], n, (uint64_t *)d[ip]);
+    return NTRU_OK;
+  });
+}
+
+// Plain device buffers on the engine's device, with copies ordered on the engine's stream: what a binding needs to keep arrays
+// on the GPU between *_dev calls (the addon hands them to JavaScript as opaque handles).
+extern "C" int ntru_dev_alloc(ntru_engine_t *eng, size_t bytes, void **d_ptr) {
+  if (!eng || !d_ptr) return ntru_fail(NTRU_ERR_ARG, "ntru_dev_alloc: NULL argument");
+  *d_ptr = nullptr;
+  HIP_TRY(hipSetDevice(eng->device));
+  if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) { *d_ptr = nullptr; return ntru_fail(NTRU_ERR_HIP, "hipMalloc failed"); }
+  return NTRU_OK;
+}
+
+extern "C" int ntru_dev_free(ntru_engine_t *eng, void *d_ptr) {
+  if (!eng) return ntru_fail(NTRU_ERR_ARG, "engine is NULL");
+  if (!d_ptr) return NTRU_OK;
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipFree(d_ptr));                  // waits for the device: nothing in flight still uses the buffer
+  return NTRU_OK;
+}
+
+// Returns when `src` may be reused (pageable memory is copied before the call returns, pinned memory once the DMA is done); the data
+// is in place for every later call on the engine's stream.
+extern "C" int ntru_dev_upload(ntru_engine_t *eng, void *d_dst, const void *src, size_t bytes) {
+  if (!eng || (bytes && (!d_dst || !src))) return ntru_fail(NTRU_ERR_ARG, "ntru_dev_upload: NULL argument");
+  if (!bytes) return NTRU_OK;
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, eng->stream));
+  HIP_TRY(hipStreamSynchronize(eng->stream));
+  return NTRU_OK;
+}
+
+// Waits for everything enqueued on the engine's stream, then returns with the bytes in `dst`.
+extern "C" int ntru_dev_download(ntru_engine_t *eng, void *dst, const void *d_src, size_t bytes) {
+  if (!eng || (bytes && (!dst || !d_src))) return ntru_fail(NTRU_ERR_ARG, "ntru_dev_download: NULL argument");
+  HIP_TRY(hipSetDevice(eng->device));
+  if (bytes) HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, eng->stream));
+  HIP_TRY(hipStreamSynchronize(eng->stream));
+  return NTRU_OK;
 }
 
 // ---- several devices in ONE process: contiguous shards, one host thread + engine (with its two streams) per device ------

@@ -55,6 +55,12 @@ for _sfx in ("", "_dev"):
     _SIGS["ntru_encrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
     _SIGS["ntru_decrypt_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
     _SIGS["ntru_verify_keys_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i] + [_vp] * 5 + [_i64] + [_vp] * 7)
+_SIGS["ntru_pack_bytes_batch_dev"] = (C.c_int, [_vp, _i, _i, _vp, _i64, _vp])
+_SIGS["ntru_pipeline_batch"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint64, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
+_SIGS["ntru_dev_alloc"] = (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)])
+_SIGS["ntru_dev_free"] = (C.c_int, [_vp, _vp])
+_SIGS["ntru_dev_upload"] = (C.c_int, [_vp, _vp, _vp, C.c_size_t])
+_SIGS["ntru_dev_download"] = (C.c_int, [_vp, _vp, _vp, C.c_size_t])
 _SIGS["ntru_host_alloc"] = (C.c_void_p, [C.c_size_t])
 _SIGS["ntru_host_free"] = (None, [_vp])
 _SIGS["ntru_generic_capacity"] = (C.c_int, [_i, _i])
@@ -229,6 +235,50 @@ class Engine:
         self._chk(self._lib.ntru_sample_ternary_dev(self._h, N, n1, n2, other, _ptr(key), int(first_item), B,
                                                     self._dp(d_out)))
         self._note(N, B, N)
+
+    def pipeline_batch(self, N, q, p, h, m, f=None, fp=None, key=None, first_item=0, n1=0, n2=0, r=None,
+                       want_r=False, want_e=False, want_value=False, want_packed=False):
+        """ntru_pipeline_batch: sampler (key) or given r -> encryptBits -> decryptBits (f, fp) -> packOutput, device-resident between
+        the stages; host arrays in and out.  Returns a dict of the outputs asked for."""
+        h = _np(h, np.uint16, (N,))
+        m = _np(m, np.uint8).reshape(-1, N)
+        B = m.shape[0]
+        f = None if f is None else _np(f, np.int8, (N,))
+        fp = None if fp is None else _np(fp, np.uint8, (N,))
+        key = None if key is None else _np(key, np.uint32, (8,))
+        r = None if r is None else _np(r, np.uint8).reshape(-1, N)
+        out = {}
+        if want_r: out["r"] = np.empty((B, N), np.uint8)
+        if want_e: out["e"] = np.empty((B, N), np.uint16)
+        if want_value: out["value"] = np.empty((B, N), np.uint8)
+        if want_packed:
+            osz = self.pack_params(p - 1 if f is not None else q - 1, N)["outputSize"]
+            out["packed"] = np.empty((B, osz, 4), np.uint64)
+        self._chk(self._lib.ntru_pipeline_batch(self._h, N, q, p, _ptr(h), _ptr(f), _ptr(fp), _ptr(key), int(first_item), int(n1), int(n2),
+                                                _ptr(r), _ptr(m), B, _ptr(out.get("r")), _ptr(out.get("e")), _ptr(out.get("value")),
+                                                _ptr(out.get("packed"))))
+        return out
+
+    # ---- plain device buffers (for callers without torch: what the N-API addon hands to JavaScript) ----------------
+    def dev_alloc(self, nbytes):
+        p = _vp()
+        self._chk(self._lib.ntru_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, d_ptr):
+        self._chk(self._lib.ntru_dev_free(self._h, self._dp(d_ptr)))
+
+    def dev_upload(self, d_ptr, host):
+        host = np.ascontiguousarray(host)
+        self._chk(self._lib.ntru_dev_upload(self._h, self._dp(d_ptr), _ptr(host), host.nbytes))
+
+    def dev_download(self, d_ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._chk(self._lib.ntru_dev_download(self._h, _ptr(out), self._dp(d_ptr), out.nbytes))
+        return out
+
+    def pack_bytes_batch_dev(self, max_val, data_len, d_data, B, d_out):
+        self._chk(self._lib.ntru_pack_bytes_batch_dev(self._h, int(max_val), int(data_len), self._dp(d_data), B, self._dp(d_out)))
 
     def encrypt_batch(self, N, q, h, r, m, want_quot=True):
         h = _np(h, np.uint16, (N,))

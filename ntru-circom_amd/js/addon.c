@@ -383,6 +383,196 @@ static napi_value GenericOp(napi_env env, napi_callback_info info) {
   return arr;
 }
 
+/* ---- device-resident use (additive).  pipelineBatch chains sampler -> encryptBits -> decryptBits -> packOutput on the GPU for a batch
+ *      of host plaintexts (ntru_pipeline_batch); devAlloc / devUpload / devDownload / devFree plus the *Dev calls expose the engine's
+ *      *_dev entry points on opaque device-buffer handles, for callers that want to compose the stages themselves.  Every *Dev call
+ *      checks the byte size of each handle against what the kernel will touch before anything is launched. */
+
+/* pipelineBatch(N, q, p, h:Uint16Array[N], f:Int8Array[N]|null, fp:Uint8Array[N]|null, key:Uint32Array[8]|null, firstItem, n1, n2,
+ *               r:Uint8Array[B*N]|null, m:Uint8Array[B*N], B, rOut:Uint8Array|null, e:Uint16Array|null, value:Uint8Array|null,
+ *               packed:BigUint64Array[B*outputSize*4]|null) */
+static napi_value PipelineBatch(napi_env env, napi_callback_info info) {
+  ARGS(17)
+  int32_t N, q, p, n1, n2, B; double first; void *h, *f, *fp, *key, *r, *m, *r_out, *e, *value, *packed;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) ||
+      napi_get_value_double(env, argv[7], &first) != napi_ok || !get_i32(env, argv[8], &n1) || !get_i32(env, argv[9], &n2) ||
+      !get_i32(env, argv[12], &B) || N < 1 || B < 0 || first < 0 || first > 9007199254740991.0) BAD_ARGS();
+  const size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[3], napi_uint16_array, (size_t)N, 0, &h) || !get_buf(env, argv[4], napi_int8_array, (size_t)N, 1, &f) ||
+      !get_buf(env, argv[5], napi_uint8_array, (size_t)N, 1, &fp) || !get_buf(env, argv[6], napi_uint32_array, 8, 1, &key) ||
+      !get_buf(env, argv[10], napi_uint8_array, n, 1, &r) || !get_buf(env, argv[11], napi_uint8_array, n, 0, &m) ||
+      !get_buf(env, argv[13], napi_uint8_array, n, 1, &r_out) || !get_buf(env, argv[14], napi_uint16_array, n, 1, &e) ||
+      !get_buf(env, argv[15], napi_uint8_array, n, 1, &value)) BAD_ARGS();
+  size_t need_packed = 0;
+  {
+    int bits, per, al, os;
+    if (ntru_pack_params(f ? p - 1 : q - 1, N, &bits, &per, &al, &os) == 0) need_packed = (size_t)B * (size_t)os * 4;
+  }
+  if (!get_buf(env, argv[16], napi_biguint64_array, need_packed, 1, &packed)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, ntru_pipeline_batch(g_engine, N, q, p, h, f, fp, key, (uint64_t)first, n1, n2, r, m, B, r_out, e, value, packed));
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+typedef struct { void *p; size_t bytes; } DevBuf;
+
+static void devbuf_finalize(napi_env env, void *data, void *hint) {
+  (void)env; (void)hint;
+  DevBuf *b = (DevBuf *)data;
+  if (b->p) {                       /* not freed explicitly: release it with the handle (the engine may be gone already: then leak) */
+    pthread_mutex_lock(&g_lock);
+    if (g_engine) (void)ntru_dev_free(g_engine, b->p);
+    pthread_mutex_unlock(&g_lock);
+  }
+  free(b);
+}
+
+static DevBuf *get_dev(napi_env env, napi_value v, size_t need, int optional, int *ok) {
+  napi_valuetype vt;
+  *ok = 0;
+  if (napi_typeof(env, v, &vt) != napi_ok) return NULL;
+  if (vt == napi_null || vt == napi_undefined) { *ok = optional; return NULL; }
+  if (vt != napi_external) return NULL;
+  void *data = NULL;
+  if (napi_get_value_external(env, v, &data) != napi_ok || !data) return NULL;
+  DevBuf *b = (DevBuf *)data;
+  if (!b->p || b->bytes < need) return NULL;
+  *ok = 1;
+  return b;
+}
+
+/* devAlloc(bytes) -> handle */
+static napi_value DevAlloc(napi_env env, napi_callback_info info) {
+  ARGS(1)
+  double bytes;
+  if (napi_get_value_double(env, argv[0], &bytes) != napi_ok || bytes < 0 || bytes > 281474976710656.0) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  DevBuf *b = (DevBuf *)calloc(1, sizeof *b);
+  if (!b) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  int rc;
+  ENGINE_CALL(rc, ntru_dev_alloc(g_engine, (size_t)bytes, &b->p));
+  if (rc) { free(b); return throw_engine(env, rc); }
+  b->bytes = (size_t)bytes;
+  napi_value ext;
+  if (napi_create_external(env, b, devbuf_finalize, NULL, &ext) != napi_ok) {
+    ENGINE_CALL(rc, ntru_dev_free(g_engine, b->p)); free(b);
+    napi_throw_error(env, NULL, "napi_create_external failed"); return NULL;
+  }
+  return ext;
+}
+
+/* devFree(handle) */
+static napi_value DevFree(napi_env env, napi_callback_info info) {
+  ARGS(1)
+  int ok; DevBuf *b = get_dev(env, argv[0], 0, 0, &ok);
+  if (!ok) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, ntru_dev_free(g_engine, b->p));
+  b->p = NULL; b->bytes = 0;
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* The bytes of any TypedArray. */
+static int get_any(napi_env env, napi_value v, void **data, size_t *bytes) {
+  bool is_ta = false;
+  if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) return 0;
+  napi_typedarray_type t; size_t len;
+  if (napi_get_typedarray_info(env, v, &t, &len, data, NULL, NULL) != napi_ok) return 0;
+  static const size_t w[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+  if ((int)t < 0 || (size_t)t >= sizeof w / sizeof w[0]) return 0;
+  *bytes = len * w[t];
+  return 1;
+}
+
+/* devUpload(handle, src:TypedArray): the whole array to the start of the buffer */
+static napi_value DevUpload(napi_env env, napi_callback_info info) {
+  ARGS(2)
+  void *src; size_t bytes;
+  if (!get_any(env, argv[1], &src, &bytes)) BAD_ARGS();
+  int ok; DevBuf *b = get_dev(env, argv[0], bytes, 0, &ok);
+  if (!ok) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, ntru_dev_upload(g_engine, b->p, src, bytes));
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* devDownload(dst:TypedArray, handle): the first dst.byteLength bytes of the buffer; waits for the engine's stream */
+static napi_value DevDownload(napi_env env, napi_callback_info info) {
+  ARGS(2)
+  void *dst; size_t bytes;
+  if (!get_any(env, argv[0], &dst, &bytes)) BAD_ARGS();
+  int ok; DevBuf *b = get_dev(env, argv[1], bytes, 0, &ok);
+  if (!ok) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, ntru_dev_download(g_engine, dst, b->p, bytes));
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+#define DEV(i, need, opt, var) DevBuf *var = get_dev(env, argv[i], (need), (opt), &ok); if (!ok) BAD_ARGS();
+
+/* sampleTernaryDev(N, n1, n2, other, key:Uint32Array[8], firstItem, B, out:handle[B*N]) */
+static napi_value SampleTernaryDev(napi_env env, napi_callback_info info) {
+  ARGS(8)
+  int32_t N, n1, n2, other, B; double first; void *key; int ok;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &n1) || !get_i32(env, argv[2], &n2) || !get_i32(env, argv[3], &other) ||
+      napi_get_value_double(env, argv[5], &first) != napi_ok || !get_i32(env, argv[6], &B) || N < 1 || B < 0 || first < 0 ||
+      first > 9007199254740991.0 || !get_buf(env, argv[4], napi_uint32_array, 8, 0, &key)) BAD_ARGS();
+  DEV(7, (size_t)N * (size_t)B, 0, out)
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, ntru_sample_ternary_dev(g_engine, N, n1, n2, other, key, (uint64_t)first, B, out->p));
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* encryptBatchDev(N, q, h:handle[N u16], r:handle[B*N u8], m:handle[B*N u8], B, e:handle[B*N u16], quotE:handle|null) */
+static napi_value EncryptBatchDev(napi_env env, napi_callback_info info) {
+  ARGS(8)
+  int32_t N, q, B; int ok;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[5], &B) || N < 1 || B < 0) BAD_ARGS();
+  const size_t n = (size_t)N * (size_t)B;
+  DEV(2, 2 * (size_t)N, 0, h) DEV(3, n, 0, r) DEV(4, n, 0, m) DEV(6, 2 * n, 0, e) DEV(7, 2 * n, 1, quot)
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, ntru_encrypt_batch_dev(g_engine, N, q, h->p, r->p, m->p, B, e->p, quot ? quot->p : NULL));
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* decryptBatchDev(N, q, p, f:handle[N i8], fp:handle[N u8], e:handle[B*N u16], B, value:handle[B*N u8],
+ *                 quot1:handle|null, rem1:handle|null, quot2:handle|null) */
+static napi_value DecryptBatchDev(napi_env env, napi_callback_info info) {
+  ARGS(11)
+  int32_t N, q, p, B; int ok;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) || !get_i32(env, argv[6], &B) ||
+      N < 1 || B < 0) BAD_ARGS();
+  const size_t n = (size_t)N * (size_t)B;
+  DEV(3, (size_t)N, 0, f) DEV(4, (size_t)N, 0, fp) DEV(5, 2 * n, 0, e) DEV(7, n, 0, value) DEV(8, 2 * n, 1, q1) DEV(9, 2 * n, 1, r1) DEV(10, n, 1, q2)
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, ntru_decrypt_batch_dev(g_engine, N, q, p, f->p, fp->p, e->p, B, value->p, q1 ? q1->p : NULL, r1 ? r1->p : NULL,
+                                         q2 ? q2->p : NULL));
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
+/* packBatchDev(maxVal, dataLen, data:handle, B, out:handle[B*outputSize*32 bytes], bytes:boolean)   bytes: data holds uint8 values */
+static napi_value PackBatchDev(napi_env env, napi_callback_info info) {
+  ARGS(6)
+  int32_t max_val, data_len, B; bool is_bytes; int ok;
+  if (!get_i32(env, argv[0], &max_val) || !get_i32(env, argv[1], &data_len) || !get_i32(env, argv[3], &B) || data_len < 0 || B < 0 ||
+      napi_get_value_bool(env, argv[5], &is_bytes) != napi_ok) BAD_ARGS();
+  int bits, per, al, os;
+  if (ntru_pack_params(max_val, data_len, &bits, &per, &al, &os)) return throw_engine(env, NTRU_ERR_ARG);
+  DEV(2, (size_t)B * (size_t)data_len * (is_bytes ? 1 : 2), 0, data) DEV(4, (size_t)B * (size_t)os * 32, 0, out)
+  if (!ensure_engine(env)) return NULL;
+  int rc;
+  ENGINE_CALL(rc, is_bytes ? ntru_pack_bytes_batch_dev(g_engine, max_val, data_len, data->p, B, out->p)
+                           : ntru_pack_batch_dev(g_engine, max_val, data_len, data->p, B, out->p));
+  return rc ? throw_engine(env, rc) : undefined(env);
+}
+
 /* ---- asynchronous batch calls (additive; the reference API stays synchronous).  encryptBatchAsync / decryptBatchAsync take
  *      the arguments of their synchronous twins and return a Promise; the engine call runs on a libuv worker thread, so the
  *      event loop keeps turning while a 2^18-item batch (tens of milliseconds of PCIe) is in flight.  The typed arrays are
@@ -514,6 +704,15 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"allocPinned", NULL, AllocPinned, NULL, NULL, NULL, napi_default, NULL},
     {"genericCapacity", NULL, GenericCapacity, NULL, NULL, NULL, napi_default, NULL},
     {"genericOp", NULL, GenericOp, NULL, NULL, NULL, napi_default, NULL},
+    {"pipelineBatch", NULL, PipelineBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"devAlloc", NULL, DevAlloc, NULL, NULL, NULL, napi_default, NULL},
+    {"devFree", NULL, DevFree, NULL, NULL, NULL, napi_default, NULL},
+    {"devUpload", NULL, DevUpload, NULL, NULL, NULL, napi_default, NULL},
+    {"devDownload", NULL, DevDownload, NULL, NULL, NULL, napi_default, NULL},
+    {"sampleTernaryDev", NULL, SampleTernaryDev, NULL, NULL, NULL, napi_default, NULL},
+    {"encryptBatchDev", NULL, EncryptBatchDev, NULL, NULL, NULL, napi_default, NULL},
+    {"decryptBatchDev", NULL, DecryptBatchDev, NULL, NULL, NULL, napi_default, NULL},
+    {"packBatchDev", NULL, PackBatchDev, NULL, NULL, NULL, napi_default, NULL},
     {"encryptBatchAsync", NULL, EncryptBatchAsync, NULL, NULL, NULL, napi_default, NULL},
     {"decryptBatchAsync", NULL, DecryptBatchAsync, NULL, NULL, NULL, napi_default, NULL},
   };

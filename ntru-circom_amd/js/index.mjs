@@ -454,6 +454,54 @@ export default class NTRU {
     return { value, quotient1: q1, remainder1: r1, quotient2: q2 };
   }
 
+  // Device-resident pipeline for a batch of plaintexts (additive): the stages of the reference's encrypt / decrypt flow that the
+  // caller names run back to back on the GPU, chunk by chunk, and only what is asked for crosses PCIe:
+  //   sampleR: { key: Uint32Array[8], firstItem }   r = generateCustomArray(N, dr, dr) with -1 -> p-1 (index.js:89, :461-488) drawn on the
+  //                                                 device from the ChaCha20 stream of `key` (replayable) -- or  r: Uint8Array[B*N]
+  //   encrypt                                       always (index.js:87-110, this.h)
+  //   decrypt: true                                 decryptBits of the fresh ciphertexts (index.js:111-140, this.f / this.fp)
+  //   pack: true                                    packOutput (index.js:572-596) of the last stage's result: value (maxVal p-1) when
+  //                                                 decrypting, else the ciphertext (maxVal q-1); BigUint64Array[B*outputSize*4] limbs
+  //   want: { r, e, value }                         which plain arrays come back (default: e without decrypt, value with it, nothing
+  //                                                 but `packed` when pack is set)
+  // m: Uint8Array[B*N].  Arrays in `out` (e.g. from NTRU.allocUint8, page-locked) are filled in place.
+  pipeline({ m, B, sampleR = null, r = null, decrypt = false, pack = false, want = null, out = {} }) {
+    const { N, p, q, dr } = this;
+    if (!(m instanceof Uint8Array) || m.length < B * N) throw new TypeError('pipeline: m must be a Uint8Array of B*N plaintext coefficients');
+    if ((sampleR === null) === (r === null)) throw new TypeError('pipeline: give either sampleR: {key, firstItem} or r');
+    const w = want || (pack ? {} : (decrypt ? { value: true } : { e: true }));
+    const res = {};
+    if (w.r && sampleR) res.r = out.r || new Uint8Array(B * N);
+    if (w.e) res.e = out.e || new Uint16Array(B * N);
+    if (w.value) {
+      if (!decrypt) throw new TypeError('pipeline: `value` needs decrypt: true');
+      res.value = out.value || new Uint8Array(B * N);
+    }
+    if (pack) {
+      const outputSize = engine().packParams(decrypt ? p - 1 : q - 1, N)[3];
+      res.packed = out.packed || new BigUint64Array(B * outputSize * 4);
+      res.outputSize = outputSize;
+    }
+    engine().pipelineBatch(N, q, p, Uint16Array.from(expandArray(this.h, N, 0)),
+      decrypt ? Int8Array.from(expandArray(this.f, N, 0)) : null, decrypt ? Uint8Array.from(expandArray(this.fp, N, 0)) : null,
+      sampleR ? sampleR.key : null, sampleR ? (sampleR.firstItem || 0) : 0, dr, dr, r, m, B,
+      res.r || null, res.e || null, res.value || null, res.packed || null);
+    return res;
+  }
+
+  // Opaque device buffers + the engine's *_dev entry points on them, for callers that compose the stages themselves
+  // (sizes are checked against every handle before a kernel is launched).
+  static devAlloc(bytes) { return engine().devAlloc(bytes); }
+  static devFree(handle) { engine().devFree(handle); }
+  static devUpload(handle, typedArray) { engine().devUpload(handle, typedArray); }
+  static devDownload(typedArray, handle) { engine().devDownload(typedArray, handle); return typedArray; }
+  sampleRDev(key, firstItem, B, rDev) { engine().sampleTernaryDev(this.N, this.dr, this.dr, this.p - 1, key, firstItem, B, rDev); }
+  encryptBatchDev(hDev, rDev, mDev, B, eDev, quotDev = null) { engine().encryptBatchDev(this.N, this.q, hDev, rDev, mDev, B, eDev, quotDev); }
+  decryptBatchDev(fDev, fpDev, eDev, B, valueDev, q1Dev = null, r1Dev = null, q2Dev = null) {
+    engine().decryptBatchDev(this.N, this.q, this.p, fDev, fpDev, eDev, B, valueDev, q1Dev, r1Dev, q2Dev);
+  }
+  static packBatchDev(maxVal, dataLen, dataDev, B, outDev, bytes = false) { engine().packBatchDev(maxVal, dataLen, dataDev, B, outDev, bytes); }
+
   // Promise-returning twins of the two batch calls: the engine call runs on a libuv worker thread, the event loop keeps
   // turning meanwhile (calls are serialised inside the addon: one engine).  Same arguments, same results; the input and
   // output arrays must be left alone until the Promise settles.

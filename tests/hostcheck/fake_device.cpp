@@ -100,6 +100,13 @@ extern "C" int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len
   fake_enqueue(eng->stream, [=] { for (int64_t b = 0; b < B; b++) for (int j = 0; j < os * 4; j++) d_out[b * os * 4 + j] = (uint64_t)d_data[b * data_len + j % data_len] * 0x10001ull + j; });
   return NTRU_OK;
 }
+extern "C" int ntru_pack_bytes_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint8_t *d_data, int64_t B, uint64_t *d_out) {
+  int bits, per, al, os;
+  ntru_pack_params(max_val, data_len, &bits, &per, &al, &os);
+  if (B == 0) return NTRU_OK;
+  fake_enqueue(eng->stream, [=] { for (int64_t b = 0; b < B; b++) for (int j = 0; j < os * 4; j++) d_out[b * os * 4 + j] = (uint64_t)d_data[b * data_len + j % data_len] * 0x101ull + j; });
+  return NTRU_OK;
+}
 extern "C" int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *d_in, int packed_size, int64_t B,
                                      uint16_t *d_out) {
   int bits = 0;

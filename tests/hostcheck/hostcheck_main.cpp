@@ -92,6 +92,31 @@ static void per_item(ntru_engine_t *eng, int N, int q, int64_t B, bool pin) {
   CHECK(same, "sample_ternary (item offsets across chunks), B=%ld", (long)B);
 }
 
+// ntru_pipeline_batch: device-only intermediates (r, e), optional outputs, several chunks
+static void pipeline(ntru_engine_t *eng, int N, int q, int64_t B, bool pin) {
+  const int p = 3;
+  Buf<uint16_t> h(N, false), e(B * N, pin), e_want(B * N, false);
+  Buf<int8_t> f(N, false);
+  Buf<uint8_t> fp(N, false), m(B * N, pin), r(B * N, false), value(B * N, pin), value_want(B * N, false), r_back(B * N, pin);
+  for (int i = 0; i < N; i++) { h.p[i] = (uint16_t)(rnd() % q); f.p[i] = (int8_t)((int)(rnd() % 3) - 1); fp.p[i] = (uint8_t)(rnd() % 3); }
+  for (int64_t i = 0; i < B * N; i++) m.p[i] = (uint8_t)(rnd() % 2);
+  uint32_t key[8] = {5, 4, 3, 2, 1, 0, 9, 8};
+  for (int64_t b = 0; b < B; b++) for (int i = 0; i < N; i++) r.p[b * N + i] = (uint8_t)((77 + b) * 7 + i * 3 + 5 + 4 + 4 + 2);   // what the fake sampler draws
+  fake_encrypt(N, q, h.p, r.p, m.p, B, e_want.p, nullptr);
+  std::vector<uint16_t> d1(B * N ? B * N : 1), d2(B * N ? B * N : 1);
+  std::vector<uint8_t> d3(B * N ? B * N : 1);
+  fake_decrypt(N, q, p, f.p, fp.p, e_want.p, B, value_want.p, d1.data(), d2.data(), d3.data());
+  OK(ntru_pipeline_batch(eng, N, q, p, h.p, f.p, fp.p, key, 77, 4, 4, nullptr, m.p, B, r_back.p, e.p, value.p, nullptr));
+  CHECK(!memcmp(r_back.p, r.p, B * N) && !memcmp(e.p, e_want.p, B * N * 2) && !memcmp(value.p, value_want.p, B * N), "pipeline r / e / value, B=%ld pin=%d", (long)B, pin);
+  memset(value.p, 0xEE, B * N);
+  OK(ntru_pipeline_batch(eng, N, q, p, h.p, f.p, fp.p, key, 77, 4, 4, nullptr, m.p, B, nullptr, nullptr, value.p, nullptr));   // only m up, only value down
+  CHECK(!memcmp(value.p, value_want.p, B * N), "lean pipeline, B=%ld", (long)B);
+  OK(ntru_pipeline_batch(eng, N, q, p, h.p, nullptr, nullptr, nullptr, 0, 0, 0, r.p, m.p, B, nullptr, e.p, nullptr, nullptr));   // encrypt only, r given
+  CHECK(!memcmp(e.p, e_want.p, B * N * 2), "encrypt-only pipeline, B=%ld", (long)B);
+  CHECK(ntru_pipeline_batch(eng, N, q, p, h.p, f.p, fp.p, key, 0, 4, 4, r.p, m.p, B, nullptr, e.p, nullptr, nullptr) != 0, "key AND r must be refused");
+  CHECK(ntru_pipeline_batch(eng, N, q, p, h.p, nullptr, nullptr, key, 0, 4, 4, nullptr, m.p, B, nullptr, nullptr, value.p, nullptr) != 0, "value without f, fp must be refused");
+}
+
 static void two_streams_share_the_scratch(ntru_engine_t *eng, int N, int q) {
   hipStream_t sa, sb;
   hipStreamCreateWithFlags(&sa, 0); hipStreamCreateWithFlags(&sb, 0);
@@ -162,6 +187,18 @@ int main() {
     for (int64_t B : {(int64_t)1, (int64_t)(1 << 15) + 9, (int64_t)2 * (1 << 15) + 1}) per_item(eng, N, q, B, pin);
 #endif
   round_trip(eng, N, q, 1000, false, false);
+  for (bool pin : {false, true})
+    for (int64_t B : {(int64_t)1, (int64_t)9001, (int64_t)4 * (1 << 15) + 3}) pipeline(eng, N, q, B, pin);
+  {   // plain device buffers
+    void *d = nullptr;
+    OK(ntru_dev_alloc(eng, 4096, &d));
+    std::vector<uint8_t> a(4096), b(4096);
+    for (auto &x : a) x = (uint8_t)rnd();
+    OK(ntru_dev_upload(eng, d, a.data(), a.size()));
+    OK(ntru_dev_download(eng, b.data(), d, b.size()));
+    CHECK(a == b, "dev_upload / dev_download");
+    OK(ntru_dev_free(eng, d));
+  }
   two_streams_share_the_scratch(eng, N, q);
   {   // two engines from two host threads at once (thread-local error strings, nothing shared between engines)
     std::thread t1([&] { round_trip(eng, N, q, (1 << 15) + 11, false, true); });

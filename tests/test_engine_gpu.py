@@ -1126,3 +1126,51 @@ def test_chunked_result_stores_at_every_base_alignment(eng, N, q):
     finally:
         eng.set_kernel_path(0)
         eng.set_stream(None)
+
+
+@pytest.mark.parametrize("N,q,d,B", [(167, 128, 18, 9001), (821, 4096, 273, 300), (509, 2048, 169, 1)])
+def test_pipeline_batch_equals_oracle_stage_by_stage(eng, N, q, d, B):
+    """ntru_pipeline_batch (sampler -> encryptBits -> decryptBits -> packOutput, device-resident between the stages, chunked through
+    the two-slot host pipeline) against the oracle's replay of every stage; every combination of optional outputs."""
+    rng = np.random.default_rng(N + B)
+    p = 3
+    h = rng.integers(0, q, N); fp = rng.integers(0, p, N)
+    f = ternary_rows(rng, 1, N, d, d - 1, two=-1)[0]
+    m = rng.integers(0, 2, (B, N))
+    key = rng.integers(0, 2 ** 32, 8, dtype=np.uint64).astype(np.uint32)
+    first = (1 << 33) + 12345
+    r_o = orc.sample_ternary_batch(N, d, d, p - 1, key, first, B)
+    e_o, _ = orc.encrypt_batch(N, q, h, r_o, m)
+    v_o = orc.decrypt_batch(N, q, p, f, fp, e_o)[0]
+    out = eng.pipeline_batch(N, q, p, h, m, f=f, fp=fp, key=key, first_item=first, n1=d, n2=d,
+                             want_r=True, want_e=True, want_value=True, want_packed=True)
+    assert np.array_equal(out["r"], r_o) and np.array_equal(out["e"], e_o) and np.array_equal(out["value"], v_o)
+    assert np.array_equal(out["packed"], orc.pack_batch(p - 1, N, v_o.astype(np.uint16)))
+    lean = eng.pipeline_batch(N, q, p, h, m, f=f, fp=fp, key=key, first_item=first, n1=d, n2=d, want_value=True)
+    assert list(lean) == ["value"] and np.array_equal(lean["value"], v_o)
+    enc = eng.pipeline_batch(N, q, p, h, m, r=r_o, want_packed=True)                       # encrypt only, r given, packed ciphertext
+    assert list(enc) == ["packed"] and np.array_equal(enc["packed"], orc.pack_batch(q - 1, N, e_o))
+    for bad in (dict(key=key, r=r_o, want_e=True), dict(want_e=True), dict(key=key, want_value=True), dict(key=key)):
+        with pytest.raises(pkg.EngineError):
+            eng.pipeline_batch(N, q, p, h, m, n1=d, n2=d, **bad)
+
+
+def test_plain_device_buffers_round_trip_and_feed_the_dev_entry_points(eng):
+    N, q, p, B, d = 167, 128, 3, 77, 18
+    rng = np.random.default_rng(5)
+    h = rng.integers(0, q, N).astype(np.uint16); r = ternary_rows(rng, B, N, d, d).astype(np.uint8); m = rng.integers(0, 2, (B, N)).astype(np.uint8)
+    dh, dr, dm, de = eng.dev_alloc(2 * N), eng.dev_alloc(B * N), eng.dev_alloc(B * N), eng.dev_alloc(2 * B * N)
+    try:
+        eng.dev_upload(dh, h); eng.dev_upload(dr, r); eng.dev_upload(dm, m)
+        assert np.array_equal(eng.dev_download(dr, (B, N), np.uint8), r)
+        eng.encrypt_batch_dev(N, q, dh, dr, dm, B, de)
+        e = eng.dev_download(de, (B, N), np.uint16)                     # waits for the engine's stream
+        assert np.array_equal(e, orc.encrypt_batch(N, q, h, r, m)[0])
+        dp = eng.dev_alloc(B * eng.pack_params(2, N)["outputSize"] * 32)
+        eng.pack_bytes_batch_dev(2, N, dr, B, dp)
+        got = eng.dev_download(dp, (B, eng.pack_params(2, N)["outputSize"], 4), np.uint64)
+        assert np.array_equal(got, orc.pack_batch(2, N, r.astype(np.uint16)))
+        eng.dev_free(dp)
+    finally:
+        for x in (dh, dr, dm, de):
+            eng.dev_free(x)

@@ -61,6 +61,27 @@ const pinned = roundTrips(n => NTRU.allocUint8(n), n => NTRU.allocUint16(n));
 const pageable = roundTrips(n => new Uint8Array(n), n => new Uint16Array(n));
 if (pinned.checksum !== pageable.checksum) throw new Error('pinned and pageable paths disagree');
 
+// Device-resident pipeline (ntru.pipeline): only m goes up, r is drawn on the GPU, e stays there, only value (or its packed form)
+// comes down.  PCIe carries 2N bytes per round trip (N up, N down -- the two directions are separate links: full duplex).
+function pipelineRate(opts, bytesUp, bytesDown) {
+  const mPin = NTRU.allocUint8(B * N); mPin.set(mSrc);
+  const out = {};
+  if (!opts.pack) out.value = NTRU.allocUint8(B * N);
+  const chacha = Uint32Array.from([1, 2, 3, 4, 5, 6, 7, 8]);
+  const run = () => ntru.pipeline({ m: mPin, B, sampleR: { key: chacha, firstItem: 0 }, decrypt: true, out, ...opts });
+  let res = run();
+  if (opts.pack) out.packed = res.packed;
+  const t = [];
+  for (let i = 0; i < iters; i++) { const t0 = now(); res = run(); t.push(now() - t0); }
+  const ms = t.slice().sort((x, y) => x - y)[t.length >> 1];
+  const up = bytesUp * B / (ms * 1e-3) / 1e9, down = bytesDown * B / (ms * 1e-3) / 1e9;
+  return { ms_per_batch: ms, round_trips_per_s: B / (ms * 1e-3), pcie_bytes_up_per_round_trip: bytesUp, pcie_bytes_down_per_round_trip: bytesDown,
+    up_GBs: up, down_GBs: down, frac_of_pcie_one_direction: Math.max(up, down) / PCIE_GBS,
+    checksum: opts.pack ? Number(res.packed[res.packed.length - 4] & 0xffffn) : res.value.reduce((s, x) => (s + x) >>> 0, 0) };
+}
+const pipeValue = pipelineRate({}, N, N);
+const pipePacked = pipelineRate({ pack: true }, N, 32 * Math.max(3, Math.ceil(N / Math.floor(252 / 2))));
+
 // single calls through the reference's own API (plain Arrays in, witness objects out)
 const lat = (fn, n) => { const t = []; for (let i = 0; i < n; i++) { const t0 = now(); fn(); t.push(now() - t0); } t.sort((a, b) => a - b); return { median_ms: t[n >> 1], p90_ms: t[Math.floor(n * 0.9)], min_ms: t[0] }; };
 const mBits = Array.from(mSrc.subarray(0, N));
@@ -74,6 +95,9 @@ console.log(JSON.stringify({
   N, q: ntru.q, batch: B, iters, devices: devices || 'single', host_cpus: cpus().length, pcie_roof_GBs_one_direction: PCIE_GBS,
   bound_round_trips_per_s_at_14N_over_pcie: PCIE_GBS * 1e9 / (14 * N),
   pinned, pageable,
+  pipeline_value_only: { what: 'ntru.pipeline({sampleR, decrypt}): sampler -> encryptBits -> decryptBits on the GPU, m up, value down (page-locked arrays)',
+    bound_round_trips_per_s_at_N_each_way: PCIE_GBS * 1e9 / N, ...pipeValue },
+  pipeline_packed_value: { what: 'the same with pack: true: packOutput(2, N, value) comes down instead of value', ...pipePacked },
   single_call_latency: { encryptBits: encLat, decryptBits: decLat, verifyKeysInputs: verLat,
     note: 'includes sampling r in JS (N-1 CSPRNG draws), Array <-> TypedArray conversion, one H2D, one launch, one D2H' },
 }));
