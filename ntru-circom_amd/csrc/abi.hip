@@ -104,6 +104,7 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
   eng->last_kernel[0] = 0;
   eng->n_occ = 0;
   eng->cur_scratch = &eng->scratch_dev;
+  eng->st_up = eng->st_comp = eng->st_down = nullptr;
   eng->scratch_stream = nullptr;
   eng->scratch_event = nullptr;
   eng->scratch_used = false;
@@ -119,8 +120,10 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
 extern "C" void ntru_engine_destroy(ntru_engine_t *eng) {
   if (!eng) return;
   (void)hipSetDevice(eng->device);
+  for (hipStream_t st : {eng->st_up, eng->st_comp, eng->st_down})
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   for (HostSlot &s : eng->slot) {
-    if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+    for (hipEvent_t ev : {s.up_done, s.comp_done, s.down_done}) if (ev) (void)hipEventDestroy(ev);
     if (s.pinned.p) (void)hipHostFree(s.pinned.p);
     if (s.dev.p) (void)hipFree(s.dev.p);
     if (s.scratch.p) (void)hipFree(s.scratch.p);

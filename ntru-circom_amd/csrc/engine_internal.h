@@ -39,16 +39,21 @@ struct GrowBuf {
   size_t cap = 0;
 };
 
-// Host-path staging (ntru_host.hip): two slots, each with a pinned host arena, a device arena, its own stream and an
-// event that marks "slot free again".  Chunk k uses slot k & 1, so the H2D copy of chunk k+1 and the D2H copy of
-// chunk k-1 run while chunk k computes.
+// Host-path staging (ntru_host.hip): a chunk moves through three STAGES, each with its own engine-owned stream -- upload (H2D),
+// compute (the *_dev launches), download (D2H) -- chained by events, so that at any time ONE upload, one set of kernels and ONE
+// download are in flight: chunk k+1 goes up while chunk k computes and chunk k-1 comes down (PCIe is full duplex: 57 GB/s one
+// way, 47 + 47 GB/s both ways on this box, profiles/r03_pcie_duplex.json).  Chunk k owns buffer set k % 3 (pinned host arena +
+// device arena + scratch) until its download has finished.  [Round 2 ran each chunk on the stream of one of TWO slots: the two
+// slots fell into lock-step -- both uploading, then both computing, then both downloading -- and the two directions never
+// overlapped: 56 GB/s in total.]
 struct HostSlot {
-  hipStream_t stream = nullptr;
   GrowBuf pinned;           // hipHostMalloc
   GrowBuf dev;              // hipMalloc
-  GrowBuf scratch;          // temporaries of a *_dev call issued on this slot's stream
-  bool busy = false;        // work enqueued on `stream` that has not been waited for yet
+  GrowBuf scratch;          // temporaries of a *_dev call of the chunk that owns this set
+  hipEvent_t up_done = nullptr, comp_done = nullptr, down_done = nullptr;
+  bool busy = false;        // a chunk has been enqueued with this set and its download has not been waited for yet
 };
+constexpr int NTRU_HOST_SLOTS = 3;
 
 struct ntru_engine {
   int device;
@@ -58,7 +63,8 @@ struct ntru_engine {
                             // workgroups per CU, 5 matrix cores with the lock-step decrypt; 6-9 only in -DNTRU_EXPERIMENTS builds
   int max_blocks_per_cu;    // NTRU_MAX_BLOCKS_PER_CU read once at creation (tuning experiments); 0 = no cap
   char last_kernel[64];     // name of the kernel the last *_dev call launched (reporting only)
-  HostSlot slot[2];
+  HostSlot slot[NTRU_HOST_SLOTS];
+  hipStream_t st_up, st_comp, st_down;   // the three stage streams of the host path (created at first use)
   GrowBuf shared_dev;       // shared key rows of the host path (h, f, fp)
   GrowBuf scratch_dev;      // temporaries of *_dev calls (Newton rounds, generic family) on the caller's stream
   hipStream_t scratch_stream;   // the stream whose work used scratch_dev last, and an event recorded behind that work: a call on

@@ -2,15 +2,15 @@
 //
 // The reference keeps everything in JS arrays (index.js:87-197); a host binding therefore hands the engine HOST buffers.
 // This file moves them through the GPU as a pipeline instead of "allocate, copy, run, copy, free" per call:
-//   * the engine owns two SLOTS, each with its own HIP stream, a pinned host arena and a device arena that only grow
-//     (no hipMalloc / hipFree / hipHostMalloc on the steady-state path);
-//   * a batch is cut into chunks; chunk k runs on slot k & 1: H2D copies, the *_dev kernel launch and the D2H copies are
-//     enqueued on the slot's stream, so the upload of chunk k+1 and the download of chunk k-1 overlap the kernels of
-//     chunk k and each other (PCIe is full duplex), and the CPU-side staging copies of one slot overlap the DMA of the other;
+//   * a batch is cut into chunks; a chunk passes three stages -- upload, compute, download -- each on its own engine-owned stream,
+//     chained by events: while chunk k computes, chunk k+1 is uploaded and chunk k-1 downloaded, one copy per direction at a time
+//     (PCIe is full duplex), and the CPU-side staging copies of the next chunk overlap all three;
+//   * chunk k owns buffer set k % 3 (pinned host arena, device arena, scratch: they only grow -- no hipMalloc / hipFree /
+//     hipHostMalloc on the steady-state path) until its download is done;
 //   * buffers the caller allocated with ntru_host_alloc (pinned; the addon exposes them as TypedArrays) are DMA'd in place;
-//     ordinary pageable memory is staged through the slot's pinned arena with a multi-threaded memcpy.
+//     ordinary pageable memory is staged through the set's pinned arena with a multi-threaded memcpy.
 // Shared key rows (h, f, fp) travel with every chunk (<= 4N bytes), which keeps a single-item call at one H2D, one launch
-// and one D2H on one stream with a single synchronisation.
+// and one D2H with a single host synchronisation.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -68,7 +68,7 @@ struct Pipeline {
   ntru_engine *eng;
   HArr arr[MAX_ARR];
   int n = 0;
-  std::vector<Pending> pending[2];
+  std::vector<Pending> pending[NTRU_HOST_SLOTS];
   hipStream_t saved_stream;
   GrowBuf *saved_scratch;
 
@@ -88,10 +88,11 @@ struct Pipeline {
     return n++;
   }
 
+  // Waits until the chunk that owns buffer set s has been downloaded, then hands its staged outputs to the caller's arrays.
   int drain(int s) {
     HostSlot &sl = eng->slot[s];
     if (!sl.busy) return NTRU_OK;
-    HIP_TRY(hipStreamSynchronize(sl.stream));
+    HIP_TRY(hipEventSynchronize(sl.down_done));
     sl.busy = false;
     for (const Pending &p : pending[s]) big_memcpy(p.dst, p.pin, p.bytes);
     pending[s].clear();
@@ -112,22 +113,28 @@ struct Pipeline {
       a.dev_off = dev_bytes; dev_bytes += up(bytes);
       if (!a.direct && !a.temp) { a.pin_off = pin_bytes; pin_bytes += up(bytes); }
     }
-    for (int s = 0; s < 2; s++) {
+    for (hipStream_t *st : {&eng->st_up, &eng->st_comp, &eng->st_down})
+      if (!*st) HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    const int64_t nchunks = (B + C - 1) / C;
+    // A single chunk (every call of the reference's own API) has nothing to overlap with: its three stages go onto ONE stream, in
+    // order, without events between them.
+    const bool single = nchunks == 1;
+    const hipStream_t s_up = single ? eng->st_comp : eng->st_up, s_down = single ? eng->st_comp : eng->st_down;
+    for (int s = 0; s < NTRU_HOST_SLOTS && s < nchunks; s++) {          // a single chunk touches one buffer set only
       HostSlot &sl = eng->slot[s];
-      if (!sl.stream) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-      if (s == 1 && B <= C) break;                      // a single chunk never touches the second slot
+      for (hipEvent_t *ev : {&sl.up_done, &sl.comp_done, &sl.down_done})
+        if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
       if (int rc = ntru_grow_dev(&sl.dev, dev_bytes)) return rc;
       if (int rc = ntru_grow_pinned(&sl.pinned, pin_bytes)) return rc;
     }
     int rc = NTRU_OK;
     int64_t k = 0;
     for (int64_t o = 0; o < B && rc == NTRU_OK; o += C, k++) {
-      const int s = (int)(k & 1);
+      const int s = (int)(k % NTRU_HOST_SLOTS);
       const int64_t cnt = std::min(C, B - o);
       HostSlot &sl = eng->slot[s];
-      if ((rc = drain(s))) break;
-      eng->stream = sl.stream;
-      eng->cur_scratch = &sl.scratch;
+      if ((rc = drain(s))) break;                        // chunk k - 3 is out of this buffer set
+      // ---- stage 1: upload (staging copies on this thread, DMA on the upload stream)
       void *dev[MAX_ARR];
       for (int i = 0; i < n && rc == NTRU_OK; i++) {
         HArr &a = arr[i];
@@ -140,10 +147,18 @@ struct Pipeline {
           big_memcpy(pin, from, bytes);
           from = pin;
         }
-        if (hipMemcpyAsync(dev[i], from, bytes, hipMemcpyHostToDevice, sl.stream) != hipSuccess)
+        if (hipMemcpyAsync(dev[i], from, bytes, hipMemcpyHostToDevice, s_up) != hipSuccess)
           rc = ntru_fail(NTRU_ERR_HIP, "hipMemcpyAsync (host to device) failed");
       }
+      if (!single && rc == NTRU_OK && hipEventRecord(sl.up_done, s_up) != hipSuccess) rc = ntru_fail(NTRU_ERR_HIP, "hipEventRecord failed");
+      // ---- stage 2: compute, behind this chunk's upload
+      if (!single && rc == NTRU_OK && hipStreamWaitEvent(eng->st_comp, sl.up_done, 0) != hipSuccess) rc = ntru_fail(NTRU_ERR_HIP, "hipStreamWaitEvent failed");
+      eng->stream = eng->st_comp;
+      eng->cur_scratch = &sl.scratch;
       if (rc == NTRU_OK) rc = launch(o, cnt, dev);
+      if (!single && rc == NTRU_OK && hipEventRecord(sl.comp_done, eng->st_comp) != hipSuccess) rc = ntru_fail(NTRU_ERR_HIP, "hipEventRecord failed");
+      // ---- stage 3: download, behind this chunk's kernels
+      if (!single && rc == NTRU_OK && hipStreamWaitEvent(s_down, sl.comp_done, 0) != hipSuccess) rc = ntru_fail(NTRU_ERR_HIP, "hipStreamWaitEvent failed");
       for (int i = 0; i < n && rc == NTRU_OK; i++) {
         HArr &a = arr[i];
         if (!a.dst) continue;
@@ -154,18 +169,22 @@ struct Pipeline {
           pending[s].push_back({to, pin, bytes});
           to = pin;
         }
-        if (hipMemcpyAsync(to, dev[i], bytes, hipMemcpyDeviceToHost, sl.stream) != hipSuccess)
+        if (hipMemcpyAsync(to, dev[i], bytes, hipMemcpyDeviceToHost, s_down) != hipSuccess)
           rc = ntru_fail(NTRU_ERR_HIP, "hipMemcpyAsync (device to host) failed");
       }
-      sl.busy = true;
+      // (recorded even after a failure: whatever was enqueued for this set must be waited for before the set is reused)
+      if (hipEventRecord(sl.down_done, s_down) == hipSuccess) sl.busy = true;
+      else if (rc == NTRU_OK) rc = ntru_fail(NTRU_ERR_HIP, "hipEventRecord failed");
     }
-    // results of the last two chunks, oldest first; on failure still wait so nothing is left in flight
-    const int first = (int)(k & 1);
+    // results of the chunks still in flight, oldest first; on failure still wait so nothing is left in flight
     const std::string err = rc ? std::string(ntru_last_error()) : std::string();
-    for (int t = 0; t < 2; t++) {
-      const int s = (first + t) & 1;
-      if (rc) { HostSlot &sl = eng->slot[s]; if (sl.stream && sl.busy) { (void)hipStreamSynchronize(sl.stream); sl.busy = false; } pending[s].clear(); }
-      else rc = drain(s);
+    for (int t = 0; t < NTRU_HOST_SLOTS; t++) {
+      const int s = (int)((k + t) % NTRU_HOST_SLOTS);
+      if (rc) {
+        HostSlot &sl = eng->slot[s];
+        if (sl.busy) { (void)hipStreamSynchronize(eng->st_up); (void)hipStreamSynchronize(eng->st_comp); (void)hipStreamSynchronize(eng->st_down); sl.busy = false; }
+        pending[s].clear();
+      } else rc = drain(s);
     }
     if (!err.empty()) ntru_fail(rc, err);
     return rc;

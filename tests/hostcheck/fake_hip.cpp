@@ -112,6 +112,12 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
   S(s)->push([=] { { std::lock_guard<std::mutex> l(e->mu); if (e->done < gen) e->done = gen; } e->cv.notify_all(); });
   return hipSuccess;
 }
+hipError_t hipEventSynchronize(hipEvent_t e) {
+  std::unique_lock<std::mutex> l(e->mu);
+  const unsigned long gen = e->recorded;
+  e->cv.wait(l, [=] { return e->done >= gen; });
+  return hipSuccess;
+}
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
   unsigned long gen;
   { std::lock_guard<std::mutex> l(e->mu); gen = e->recorded; }

@@ -41,6 +41,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipFuncSetAttribute(const void *fn, hipFuncAttribute a, int v);
 hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *fn, int threads, size_t lds);
 
