@@ -130,6 +130,11 @@ static __device__ __forceinline__ void pi_product(const unsigned char *pa0, cons
   };
 #pragma unroll
   for (int i = 0; i < 16; i++) { H0[i] = 0; H1[i] = 0; }   // NT = 1 has no d < 0 step; otherwise folded into the first step below
+#if NTRU_ABLATE & 2                                                       // timing only: no matrix loops
+  NT = 1;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { L1[i] = 0; }
+#endif
   Ops A, Bq, C;
   int d = -(NT - 1);
   ld(d, A); ld(d + 1, Bq);
@@ -176,6 +181,11 @@ static __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+#if NTRU_ABLATE & 4                                                       // timing only: operands made up in registers
+#define PI_LOAD(NCH, src, pos) fake_raw<NCH>((int)(pos))
+#else
+#define PI_LOAD(NCH, src, pos) load_raw<NCH>(src, pos, 0)
+#endif
 __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_verify_keys_m(
     PGeom g, u32 q, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
     const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
@@ -196,17 +206,28 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
   const v4i cmask = col_mask16(16 * lane, N);                              // bytes of this lane's chunk that are below N
   const int kl = 128 * hh + r;                                             // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + kl
   wave_lds_fence();
-  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
+  const long item_step = (long)gridDim.x * PI_WAVES;
+  // The first operand rows of an item (fq, f: product 1) are requested at the end of the PREVIOUS item's last epilogue: a timing-only build
+  // with made-up operands was 14 % faster (profiles/r03_ablation_verify_keys.txt), i.e. that much of an item was the wave waiting
+  // for its first round trip to HBM.  They stay in these registers across the loop back-edge.
+  RawChunks<2> r_fq;
+  RawChunks<1> r_f;
+  {
+    const long item0 = (long)blockIdx.x * PI_WAVES + wave;
+    if (item0 < B) {
+      const long row = item0 * N, left = (B - item0) * N;
+      const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left);
+      r_fq = PI_LOAD(2, s_fq, s_fq.a0 + 32 * lane); r_f = PI_LOAD(1, s_f, s_f.a0 + 16 * lane);
+    }
+  }
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
     const long row = item * N, left = (B - item) * N;
     u32 fl = 0;
-    // Every operand row is requested one product ahead of its use (rows at any alignment: aligned chunks + a wave-uniform
-    // byte shift at use): fq, f and fp at the top, g and fq again (an L2 hit) before product 2, h before product 3.  A fetch
+    // Every operand row is requested ahead of its use (rows at any alignment: aligned chunks + a wave-uniform byte shift at
+    // use): fq, f and fp during the previous item, g and fq again (an L2 hit) before product 2, h before product 3.  A fetch
     // right where each product needs it left the wave idle for a round trip to HBM three times per item.
     const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_g = aligned_src(gg + row, left),
                      s_fp = aligned_src(fp + row, left);
-    RawChunks<2> r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * lane, 0);
-    const RawChunks<1> r_f = load_raw<1>(s_f, s_f.a0 + 16 * lane, 0);
-    const RawChunks<1> r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * lane, 0);
     auto bytes_of = [&](const RawChunks<1> &rw, const AlignedSrc &sr) {
       v4i v[1];
       shift_raw<1>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     }
     v16i L0, L1, H0, H1;
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    const RawChunks<1> r_fp = PI_LOAD(1, s_fp, s_fp.a0 + 16 * lane);     // product 2's operand: it has product 1's epilogue to arrive
     {
       // stores through one-row descriptors: index k = 32 kb + r is a per-lane offset (128 hh + r) plus a compile-time
       // one per register, indices >= N fall outside the descriptor and are dropped -- no address arithmetic per store
@@ -256,8 +278,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
         const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
         const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
         const u32 rv = (u32)(lo + hi) & (q - 1);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        if (1 ABL_STORE(lo)) {
+          __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+          __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        }
         nz_hi |= k >= 1 && k < N && rv != 0;
         first_not_one |= k == 0 && rv != 1;
       }
@@ -273,8 +297,8 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       if (stager) *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = u.v;
     }
     wave_lds_fence();
-    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * lane, 0);                       // for product 3, in flight during product 2
-    const RawChunks<1> r_g = load_raw<1>(s_g, s_g.a0 + 16 * lane, 0);
+    r_fq = PI_LOAD(2, s_fq, s_fq.a0 + 32 * lane);                           // for product 3, in flight during product 2
+    const RawChunks<1> r_g = PI_LOAD(1, s_g, s_g.a0 + 16 * lane);
     pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
@@ -285,8 +309,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
         // |L + H|, |H| <= 127 N (f is an int8, fp < 3): a multiple of 3 above that keeps the dividend non-negative
         const u32 x = (u32)(L0[i] + H0[i] + 3 * 131072), y = (u32)(3 * 131072 - H0[i]);
         const u32 rv = x % 3u, qv = y % 3u;
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
+        if (1 ABL_STORE(L0[i])) {
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
+        }
         nz_hi |= k >= 1 && k < N && rv != 0;
         first_not_one |= k == 0 && rv != 1;
       }
@@ -310,8 +336,8 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     // h is requested before the product whose remainder it is compared with, as a row chunk (16 coefficients per lane);
     // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
     const AlignedSrc s_h = aligned_src(h + row, 2 * left);
-    const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * lane, 0);
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    const RawChunks<2> r_h = PI_LOAD(2, s_h, s_h.a0 + 32 * lane);          // (after the loop: its 9 registers are the loop's operand sets)
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
       u16 *remx = (u16 *)nat;
@@ -320,9 +346,16 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
         const u32 rv = (u32)(lo + hi) & (q - 1);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        if (1 ABL_STORE(lo)) {
+          __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+          __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        }
         remx[ko + kl] = (u16)rv;                                          // ko + kl < 32 NT <= (3 N + 64) / 2
+      }
+      if (item + item_step < B) {                         // the next item's first rows (product 1's operands): in flight from here on --
+        const long nrow = (item + item_step) * N, nleft = (B - item - item_step) * N;     // the accumulators are dead, the registers free
+        const AlignedSrc n_fq = aligned_src(fq + nrow, 2 * nleft), n_f = aligned_src(f + nrow, nleft);
+        r_fq = PI_LOAD(2, n_fq, n_fq.a0 + 32 * lane); r_f = PI_LOAD(1, n_f, n_f.a0 + 16 * lane);
       }
       wave_lds_fence();
       // index.js:165: h[k] must equal the remainder for every k below h's trimmed length
