@@ -42,7 +42,7 @@ def short(name):
     if m.group(2) is None:
         return fam
     args = [x.strip() for x in m.group(2).split(",")]
-    if args[-1] in ("true", "false"):                      # k_decrypt_s<K, ME, D8>
+    if fam == "k_decrypt_s" and args[-1] in ("true", "false"):     # k_decrypt_s<K, ME, D8>: the engine reports "k_decrypt_s+dot8<K,ME>"
         fam += "+dot8" if args.pop() == "true" else ""
     return "%s<%s>" % (fam, ",".join(args))
 
