@@ -47,3 +47,8 @@ def set_path_or_skip(eng, path):
     if path >= 6 and not has_experiments(eng):
         pytest.skip("kernel path %d needs the -DNTRU_EXPERIMENTS library (make experiments + NTRU_ENGINE_LIB)" % path)
     eng.set_kernel_path(path)
+
+
+# Kernel paths 6-9 are compiled only into lib/libntru_engine_experiments.so: they join the parametrisations when that is the library
+# under test (NTRU_ENGINE_LIB=.../libntru_engine_experiments.so), and are not collected otherwise.
+EXPERIMENT_PATHS = [6, 7, 8, 9] if "experiments" in os.path.basename(os.environ.get("NTRU_ENGINE_LIB", "")) else []

@@ -19,7 +19,7 @@ CONFIGS = [  # (N, q, d) -- the BASELINE.json parameter sets first
 ]
 
 
-from conftest import has_experiments, set_path_or_skip
+from conftest import EXPERIMENT_PATHS, has_experiments, set_path_or_skip
 
 
 @pytest.fixture(scope="module")
@@ -255,7 +255,7 @@ def test_kernel_families_agree(eng):
 @pytest.mark.parametrize("N,q,d", [(17, 32, 2), (31, 64, 5), (32, 128, 6), (33, 32, 7), (64, 8192, 20), (65, 4096, 21),
                                    (167, 128, 18), (509, 2048, 169), (701, 8192, 233), (821, 4096, 273),
                                    (1021, 4096, 300), (1022, 2048, 300), (1023, 8192, 300), (1024, 8192, 300)])
-@pytest.mark.parametrize("path", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("path", [4, 5] + EXPERIMENT_PATHS)
 def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
     """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step decrypt; 6-9: the variants of the experiments build), including sizes the
     automatic choice leaves to other families, batches that do not fill a 32-row block, and h at the corners of the
@@ -296,7 +296,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
         eng.set_kernel_path(0)
 
 
-@pytest.mark.parametrize("path", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("path", [4, 5] + EXPERIMENT_PATHS)
 def test_matrix_core_path_random_parameter_sweep(eng, path):
     """Differential sweep: 40 random (N, q, B) with N in [2, 1024] (odd and even, around the 32-tile boundaries), q any
     power of two up to 8192, ragged B; matrix-core family (forced) against the CPU oracle, all outputs."""
@@ -362,7 +362,7 @@ def test_role_split_kernels_many_row_blocks_per_workgroup(eng, N, q, B):
             assert np.array_equal(g_, w_), (path, name)
 
 
-@pytest.mark.parametrize("path", [0, 8])                   # 8: decrypt's rows arrive by direct-to-LDS loads (dword-aligned pieces + a shift)
+@pytest.mark.parametrize("path", [0] + [x for x in EXPERIMENT_PATHS if x == 8])   # 8: decrypt's rows arrive by direct-to-LDS loads (dword-aligned pieces + a shift)
 @pytest.mark.parametrize("N,q", [(821, 4096), (167, 128), (701, 8192), (1021, 2048), (1022, 4096), (1023, 8192), (1024, 1024)])   # N >= 1022: a row + its byte phase exceeds one 1024-byte direct-to-LDS instruction
 def test_device_pointers_at_any_alignment(eng, N, q, path):
     """The *_dev entry points take any pointer: the matrix-core kernels read rows through aligned chunks + shifts and
@@ -413,7 +413,7 @@ def test_device_pointers_at_any_alignment(eng, N, q, path):
 
 @pytest.mark.parametrize("N,q,ld", [(821, 4096, 832), (821, 4096, 822), (821, 4096, 1024), (167, 128, 192), (701, 8192, 704),
                                     (509, 2048, 509), (64, 32, 80), (33, 8192, 47)])
-@pytest.mark.parametrize("path", [0, 8])
+@pytest.mark.parametrize("path", [0] + [x for x in EXPERIMENT_PATHS if x == 8])
 def test_pitched_rows_equal_oracle(eng, N, q, ld, path):
     """ntru_*_batch_pitched_dev: rows at a pitch of ld >= N elements.  Pad elements of the inputs hold garbage and must
     not reach any result; pad elements of the outputs must stay untouched; a ragged batch (B % 32 != 0) must not write
@@ -1083,7 +1083,7 @@ def test_multi_device_host_api_shards_equal_oracle():
         pkg.MultiEngine([0, 99])                                               # no such device
 
 
-@pytest.mark.parametrize("N,q", [(821, 4096), (701, 8192), (509, 2048), (167, 128), (33, 64), (96, 256)])
+@pytest.mark.parametrize("N,q", [(821, 4096), (701, 8192), (509, 2048), (167, 128), (33, 64), (96, 256)] if EXPERIMENT_PATHS else [])
 def test_chunked_result_stores_at_every_base_alignment(eng, N, q):
     """Kernel path 7 (k_encrypt_mc): results leave through per-wave LDS chunks as aligned 16-byte pieces plus 2-byte edges,
     so the geometry depends on the byte phase of every row segment.  Output arrays at all eight 2-byte phases of a 16-byte
