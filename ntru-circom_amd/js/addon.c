@@ -580,11 +580,12 @@ static napi_value PackBatchDev(napi_env env, napi_callback_info info) {
 typedef struct {
   napi_async_work work;
   napi_deferred deferred;
-  napi_ref keep[8];
+  napi_ref keep[12];
   int n_keep;
-  int kind;                       /* 0 encrypt, 1 decrypt */
-  int N, q, p, B;
-  void *ptr[8];
+  int kind;                       /* 0 encrypt, 1 decrypt, 2 pipeline */
+  int N, q, p, B, n1, n2;
+  uint64_t first;
+  void *ptr[12];
   int rc;
   char err[400];
 } AsyncJob;
@@ -598,6 +599,9 @@ static void async_execute(napi_env env, void *data) {
     if (j->kind == 0)
       j->rc = g_multi ? ntru_multi_encrypt_batch(g_multi, j->N, j->q, j->ptr[0], j->ptr[1], j->ptr[2], j->B, j->ptr[3], j->ptr[4])
                       : ntru_encrypt_batch(g_engine, j->N, j->q, j->ptr[0], j->ptr[1], j->ptr[2], j->B, j->ptr[3], j->ptr[4]);
+    else if (j->kind == 2)
+      j->rc = ntru_pipeline_batch(g_engine, j->N, j->q, j->p, j->ptr[0], j->ptr[1], j->ptr[2], j->ptr[3], j->first, j->n1, j->n2, j->ptr[4],
+                                  j->ptr[5], j->B, j->ptr[6], j->ptr[7], j->ptr[8], j->ptr[9]);
     else
       j->rc = g_multi ? ntru_multi_decrypt_batch(g_multi, j->N, j->q, j->p, j->ptr[0], j->ptr[1], j->ptr[2], j->B, j->ptr[3],
                                                  j->ptr[4], j->ptr[5], j->ptr[6])
@@ -682,6 +686,35 @@ static napi_value DecryptBatchAsync(napi_env env, napi_callback_info info) {
   return async_start(env, j, hold, 7, "ntru.decryptBatchAsync");
 }
 
+/* pipelineBatchAsync(...the arguments of pipelineBatch...) -> Promise<undefined> */
+static napi_value PipelineBatchAsync(napi_env env, napi_callback_info info) {
+  ARGS(17)
+  int32_t N, q, p, n1, n2, B; double first; void *h, *f, *fp, *key, *r, *m, *r_out, *e, *value, *packed;
+  if (!get_i32(env, argv[0], &N) || !get_i32(env, argv[1], &q) || !get_i32(env, argv[2], &p) ||
+      napi_get_value_double(env, argv[7], &first) != napi_ok || !get_i32(env, argv[8], &n1) || !get_i32(env, argv[9], &n2) ||
+      !get_i32(env, argv[12], &B) || N < 1 || B < 0 || first < 0 || first > 9007199254740991.0) BAD_ARGS();
+  const size_t n = (size_t)N * (size_t)B;
+  if (!get_buf(env, argv[3], napi_uint16_array, (size_t)N, 0, &h) || !get_buf(env, argv[4], napi_int8_array, (size_t)N, 1, &f) ||
+      !get_buf(env, argv[5], napi_uint8_array, (size_t)N, 1, &fp) || !get_buf(env, argv[6], napi_uint32_array, 8, 1, &key) ||
+      !get_buf(env, argv[10], napi_uint8_array, n, 1, &r) || !get_buf(env, argv[11], napi_uint8_array, n, 0, &m) ||
+      !get_buf(env, argv[13], napi_uint8_array, n, 1, &r_out) || !get_buf(env, argv[14], napi_uint16_array, n, 1, &e) ||
+      !get_buf(env, argv[15], napi_uint8_array, n, 1, &value)) BAD_ARGS();
+  size_t need_packed = 0;
+  {
+    int bits, per, al, os;
+    if (ntru_pack_params(f ? p - 1 : q - 1, N, &bits, &per, &al, &os) == 0) need_packed = (size_t)B * (size_t)os * 4;
+  }
+  if (!get_buf(env, argv[16], napi_biguint64_array, need_packed, 1, &packed)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
+  if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  j->kind = 2; j->N = N; j->q = q; j->p = p; j->B = B; j->n1 = n1; j->n2 = n2; j->first = (uint64_t)first;
+  void *ptrs[10] = {h, f, fp, key, r, m, r_out, e, value, packed};
+  memcpy(j->ptr, ptrs, sizeof ptrs);
+  napi_value hold[10] = {argv[3], argv[4], argv[5], argv[6], argv[10], argv[11], argv[13], argv[14], argv[15], argv[16]};
+  return async_start(env, j, hold, 10, "ntru.pipelineAsync");
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
     {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
@@ -705,6 +738,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"genericCapacity", NULL, GenericCapacity, NULL, NULL, NULL, napi_default, NULL},
     {"genericOp", NULL, GenericOp, NULL, NULL, NULL, napi_default, NULL},
     {"pipelineBatch", NULL, PipelineBatch, NULL, NULL, NULL, napi_default, NULL},
+    {"pipelineBatchAsync", NULL, PipelineBatchAsync, NULL, NULL, NULL, napi_default, NULL},
     {"devAlloc", NULL, DevAlloc, NULL, NULL, NULL, napi_default, NULL},
     {"devFree", NULL, DevFree, NULL, NULL, NULL, napi_default, NULL},
     {"devUpload", NULL, DevUpload, NULL, NULL, NULL, napi_default, NULL},

@@ -465,7 +465,10 @@ export default class NTRU {
   //   want: { r, e, value }                         which plain arrays come back (default: e without decrypt, value with it, nothing
   //                                                 but `packed` when pack is set)
   // m: Uint8Array[B*N].  Arrays in `out` (e.g. from NTRU.allocUint8, page-locked) are filled in place.
-  pipeline({ m, B, sampleR = null, r = null, decrypt = false, pack = false, want = null, out = {} }) {
+  pipeline(opts) { return this._pipeline(opts, false); }
+  // The same on a libuv worker thread: a Promise of the same result object; the arrays must be left alone until it settles.
+  pipelineAsync(opts) { return this._pipeline(opts, true); }
+  _pipeline({ m, B, sampleR = null, r = null, decrypt = false, pack = false, want = null, out = {} }, asynchronous) {
     const { N, p, q, dr } = this;
     if (!(m instanceof Uint8Array) || m.length < B * N) throw new TypeError('pipeline: m must be a Uint8Array of B*N plaintext coefficients');
     if ((sampleR === null) === (r === null)) throw new TypeError('pipeline: give either sampleR: {key, firstItem} or r');
@@ -482,10 +485,12 @@ export default class NTRU {
       res.packed = out.packed || new BigUint64Array(B * outputSize * 4);
       res.outputSize = outputSize;
     }
-    engine().pipelineBatch(N, q, p, Uint16Array.from(expandArray(this.h, N, 0)),
+    const args = [N, q, p, Uint16Array.from(expandArray(this.h, N, 0)),
       decrypt ? Int8Array.from(expandArray(this.f, N, 0)) : null, decrypt ? Uint8Array.from(expandArray(this.fp, N, 0)) : null,
       sampleR ? sampleR.key : null, sampleR ? (sampleR.firstItem || 0) : 0, dr, dr, r, m, B,
-      res.r || null, res.e || null, res.value || null, res.packed || null);
+      res.r || null, res.e || null, res.value || null, res.packed || null];
+    if (asynchronous) return engine().pipelineBatchAsync(...args).then(() => res);
+    engine().pipelineBatch(...args);
     return res;
   }
 

@@ -416,6 +416,23 @@ class NTRU:
         }
 
     # -- string helpers, index.js:80-86 -------------------------------------------------------------------
+    # ---- additive batch API (the Node shim's ntru.pipeline): stages chained on the GPU, only m up, only what is asked for down
+    def pipeline(self, m, sampleR=None, r=None, decrypt=False, pack=False, want=None):
+        """m: [B][N] plaintext coefficients.  sampleR = (key[8] uint32, firstItem): r = generateCustomArray(N, dr, dr) with -1 -> p-1
+        (index.js:89, :461-488) drawn on the device from a ChaCha20 stream -- or r: [B][N].  encryptBits always (index.js:87-110);
+        decrypt: decryptBits of the fresh ciphertexts (index.js:111-140); pack: packOutput (index.js:572-596) of the last stage's
+        result.  want: subset of {"r", "e", "value"} (default: e without decrypt, value with it, only `packed` when pack is set)."""
+        N = self.N
+        if (sampleR is None) == (r is None):
+            raise ValueError("pipeline: give either sampleR=(key, firstItem) or r")
+        want = set(want) if want is not None else (set() if pack else ({"value"} if decrypt else {"e"}))
+        pad = lambda a, dt: np.array(list(a) + [0] * (N - len(a)), dtype=dt)
+        key, first = (sampleR if sampleR is not None else (None, 0))
+        return self.engine.pipeline_batch(N, self.q, self.p, pad(self.h, np.uint16), m,
+                                          f=pad(self.f, np.int8) if decrypt else None, fp=pad(self.fp, np.uint8) if decrypt else None,
+                                          key=key, first_item=first, n1=self.dr, n2=self.dr, r=r, want_r="r" in want and key is not None,
+                                          want_e="e" in want, want_value="value" in want, want_packed=pack)
+
     def encryptStr(self, inputPlain):
         return self.encryptBits(stringToBits(inputPlain))["value"]
 

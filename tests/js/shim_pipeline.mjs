@@ -55,6 +55,15 @@ for (const d of [hDev, fDev, fpDev, rDev, mDev, eDev, vDev, pkDev]) NTRU.devFree
 threw = false;
 try { NTRU.devUpload(mDev, m); } catch (e) { threw = true; }
 if (!threw) throw new Error('a freed handle must be refused');
+(async () => {
+// 5. the Promise-returning twin (libuv worker thread): same results, and the event loop turns while it runs
+let ticks = 0;
+const timer = setInterval(() => { ticks++; }, 0);
+const viaPromise = await ntru.pipelineAsync({ m, B, sampleR: { key: chacha, firstItem }, decrypt: true, pack: true, want: { value: true } });
+clearInterval(timer);
+for (let i = 0; i < viaPromise.value.length; i++) if (viaPromise.value[i] !== all.value[i]) throw new Error('pipelineAsync: value differs at ' + i);
+for (let i = 0; i < viaPromise.packed.length; i++) if (viaPromise.packed[i] !== all.packed[i]) throw new Error('pipelineAsync: packed differs at ' + i);
 writeFileSync(join(outDir, 'meta.json'), JSON.stringify({ N, q, p, dr: ntru.dr, B, outputSizeValue: os, outputSizeE: enc.outputSize,
   key: Array.from(chacha), firstItem }));
 console.log('shim_pipeline: OK', profile, B);
+})().catch(e => { console.error(e); process.exit(1); });
