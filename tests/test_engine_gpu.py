@@ -1174,3 +1174,22 @@ def test_plain_device_buffers_round_trip_and_feed_the_dev_entry_points(eng):
     finally:
         for x in (dh, dr, dm, de):
             eng.dev_free(x)
+
+
+def test_python_mirror_pipeline_equals_oracle(eng):
+    """ntru.NTRU.pipeline (the Python twin of the shim's ntru.pipeline) on a golden key."""
+    from conftest import load_golden
+    g = load_golden("scheme_n167_q128.json"); k = g["keys"][0]
+    n = pkg.NTRU(dict(g["options"], f=k["f"], fp=k["fp"], fq=k["fq"], g=k["g"], h=k["h"]), engine=eng)
+    N = n.N
+    m = np.random.default_rng(1).integers(0, 2, (500, N))
+    key = np.arange(8, dtype=np.uint32)
+    pad = lambda a, dt: np.array(list(a) + [0] * (N - len(a)), dtype=dt)
+    r_o = orc.sample_ternary_batch(N, n.dr, n.dr, n.p - 1, key, 7, 500)
+    e_o, _ = orc.encrypt_batch(N, n.q, pad(n.h, np.uint16), r_o, m)
+    v_o = orc.decrypt_batch(N, n.q, n.p, pad(n.f, np.int8), pad(n.fp, np.uint8), e_o)[0]
+    out = n.pipeline(m, sampleR=(key, 7), decrypt=True, want={"r", "e", "value"})
+    assert np.array_equal(out["r"], r_o) and np.array_equal(out["e"], e_o) and np.array_equal(out["value"], v_o)
+    assert list(n.pipeline(m, r=r_o)) == ["e"]
+    packed = n.pipeline(m, r=r_o, decrypt=True, pack=True)
+    assert list(packed) == ["packed"] and np.array_equal(packed["packed"], orc.pack_batch(n.p - 1, N, v_o.astype(np.uint16)))
