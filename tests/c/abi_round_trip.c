@@ -85,6 +85,32 @@ int main(void) {
     bad |= !same;
     ntru_host_free(r); ntru_host_free(m); ntru_host_free(e2); ntru_host_free(qe2); free(h); free(e1); free(rp); free(mp);
   }
+  /* the device-resident pipeline from C: a given r (so that the oracle can follow), encrypt -> decrypt on the GPU, only value
+   * and the ciphertexts come back; then plain device buffers through the *_dev entry points */
+  {
+    const int N = 821, q = 4096, p = 3; const int64_t B = 9001;           /* four chunks */
+    const size_t n = (size_t)B * N;
+    uint16_t *h = malloc(2 * (size_t)N), *e = malloc(2 * n), *e_o = malloc(2 * n), *t16 = malloc(2 * n);
+    int8_t *f = malloc(N);
+    uint8_t *fp = malloc(N), *r = malloc(n), *m = malloc(n), *v = malloc(n), *v_o = malloc(n), *t8 = malloc(n);
+    for (int i = 0; i < N; i++) { h[i] = (uint16_t)(rnd() % (uint32_t)q); f[i] = (int8_t)(rnd() % 3) - 1; fp[i] = (uint8_t)(rnd() % 3); }
+    for (size_t i = 0; i < n; i++) { r[i] = (uint8_t)(rnd() % 3); m[i] = (uint8_t)(rnd() & 1); }
+    CHECK(ntru_pipeline_batch(eng, N, q, p, h, f, fp, NULL, 0, 0, 0, r, m, B, NULL, e, v, NULL));
+    if (orc_encrypt_batch(N, q, h, r, m, B, e_o, NULL, 0) || orc_decrypt_batch(N, q, p, f, fp, e_o, B, v_o, t16, t16, t8, 0)) return 2;
+    int same = !memcmp(e, e_o, 2 * n) && !memcmp(v, v_o, n);
+    void *d_h, *d_r, *d_m, *d_e;
+    CHECK(ntru_dev_alloc(eng, 2 * (size_t)N, &d_h)); CHECK(ntru_dev_alloc(eng, n, &d_r)); CHECK(ntru_dev_alloc(eng, n, &d_m));
+    CHECK(ntru_dev_alloc(eng, 2 * n, &d_e));
+    CHECK(ntru_dev_upload(eng, d_h, h, 2 * (size_t)N)); CHECK(ntru_dev_upload(eng, d_r, r, n)); CHECK(ntru_dev_upload(eng, d_m, m, n));
+    CHECK(ntru_encrypt_batch_dev(eng, N, q, d_h, d_r, d_m, B, d_e, NULL));
+    memset(e, 0, 2 * n);
+    CHECK(ntru_dev_download(eng, e, d_e, 2 * n));
+    same = same && !memcmp(e, e_o, 2 * n);
+    CHECK(ntru_dev_free(eng, d_h)); CHECK(ntru_dev_free(eng, d_r)); CHECK(ntru_dev_free(eng, d_m)); CHECK(ntru_dev_free(eng, d_e));
+    printf("pipeline + device buffers, N=%d B=%lld: %s\n", N, (long long)B, same ? "identical" : "DIFFERENT");
+    bad |= !same;
+    free(h); free(e); free(e_o); free(t16); free(f); free(fp); free(r); free(m); free(v); free(v_o); free(t8);
+  }
   /* generic family: the two divisions of test/circuits.test.js:165-170 that the reference computes / refuses, and its
    * worked Euclid example (index.js:411-423): [4,2,0,3]^-1 mod [3,2,1] over Z_11 = [5,8] */
   {

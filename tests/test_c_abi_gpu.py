@@ -32,4 +32,5 @@ def test_plain_c_consumer_round_trip(tmp_path):
     assert len(lines) == 4 and all(l.endswith("identical") for l in lines), out.stdout
     assert "k_decrypt_m" in lines[0]              # the matrix-core kernels served the headline parameter set
     assert "pinned vs pageable host buffers" in out.stdout and "DIFFERENT" not in out.stdout
+    assert "pipeline + device buffers, N=821 B=9001: identical" in out.stdout
     assert "generic family: divide ok, refused divide ok, Euclid example ok" in out.stdout
