@@ -201,39 +201,59 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       u32 vcar[PL], gprev[PL];
 #pragma unroll
       for (int pl = 0; pl < PL; pl++) { vcar[pl] = 0; gprev[pl] = 0; }
+      // v and w have degree <= step before this step (v = 0, w = 1 at the start; a step multiplies v by x and adds a multiple of
+      // it to w), so words above (step + 1) / 32 of both are zero before and after it: their half of the work is skipped.  The
+      // bound is the same in every lane (the step counter is), so the test is a scalar branch per word.
+      const int vw_top = (step + 1) >> 5;
 #pragma unroll UNR
       for (int w = 0; w < NW; w++) {
-        u32 F[PL], G[PL], V[PL], W[PL];
+        u32 F[PL], G[PL];
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
-          F[pl] = at(AF, pl, w); G[pl] = at(AG, pl, w); W[pl] = at(AW, pl, w);
-          const u32 v = at(AV, pl, w);
-          V[pl] = (v << 1) | vcar[pl];                    // v = x v
-          vcar[pl] = v >> 31;
+          F[pl] = at(AF, pl, w); G[pl] = at(AG, pl, w);
           if (P == 2) {
-            u32 t = sm & (F[pl] ^ G[pl]); F[pl] ^= t; G[pl] ^= t;    // conditional swaps
-            t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
-          } else {                                                    // ... as selects: the condition is per lane, not per bit
-            const u32 f_ = F[pl], v_ = V[pl];
+            const u32 t = sm & (F[pl] ^ G[pl]); F[pl] ^= t; G[pl] ^= t;    // conditional swap
+          } else {                                                          // ... as selects: the condition is per lane, not per bit
+            const u32 f_ = F[pl];
             F[pl] = swap ? G[pl] : f_; G[pl] = swap ? f_ : G[pl];
-            V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
           }
         }
-        u32 NG[PL], NWW[PL];
+        u32 NG[PL];
         if (P == 2) {                                     // c1 = 1; c2 = g(0)
           NG[0] = G[0] ^ (c2m1 & F[0]);
-          NWW[0] = W[0] ^ (c2m1 & V[0]);
         } else {
           const u32 b0 = k1 ? F[0] : (k2 ? F[1] : 0u), b1 = k1 ? F[1] : (k2 ? F[0] : 0u);      // cm * f
           add3(G[0], G[1], b0, b1, NG[0], NG[1]);
-          const u32 d0 = k1 ? V[0] : (k2 ? V[1] : 0u), d1 = k1 ? V[1] : (k2 ? V[0] : 0u);      // cm * v
-          add3(W[0], W[1], d0, d1, NWW[0], NWW[1]);
         }
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
-          at(AF, pl, w) = F[pl]; at(AV, pl, w) = V[pl]; at(AW, pl, w) = NWW[pl];
+          at(AF, pl, w) = F[pl];
           if (w > 0) at(AG, pl, w - 1) = (gprev[pl] >> 1) | (NG[pl] << 31);      // g = g / x, one word behind
           gprev[pl] = NG[pl];
+        }
+        if (w <= vw_top) {
+          u32 V[PL], W[PL], NWW[PL];
+#pragma unroll
+          for (int pl = 0; pl < PL; pl++) {
+            W[pl] = at(AW, pl, w);
+            const u32 v = at(AV, pl, w);
+            V[pl] = (v << 1) | vcar[pl];                  // v = x v
+            vcar[pl] = v >> 31;
+            if (P == 2) {
+              const u32 t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
+            } else {
+              const u32 v_ = V[pl];
+              V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
+            }
+          }
+          if (P == 2) {
+            NWW[0] = W[0] ^ (c2m1 & V[0]);
+          } else {
+            const u32 d0 = k1 ? V[0] : (k2 ? V[1] : 0u), d1 = k1 ? V[1] : (k2 ? V[0] : 0u);    // cm * v
+            add3(W[0], W[1], d0, d1, NWW[0], NWW[1]);
+          }
+#pragma unroll
+          for (int pl = 0; pl < PL; pl++) { at(AV, pl, w) = V[pl]; at(AW, pl, w) = NWW[pl]; }
         }
       }
 #pragma unroll
