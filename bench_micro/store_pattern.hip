@@ -116,7 +116,62 @@ __global__ __launch_bounds__(256) void k6(unsigned short* out, long nrb, int N) 
   }
 }
 
+// patterns 8 / 9: POLYPHASE column assignment (tile t of a group of P tiles holds the columns c0 + P l + t, l = lane & 31): a lane owns
+// P adjacent columns of its row in P registers, packs them and stores 2 P bytes; one instruction = lanes 0-31 -> ONE contiguous run of
+// 64 P bytes of row R, lanes 32-63 the same of row R + 4.  8: P = 2 (4 bytes per lane, 128-byte runs); 9: P = 4 (8 bytes, 256-byte runs).
+// The lane that holds the row end stores its valid columns as 2-byte pieces.
+template <int P>
+__global__ __launch_bounds__(256) void k8(unsigned short* out, long nrb, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31, h = lane >> 5;
+  const int groups = (N + 32 * P - 1) / (32 * P);               // groups of P tiles
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    unsigned short* blk = out + rb * 32 * N;
+    for (int gi = wave; gi < groups; gi += 4) {
+      const int col = 32 * P * gi + P * l;
+      for (int j = 0; j < 4; j++)
+        for (int ii = 0; ii < 4; ii++) {
+          unsigned short* q = blk + (ii + 8 * j + 4 * h) * N + col;
+          if (col + P <= N) {
+            if (P == 2) *(unsigned*)q = (unsigned)(rb + col);
+            else *(uint2*)q = make_uint2((unsigned)rb, col);
+          } else for (int c = col; c < N; c++) q[c - col] = (unsigned short)c;
+        }
+    }
+  }
+}
+
+// pattern 10: pattern 8 with every dword store ALIGNED: a row whose group segment starts at an address = 2 mod 4 stores the dwords
+// (column 2l+1, column 2l+2) -- the second half fetched from the next lane -- for l < 31 and its two edge columns (first and last of the
+// group) as one 2-byte store instruction with two active lanes per half-wave.
+__global__ __launch_bounds__(256) void k10(unsigned short* out, long nrb, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31, h = lane >> 5;
+  const int groups = (N + 63) / 64;
+  for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    unsigned short* blk = out + rb * 32 * N;
+    for (int gi = wave; gi < groups; gi += 4) {
+      const int col = 64 * gi + 2 * l;
+      for (int j = 0; j < 4; j++)
+        for (int ii = 0; ii < 4; ii++) {
+          const int row = ii + 8 * j;                                   // lanes 32-63: row + 4 (same parity)
+          unsigned short* q = blk + (row + 4 * h) * N + col;
+          const bool odd = (((unsigned long long)(blk + row * N + 64 * gi)) & 2) != 0;     // wave-uniform
+          if (!odd) {
+            if (col + 2 <= N) *(unsigned*)q = (unsigned)(rb + col);
+            else if (col < N) q[0] = (unsigned short)col;
+          } else {
+            if (l < 31 && col + 3 <= N) *(unsigned*)(q + 1) = (unsigned)(rb + col);
+            else if (l < 31 && col + 1 < N) q[1] = (unsigned short)col;
+            if ((l == 0 || l == 31) && col + (l ? 1 : 0) < N) q[l ? 1 : 0] = (unsigned short)(rb);
+          }
+        }
+    }
+  }
+}
+
 static void launch(int pat, int cus, unsigned short* d, long nrb, int N) {
+  if (pat == 10) { k10<<<cus * 2, 256>>>(d, nrb, N); return; }
+  if (pat == 8) { k8<2><<<cus * 2, 256>>>(d, nrb, N); return; }
+  if (pat == 9) { k8<4><<<cus * 2, 256>>>(d, nrb, N); return; }
   if (pat == 6) { k6<6><<<cus * 2, 256>>>(d, nrb, N); return; }
   if (pat == 7) { k6<7><<<cus * 2, 256>>>(d, nrb, N); return; }
   if (pat == 0) k<0><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 1) k<1><<<cus * 2, 256>>>(d, nrb, N); else if (pat == 2) k<2><<<cus * 2, 256>>>(d, nrb, N);
@@ -125,6 +180,8 @@ static void launch(int pat, int cus, unsigned short* d, long nrb, int N) {
 static const char* pat_name(int pat) {
   return pat == 0 ? "2 rows x 64 B per instruction" : pat == 1 ? "1 row x 128 B per instruction" : pat == 2 ? "8 rows x 64 B per instruction (8 B per lane)"
        : pat == 3 ? "aligned 16 B pieces + 2 B edges per row segment" : pat == 4 ? "whole row block, aligned 16 B pieces" : pat == 5 ? "1 row x 128 B per instruction, rows pitched to 832 elements"
+       : pat == 10 ? "polyphase P = 2 with aligned dwords on odd rows (+ one 2-lane edge store)"
+       : pat == 8 ? "polyphase P = 2: 2 rows x 128 B per instruction (4 B per lane, 2-byte aligned)" : pat == 9 ? "polyphase P = 4: 2 rows x 256 B per instruction (8 B per lane)"
        : pat == 6 ? "transposed layout: 32 rows x 32 B per instruction (16 B per lane, 2-byte aligned)" : "transposed layout: 32 rows x 2 x 8 B per instruction (8 B per lane)";
 }
 
@@ -153,7 +210,7 @@ int main(int argc, char** argv) {
            (double)nrb * 32 * N * 2 / (total_ms / n) * 1e-6, (double)nrb * 32 * N * 2 * 1e-9);
     return 0;
   }
-  for (int pat = 0; pat < 8; pat++)
+  for (int pat = 0; pat < 11; pat++)
     for (int rep = 0; rep < 3; rep++) {
       CK(hipEventRecord(e0));
       launch(pat, cus, d, nrb, N);

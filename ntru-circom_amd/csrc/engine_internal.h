@@ -6,7 +6,7 @@
 //   matrix_decrypt.hip       family 4, decryptBits with a shared key (k_decrypt_m, k_decrypt_m8)
 //   matrix_peritem.hip       family 4 with per-item operands (k_verify_keys_m, k_polymul_m, k_product_tern_m)
 //   keygen_sampler_pack.hip  key inversion, ternary sampler, field packing, elementwise kernels + their *_dev entry points
-//   ntru_host.hip            host-pointer entry points: pinned staging, two streams, chunked H2D / kernel / D2H pipeline
+//   ntru_host.hip            host-pointer entry points: pinned staging, three stage streams, chunked H2D / kernel / D2H pipeline
 //   ntru_generic.hip         reference-faithful generic family (arbitrary divisors, moduli up to 2^26, signed coefficients)
 // Every kernel family exports the host function that launches it (ntru_launch_*, hidden visibility); a launcher returns
 // NTRU_NOT_TAKEN when the parameters are outside its family's range and the dispatcher in abi.hip tries the next one.
