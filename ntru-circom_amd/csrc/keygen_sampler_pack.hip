@@ -47,76 +47,152 @@ __global__ void k_add_mod(u32 mod, const u16 *__restrict__ a, const u16 *__restr
 // The u32 of step t of item b is word t of the ChaCha20 keystream (RFC 8439 block function) under the caller's key with
 // nonce (b_lo, b_hi, "NTRU"), so any host can replay it with a stock ChaCha20.  The Fisher-Yates chain is inherently
 // sequential per item, so items are spread over lanes.  A lane's row lives in LDS as 2-bit symbols (0, 1, 2 = `other`),
-// 16 per dword, pitch = odd number of dwords (the lock-step accesses of all lanes hit distinct banks): 13 KB per wave
-// instead of 52 KB as bytes, i.e. 12 waves per CU instead of 3.  i is wave-uniform, so u32 % (i+1) is a multiply by a
-// per-step reciprocal from an LDS table (floor(2^32 / d), one correction) instead of a 35-instruction division.
+// 16 per dword, laid out [word][lane]: whatever word a lane touches, it is in the lane's own bank.  13 KB per wave at
+// N = 821 -> 12 waves per CU, and the launcher asks for as much LDS as makes the resident count a MULTIPLE OF FOUR: the
+// kernel is bound by vector issue, every workgroup is one wave, and 9 waves on 4 SIMDs (what the round-2 layout with its
+// per-wave reciprocal table got) left three SIMDs idle a third of the time (profiles/r03_ablation_sampler.txt).
+// i is wave-uniform: the word that holds position i stays in a register until i leaves it, u32 % (i+1) is a multiply by
+// a reciprocal floor(2^32 / d) that arrives through the scalar cache (constant table, d < 2048; an LDS table above),
+// one 24-bit multiply-subtract (the remainder is below 2d < 2^24, so the product is only needed modulo 2^24) and one
+// correction -- instead of a 35-instruction division.
 struct ChaChaKey { u32 k[8]; };
+// A workgroup is WAVES = 4 independent waves (no barrier, private LDS regions) wherever four rows regions fit the LDS: as TWELVE
+// single-wave workgroups per CU the same kernel took 3.4 ms per 2^20 items at N = 821, as three four-wave workgroups 2.2 ms
+// (profiles/r03_ab_sampler.txt; the inversion kernel, eight single-wave workgroups per CU, does not care: more than eight workgroups
+// per CU do not seem to be resident together, whatever the occupancy query says).
+struct RecipTable {
+  u32 v[2048];
+  constexpr RecipTable() : v() { for (unsigned d = 2; d < 2048; d++) v[d] = (u32)(0x100000000ULL / d); }
+};
+static __constant__ const RecipTable g_recip = RecipTable();
 
 #define CHACHA_QR(a, b, c, d)                                                          \
   a += b; d ^= a; d = __builtin_rotateleft32(d, 16); c += d; b ^= c; b = __builtin_rotateleft32(b, 12); \
   a += b; d ^= a; d = __builtin_rotateleft32(d, 8);  c += d; b ^= c; b = __builtin_rotateleft32(b, 7);
+#ifndef NTRU_SAMPLER_ABLATE
+#define NTRU_SAMPLER_ABLATE 0      // timing-only builds: 1 = no ChaCha20 rounds, 2 = no Fisher-Yates steps (wrong values; never shipped)
+#endif
 
-__global__ __launch_bounds__(64) void k_sample_ternary(int N, int n1, int n2, u32 other, ChaChaKey key,
+// word w (symbols 16 w .. 16 w + 15) of the start row [1]*n1 ++ [2]*n2 ++ [0]*...
+static __device__ __forceinline__ u32 sampler_start_word(int w, int n1, int n2) {
+  auto below = [](int k) { return k <= 0 ? 0u : (k >= 16 ? 0xFFFFFFFFu : (1u << (2 * k)) - 1u); };   // symbols 0 .. k-1 of a word
+  const u32 m1 = below(n1 - 16 * w), m2 = below(n1 + n2 - 16 * w);
+  return (0x55555555u & m1) | (0xAAAAAAAAu & m2 & ~m1);
+}
+
+template <bool BIGN, int WAVES>     // BIGN: N + 1 >= 2048, reciprocals from an LDS table behind the rows
+__global__ __launch_bounds__(WAVES * 64) void k_sample_ternary(int N, int n1, int n2, u32 other, ChaChaKey key,
                                                        unsigned long long first_item, long B,
-                                                       uint8_t *__restrict__ out, int pd) {
+                                                       uint8_t *__restrict__ out, int NW) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  u32 *recip = (u32 *)lds;                               // [N + 1]: floor(2^32 / d)
-  u32 *rows = recip + ((N + 2) & ~1);                    // [64][pd] dwords of 16 symbols
-  const int lane = threadIdx.x;
-  for (int d = lane; d <= N; d += 64) recip[d] = d >= 2 ? (u32)(0x100000000ULL / (unsigned)d) : 0u;
-  for (long base = (long)blockIdx.x * 64; base < B; base += (long)gridDim.x * 64) {
-    // all 64 rows start identical: fill them cooperatively, one dword at a time
-    for (int idx = lane; idx < 64 * pd; idx += 64) {
-      const int c = (idx % pd) * 16;
-      u32 w = 0;
-#pragma unroll
-      for (int b = 0; b < 16; b++) {
-        const int k = c + b;
-        w |= (k < n1 ? 1u : (k < n1 + n2 ? 2u : 0u)) << (2 * b);
-      }
-      rows[idx] = w;
-    }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t per_wave = (size_t)NW * 64 + (BIGN ? (size_t)((N + 2) & ~1) : 0);     // dwords
+  u32 *rows = (u32 *)lds + wave * per_wave;              // [NW][64] dwords of 16 symbols
+  u32 *recip_l = rows + (size_t)NW * 64;                 // BIGN: [N + 1]
+  if (BIGN) {
+    for (int d = lane; d <= N; d += 64) recip_l[d] = d >= 2 ? (u32)(0x100000000ULL / (unsigned)d) : 0u;
     wave_lds_fence();
-    u32 *row = rows + (size_t)lane * pd;
+  }
+  auto recip_of = [&](int d) -> u32 { return d < 2 ? 0u : (BIGN ? recip_l[d] : g_recip.v[d]); };
+  u32 *col = rows + lane;                                // word w of this lane's row: col[64 w]
+  const bool out_aligned = (((unsigned long long)out) & 15) == 0 && N >= 16;
+  for (long base = ((long)blockIdx.x * WAVES + wave) * 64; base < B; base += (long)gridDim.x * WAVES * 64) {
+    for (int w = 0; w < NW; w++) col[64 * w] = sampler_start_word(w, n1, n2);
     const unsigned long long item = first_item + (unsigned long long)(base + lane);
     const u32 n0 = (u32)item, nn1 = (u32)(item >> 32), nn2 = 0x4e545255u;
     int i = N - 1;
+    u32 a = col[64 * (i >> 4)];                          // the word that holds position i
     for (u32 ctr = 0; i >= 1; ctr++) {                  // i is the same in every lane: uniform loop
+      u32 rc[16];
+      if (!BIGN) {                                       // requested now, needed after the rounds
+#pragma unroll
+        for (int w = 0; w < 16; w++) rc[w] = recip_of(i + 1 - w);
+      }
       u32 x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
       u32 x4 = key.k[0], x5 = key.k[1], x6 = key.k[2], x7 = key.k[3], x8 = key.k[4], x9 = key.k[5], x10 = key.k[6],
           x11 = key.k[7], x12 = ctr, x13 = n0, x14 = nn1, x15 = nn2;
-      for (int r = 0; r < 10; r++) {
+      for (int r = 0; r < (NTRU_SAMPLER_ABLATE & 1 ? 0 : 10); r++) {
         CHACHA_QR(x0, x4, x8, x12) CHACHA_QR(x1, x5, x9, x13) CHACHA_QR(x2, x6, x10, x14) CHACHA_QR(x3, x7, x11, x15)
         CHACHA_QR(x0, x5, x10, x15) CHACHA_QR(x1, x6, x11, x12) CHACHA_QR(x2, x7, x8, x13) CHACHA_QR(x3, x4, x9, x14)
       }
       const u32 ks[16] = {x0 + 0x61707865u, x1 + 0x3320646eu, x2 + 0x79622d32u, x3 + 0x6b206574u,
                           x4 + key.k[0], x5 + key.k[1], x6 + key.k[2], x7 + key.k[3], x8 + key.k[4], x9 + key.k[5],
                           x10 + key.k[6], x11 + key.k[7], x12 + ctr, x13 + n0, x14 + nn1, x15 + nn2};
+#if NTRU_SAMPLER_ABLATE & 2
+      u32 fold = 0;
+#pragma unroll
+      for (int w = 0; w < 16; w++) fold ^= ks[w] ^ (BIGN ? 0u : rc[w]);
+      if (fold == 0x12345678u) a = fold;
+      i -= 16;
+#else
 #pragma unroll
       for (int w = 0; w < 16; w++) {
         if (i >= 1) {
           const u32 d = (u32)(i + 1);
-          u32 j = ks[w] - __umulhi(ks[w], recip[d]) * d;               // in [0, 2d)
-          j = j >= d ? j - d : j;
+          const u32 hi = __umulhi(ks[w], BIGN ? recip_of((int)d) : rc[w]);
+          u32 j;                                                         // ks - hi d is in [0, 2d): its low 24 bits are all of it
+          asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(j) : "v"(hi), "s"(0 - (int)d), "v"(ks[w]));
+          j &= 0xFFFFFFu;
+          j = min(j, j - d);
           const int wi = i >> 4, si = 2 * (i & 15), wj = (int)(j >> 4), sj = 2 * (int)(j & 15);
-          const u32 a = row[wi], b = row[wj];
+          const u32 bl = col[64 * wj];
+          const bool same = wj == wi;
+          const u32 b = same ? a : bl;
           const u32 x = ((a >> si) ^ (b >> sj)) & 3u;                    // swap two 2-bit fields by their difference
-          const u32 na = a ^ (x << si);
-          row[wi] = na;
-          row[wj] = (wi == wj ? na : b) ^ (x << sj);                     // same dword: the second store wins
+          a ^= x << si;
+          const u32 nb = (same ? a : b) ^ (x << sj);
+          col[64 * wj] = nb;
+          a = same ? nb : a;
           i--;
+          if ((i & 15) == 15) {                                          // uniform: position i has moved into the word below
+            col[64 * wi] = a;
+            a = col[64 * (i >> 4)];
+          }
         }
       }
+#endif
     }
+    col[0] = a;                                          // i == 0: the register copy of word 0 (N == 1: unchanged)
     wave_lds_fence();
-    // rows -> row-major byte output, coalesced: the wave walks one row at a time
-    for (int rr = 0; rr < 64; rr++) {
-      if (base + rr >= B) break;
-      uint8_t *dst = out + (size_t)(base + rr) * N;
-      const u32 *src = rows + (size_t)rr * pd;
-      for (int k = lane; k < N; k += 64) {
-        const u32 sym = (src[k >> 4] >> (2 * (k & 15))) & 3u;
-        dst[k] = (uint8_t)(sym == 2u ? other : sym);
+    if (out_aligned && base + 64 <= B) {
+      // rows -> row-major byte output.  The 64 rows of the block are ONE contiguous run of 64 N bytes that starts on a 64-byte
+      // boundary: lane L writes the 16-byte pieces of bytes [S L, S L + S), S = 16 NW >= N, i.e. the end of row ~L and the start of
+      // row ~L + 1 (distinct rows per lane: distinct LDS banks), every store aligned; 64 N is a multiple of 16, so a piece is
+      // inside the run or outside it.
+      const u32 S = 16u * (u32)NW, a0 = S * (u32)lane, run = 64u * (u32)N;
+      u32 r = a0 / (u32)N, c = a0 - r * (u32)N;
+      uint4 *dst = (uint4 *)(out + (size_t)base * N) + (size_t)NW * lane;
+      for (int it = 0; it < NW; it++) {
+        if (a0 + 16u * (u32)it < run) {
+          const u32 *rp = rows + r;
+          const int w = (int)(c >> 4), w1i = w + 1 < NW ? w + 1 : w;
+          u32 bits = __builtin_amdgcn_alignbit(rp[64 * w1i], rp[64 * w], 2 * (c & 15));
+          const int nf = N - (int)c;                     // symbols of row r from c on (>= 1)
+          if (nf < 16) bits = (bits & ((1u << (2 * nf)) - 1u)) | (rows[r + 1] << (2 * nf));   // the piece continues in row r + 1
+          u32 o[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            u32 t = (bits >> (8 * q)) & 0xFFu;
+            t = (t | (t << 12)) & 0x000F000Fu;
+            t = (t | (t << 6)) & 0x03030303u;
+            if (other != 2u) t += ((t >> 1) & 0x01010101u) * (other - 2u);
+            o[q] = t;
+          }
+          dst[it] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        c += 16;
+        if (c >= (u32)N) { c -= (u32)N; r++; }
+      }
+    } else {
+      // any alignment, partial last block: the wave walks one row at a time, one byte per lane
+      for (int rr = 0; rr < 64; rr++) {
+        if (base + rr >= B) break;
+        uint8_t *dst = out + (size_t)(base + rr) * N;
+        const u32 *src = rows + rr;
+        for (int k = lane; k < N; k += 64) {
+          const u32 sym = (src[64 * (k >> 4)] >> (2 * (k & 15))) & 3u;
+          dst[k] = (uint8_t)(sym == 2u ? other : sym);
+        }
       }
     }
     wave_lds_fence();
@@ -469,7 +545,23 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   return NTRU_OK;
 }
 
-static int sampler_pitch(int N) { int pd = (N + 15) / 16; if ((pd & 1) == 0) pd++; return pd; }   // dwords of 16 symbols
+template <bool BIGN, int WAVES>
+static int launch_sampler(ntru_engine *eng, int N, int n1, int n2, int other, const ChaChaKey &ck, uint64_t first_item, int64_t B,
+                          uint8_t *d_out) {
+  const int NW = (N + 15) / 16;                          // dwords of 16 symbols per row
+  const size_t lds = WAVES * ((size_t)64 * NW * 4 + (BIGN ? (size_t)((N + 2) & ~1) * 4 : 0));
+  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the sampler's LDS rows");
+  const void *fn = (const void *)k_sample_ternary<BIGN, WAVES>;
+  int per_cu = 0;
+  if (int rc = ntru_blocks_per_cu(eng, fn, WAVES * 64, lds, &per_cu)) return rc;
+  long blocks = (B + WAVES * 64 - 1) / (WAVES * 64), cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
+  if (blocks > cap) blocks = cap;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_sample_ternary");
+  hipLaunchKernelGGL((k_sample_ternary<BIGN, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, eng->stream, N, n1, n2, (u32)other, ck,
+                     (unsigned long long)first_item, (long)B, d_out, NW);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
 
 extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
                                        uint64_t first_item, int64_t B, uint8_t *d_out) {
@@ -480,21 +572,11 @@ extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2
   if (!key) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: key is NULL");
   if (B == 0) return NTRU_OK;
   if (!d_out) return fail(NTRU_ERR_ARG, "ntru_sample_ternary: NULL buffer");
-  const int pitch = sampler_pitch(N);
-  const size_t lds = (size_t)64 * pitch * 4 + (size_t)((N + 2) & ~1) * 4;
-  if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the sampler's LDS rows");
   HIP_TRY(hipSetDevice(eng->device));
   ChaChaKey ck;
   memcpy(ck.k, key, 32);
-  int per_cu = 0;
-  if (int rc = ntru_blocks_per_cu(eng, (const void *)k_sample_ternary, 64, lds, &per_cu)) return rc;
-  long blocks = (B + 63) / 64, cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
-  if (blocks > cap) blocks = cap;
-  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_sample_ternary");
-  hipLaunchKernelGGL(k_sample_ternary, dim3((unsigned)blocks), dim3(64), lds, eng->stream, N, n1, n2, (u32)other, ck,
-                     (unsigned long long)first_item, (long)B, d_out, pitch);
-  HIP_TRY(hipGetLastError());
-  return NTRU_OK;
+  return N + 1 < 2048 ? launch_sampler<false, 4>(eng, N, n1, n2, other, ck, first_item, B, d_out)     // <= 32 KB of rows per wave
+                      : launch_sampler<true, 1>(eng, N, n1, n2, other, ck, first_item, B, d_out);
 }
 
 extern "C" int ntru_pack_params(int max_val, int data_len, int *bits, int *per_output, int *arr_len, int *output_size) {

@@ -12,7 +12,7 @@
 // so nothing is scaled.  2 NT - 1 (+1 for the split diagonal) matrix instructions per plane.  One item per wave, all LDS
 // regions private to the wave, no workgroup barrier.
 constexpr int PI_PAD = 32;          // zero chunks on either side of the chunk matrix: rows 0..31, distances +-(NT-1)
-constexpr int PI_WAVES = 2;         // waves per workgroup (LDS, not registers, bounds the residency: ~15 KB per wave)
+constexpr int PI_WAVES = 2;         // waves per workgroup (LDS, not registers, bounds the residency: ~15 KB per wave); 4 measured the same
 struct PGeom { int N, NT, tpitch; };
 static __host__ __device__ inline size_t pi_fa_bytes(const PGeom &g) { return (size_t)32 * (g.NT + 2 * PI_PAD); }
 static __host__ __device__ inline size_t pi_nat_bytes(const PGeom &g) { return ((size_t)3 * g.N + 64 + 15) & ~(size_t)15; }

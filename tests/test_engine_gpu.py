@@ -798,6 +798,23 @@ def test_device_sampler_equals_oracle(eng, N, n1, n2):
         eng.sample_ternary(4, 3, 2, 2, key, 0, 1)
 
 
+@pytest.mark.parametrize("N", [16, 17, 31, 33, 100, 821, 2046, 2047, 2100])
+def test_device_sampler_output_paths(eng, N):
+    """The sampler's two output paths (aligned 16-byte pieces over a whole block of 64 rows; one byte per lane for unaligned pointers and
+    the partial last block), `other` != 2, and both reciprocal sources (constant table below N = 2047, LDS table from there on)."""
+    import torch
+    key = (np.arange(8, dtype=np.uint64) * 0x85EBCA6B + 99).astype(np.uint32)
+    n1, n2, B = N // 3, N // 4, 130                                  # two whole blocks and two rows
+    for other, off, first in ((2, 0, 0), (255, 0, 5), (7, 3, 2 ** 32 - 64), (2, 16, 11)):
+        buf = torch.full((B * N + 64,), 0xEE, dtype=torch.uint8, device="cuda:0")
+        eng.sample_ternary_dev(N, n1, n2, other, key, first, B, buf.data_ptr() + off)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        want = orc.sample_ternary_batch(N, n1, n2, other, key, first, B)
+        assert np.array_equal(got[off:off + B * N].reshape(B, N), want), (other, off)
+        assert (got[:off] == 0xEE).all() and (got[off + B * N:] == 0xEE).all()          # nothing outside the rows
+
+
 def test_sampled_encrypt_matches_reference_semantics(eng, scheme_golden):
     """sample r on the device, encrypt, and replay on the CPU: r from the oracle's sampler on the same stream, then the
     oracle's encryptBits -- the witness must match bit for bit."""

@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--no-smi", action="store_true")
     ap.add_argument("--kernel-path", type=int, default=0, help="ntru_engine_set_kernel_path for the encrypt / decrypt loops")
     ap.add_argument("--row-pitch", type=int, default=0, help="row pitch in elements (0 = dense)")
-    ap.add_argument("--loads", default="all", help="comma list of: idle,mfma,encrypt,decrypt,decrypt_value,verify (default all); with "
+    ap.add_argument("--loads", default="all", help="comma list of: idle,mfma,encrypt,decrypt,decrypt_value,verify (default all), sampler; with "
                                                    "NTRU_ENGINE_LIB pointing at a timing-only build (tools/ablate.sh) this prices its energy")
     args = ap.parse_args()
     import numpy as np
@@ -237,6 +237,9 @@ def main():
     if want("decrypt"): sampled("decrypt_loop_full_witness", loop(dec, B))
     if want("decrypt_value"): sampled("decrypt_loop_value_only", loop(dec_v, B))
     if want("verify"): sampled("verify_keys_loop", loop(vk, Bk))
+    if "sampler" in args.loads.split(","):
+        skey = np.arange(8, dtype=np.uint32) + 1
+        sampled("sampler_loop", loop(lambda: eng.sample_ternary_dev(N, 273 if N == 821 else N // 3, 273 if N == 821 else N // 3, 2, skey, 0, B, r.data_ptr()), B))
     if want("idle"): sampled("idle_one_wave_again", spin(0, 1, 64))
     if not args.no_smi:
         print(json.dumps({"smi_snapshot_idle": smi_snapshot()}))
