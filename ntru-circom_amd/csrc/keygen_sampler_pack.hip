@@ -554,6 +554,7 @@ static int launch_sampler(ntru_engine *eng, int N, int n1, int n2, int other, co
   const void *fn = (const void *)k_sample_ternary<BIGN, WAVES>;
   int per_cu = 0;
   if (int rc = ntru_blocks_per_cu(eng, fn, WAVES * 64, lds, &per_cu)) return rc;
+  if (eng->max_blocks_per_cu && eng->max_blocks_per_cu < per_cu) per_cu = eng->max_blocks_per_cu;     // NTRU_MAX_BLOCKS_PER_CU (experiments)
   long blocks = (B + WAVES * 64 - 1) / (WAVES * 64), cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
   if (blocks > cap) blocks = cap;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_sample_ternary");
