@@ -255,10 +255,16 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
     }
     int delta = 1;
     // GF(3) helpers on (is-one, is-two) plane pairs
-    auto add3 = [](u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
-      const u32 az = ~(a0 | a1), bz = ~(b0 | b1);
-      r0 = (a0 & bz) | (az & b0) | (a1 & b1);
-      r1 = (a1 & bz) | (az & b1) | (a0 & b0);
+    // GF(3), planes (c == 1, c == 2): r = g + cm f with the per-lane scalar cm given as two lane masks (m2: cm == 2, mnz: cm != 0).
+    // Seven three-input functions (v_bitop3_b32 each): t = cm f as u = (f0 ^ f1) & m2, t0 = (f0 ^ u) & mnz, t1 = (f1 ^ u) & mnz (the scalar
+    // 2 exchanges the planes); then r == 1 iff t == 2 ? g == 2 : (t == 0 ? g == 1 : g == 0), and the mirror image for r == 2.
+    auto madd3 = [](u32 g0, u32 g1, u32 f0, u32 f1, u32 m2, u32 mnz, u32 &r0, u32 &r1) {
+      const u32 u = (f0 ^ f1) & m2;
+      const u32 t0 = (f0 ^ u) & mnz, t1 = (f1 ^ u) & mnz;
+      const u32 h0 = (g0 & ~t0) | (~(g0 | g1) & t0);
+      const u32 h1 = (g1 & ~t1) | (~(g0 | g1) & t1);
+      r0 = (t1 & g1) | (~t1 & h0);
+      r1 = (t0 & g0) | (~t0 & h1);
     };
     for (int step = 0; step < 2 * N - 1; step++) {
       const u32 f0w0 = at(AF, 0, 0), g0w0 = at(AG, 0, 0);
@@ -273,16 +279,20 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       // GF(3): g and w are scaled by the unit 1 / f(0) every step (they stay consistent with each other, and the inverse
       // is unique), so ONE scalar multiplies f and v: new g = (g - (g(0) / f(0)) f) / x, and 1 / f(0) = f(0) in GF(3)
       const int cm = P == 3 ? (9 - (swap ? fc : gc) * c1) % 3 : 0;
-      const bool k1 = cm == 1, k2 = cm == 2;
-      u32 vcar[PL], gprev[PL];
-#pragma unroll
-      for (int pl = 0; pl < PL; pl++) { vcar[pl] = 0; gprev[pl] = 0; }
+      u32 m2 = cm == 2 ? ~0u : 0u, mnz = cm != 0 ? ~0u : 0u;
+      asm volatile("" : "+v"(m2), "+v"(mnz));            // opaque: `x & mask` must stay a bit operation that fuses, not become a select
       // v and w have degree <= step before this step (v = 0, w = 1 at the start; a step multiplies v by x and adds a multiple of
       // it to w), so words above (step + 1) / 32 of both are zero before and after it: their half of the work is skipped.  The
       // bound is the same in every lane (the step counter is), so the test is a scalar branch per word.
       const int vw_top = (step + 1) >> 5;
+      // Words from the TOP down: g / x takes its incoming bit from the word above (already computed: `gup`), x v from the word below
+      // (not yet overwritten), so every word is read and rewritten in place within its own iteration -- with register planes nothing
+      // has to be copied at the end of a step (going up, the results land one word behind and the loop ended in ~100 moves).
+      u32 gup[PL];
+#pragma unroll
+      for (int pl = 0; pl < PL; pl++) gup[pl] = 0;
 #pragma unroll UNR
-      for (int w = 0; w < NW; w++) {
+      for (int w = NW - 1; w >= 0; w--) {
         u32 F[PL], G[PL];
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
@@ -298,23 +308,20 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
         if (P == 2) {                                     // c1 = 1; c2 = g(0)
           NG[0] = G[0] ^ (c2m1 & F[0]);
         } else {
-          const u32 b0 = k1 ? F[0] : (k2 ? F[1] : 0u), b1 = k1 ? F[1] : (k2 ? F[0] : 0u);      // cm * f
-          add3(G[0], G[1], b0, b1, NG[0], NG[1]);
+          madd3(G[0], G[1], F[0], F[1], m2, mnz, NG[0], NG[1]);
         }
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
           at(AF, pl, w) = F[pl];
-          if (w > 0) at(AG, pl, w - 1) = (gprev[pl] >> 1) | (NG[pl] << 31);      // g = g / x, one word behind
-          gprev[pl] = NG[pl];
+          at(AG, pl, w) = __builtin_amdgcn_alignbit(gup[pl], NG[pl], 1);       // g = g / x
+          gup[pl] = NG[pl];
         }
         if (w <= vw_top) {
           u32 V[PL], W[PL], NWW[PL];
 #pragma unroll
           for (int pl = 0; pl < PL; pl++) {
             W[pl] = at(AW, pl, w);
-            const u32 v = at(AV, pl, w);
-            V[pl] = (v << 1) | vcar[pl];                  // v = x v
-            vcar[pl] = v >> 31;
+            V[pl] = __builtin_amdgcn_alignbit(at(AV, pl, w), w > 0 ? at(AV, pl, w - 1) : 0u, 31);      // v = x v
             if (P == 2) {
               const u32 t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
             } else {
@@ -325,15 +332,12 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
           if (P == 2) {
             NWW[0] = W[0] ^ (c2m1 & V[0]);
           } else {
-            const u32 d0 = k1 ? V[0] : (k2 ? V[1] : 0u), d1 = k1 ? V[1] : (k2 ? V[0] : 0u);    // cm * v
-            add3(W[0], W[1], d0, d1, NWW[0], NWW[1]);
+            madd3(W[0], W[1], V[0], V[1], m2, mnz, NWW[0], NWW[1]);
           }
 #pragma unroll
           for (int pl = 0; pl < PL; pl++) { at(AV, pl, w) = V[pl]; at(AW, pl, w) = NWW[pl]; }
         }
       }
-#pragma unroll
-      for (int pl = 0; pl < PL; pl++) at(AG, pl, NW - 1) = gprev[pl] >> 1;
     }
     // unit iff the gcd (in ff) is a non-zero constant
     u32 rest = 0;
