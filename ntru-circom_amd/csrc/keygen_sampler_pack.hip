@@ -271,7 +271,6 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       const u32 f0w1 = P == 3 ? at(AF, 1, 0) : 0u, g0w1 = P == 3 ? at(AG, 1, 0) : 0u;
       const int fc = (int)(f0w0 & 1u) + 2 * (int)(f0w1 & 1u), gc = (int)(g0w0 & 1u) + 2 * (int)(g0w1 & 1u);   // constant terms
       const bool swap = delta > 0 && gc != 0;
-      const u32 sm = swap ? ~0u : 0u;
       delta = (swap ? -delta : delta) + 1;
       const int c1 = swap ? gc : fc;                      // new f(0): multiplies g and w
       const int c2 = (P - (swap ? fc : gc)) % P;           // -(new g(0)): multiplies f and v
@@ -297,12 +296,8 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
           F[pl] = at(AF, pl, w); G[pl] = at(AG, pl, w);
-          if (P == 2) {
-            const u32 t = sm & (F[pl] ^ G[pl]); F[pl] ^= t; G[pl] ^= t;    // conditional swap
-          } else {                                                          // ... as selects: the condition is per lane, not per bit
-            const u32 f_ = F[pl];
-            F[pl] = swap ? G[pl] : f_; G[pl] = swap ? f_ : G[pl];
-          }
+          const u32 f_ = F[pl];                                             // conditional swap as selects: the condition is per lane, not per bit
+          F[pl] = swap ? G[pl] : f_; G[pl] = swap ? f_ : G[pl];
         }
         u32 NG[PL];
         if (P == 2) {                                     // c1 = 1; c2 = g(0)
@@ -322,12 +317,8 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
           for (int pl = 0; pl < PL; pl++) {
             W[pl] = at(AW, pl, w);
             V[pl] = __builtin_amdgcn_alignbit(at(AV, pl, w), w > 0 ? at(AV, pl, w - 1) : 0u, 31);      // v = x v
-            if (P == 2) {
-              const u32 t = sm & (V[pl] ^ W[pl]); V[pl] ^= t; W[pl] ^= t;
-            } else {
-              const u32 v_ = V[pl];
-              V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
-            }
+            const u32 v_ = V[pl];
+            V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
           }
           if (P == 2) {
             NWW[0] = W[0] ^ (c2m1 & V[0]);
