@@ -13,6 +13,7 @@
 
 #include "fake_formulas.h"
 #include "ntru_engine.h"
+#include "engine_internal.h"
 
 static int g_fail = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { g_fail++; fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
@@ -172,6 +173,15 @@ int main() {
   CHECK(ntru_engine_create(9, &e2) != 0 && e2 == nullptr && strlen(ntru_last_error()) > 0, "device id out of range must fail with a message");
   OK(ntru_engine_create(1, &e2));
   CHECK(ntru_engine_set_kernel_path(eng, 77) != 0, "bad kernel path must be refused");
+  {   // the occupancy query is corrected for the 1280-byte pieces LDS is handed out in (profiles/r03_wg_residency.txt)
+    struct { int threads; size_t lds; int want; } cases[] = {{64, 13312, 11}, {64, 12800, 12}, {64, 12801, 11}, {64, 10241, 14},
+                                                             {256, 81920, 2}, {256, 81921, 1}, {256, 0, 2}, {64, 5121, 25}};
+    for (auto &c : cases) {
+      int n = 0;
+      OK(ntru_blocks_per_cu(eng, (const void *)&cases, c.threads, c.lds, &n));
+      CHECK(n == c.want, "workgroups per CU after the LDS-piece correction");
+    }
+  }
   const int N = 61, q = 2048;
   for (bool pin : {false, true})
     for (int64_t B : {(int64_t)0, (int64_t)1, (int64_t)1000, (int64_t)(1 << 15) + 7, (int64_t)3 * (1 << 15) + 5}) {
