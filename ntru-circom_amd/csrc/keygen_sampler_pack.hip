@@ -523,7 +523,9 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
         // Hensel lifting: round r only has to be right modulo 2^(2^(r+1)); the early rounds therefore run modulo 4, 16,
         // 256 (single int8 digit planes on the matrix cores), the last one modulo q.  The inverse modulo q is unique.
         const int mr = (2 << r) >= k ? q : 1 << (2 << r);
-        if (int rc = ntru_polymul_split_dev(eng, N, mr, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p)) return rc;
+        int rc_vv = ntru_launch_polymul_matrix(eng, N, mr, v, v, n, nullptr, (uint16_t *)t.p);       // v * v: only the remainder is used
+        if (rc_vv == NTRU_NOT_TAKEN) rc_vv = ntru_polymul_split_dev(eng, N, mr, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p);
+        if (rc_vv) return rc_vv;
         if (ntru_product_tern_matrix_applies(eng, N, mr)) {         // f * t with f ternary: per-item product on the matrix cores
           if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, (const uint16_t *)t.p, d_f + o * N, (long)n, nullptr, (uint16_t *)u.p)) return rc;
         } else if (int rc = ntru_polymul_split_dev(eng, N, mr, (const uint16_t *)f16.p, (const uint16_t *)t.p, n,

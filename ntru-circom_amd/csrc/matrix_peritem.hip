@@ -407,15 +407,25 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
   const v4i cmask = col_mask16(16 * lane, N);
   const bool want_q = quot != nullptr;
   wave_lds_fence();
-  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
-    const long row = item * N, left = (B - item) * N;
+  // The operands of the NEXT item are requested as soon as this item's are in LDS (the round trip to HBM runs under the matrix
+  // loops and the result stores instead of in front of every item).
+  const long item_step = (long)gridDim.x * PI_WAVES;
+  RawChunks<2> ra;
+  RawChunks<1> rs;
+  auto request = [&](long it) {
+    const long rw = it * N, lf = (B - it) * N;
+    const AlignedSrc sa = aligned_src(a + rw, 2 * lf), ss = aligned_src(s + rw, lf);
+    ra = load_raw<2>(sa, sa.a0 + 32 * lane, 0);
+    rs = load_raw<1>(ss, ss.a0 + 16 * lane, 0);
+  };
+  if ((long)blockIdx.x * PI_WAVES + wave < B) request((long)blockIdx.x * PI_WAVES + wave);
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
+    const long row = item * N;
     {
-      const AlignedSrc sa = aligned_src(a + row, 2 * left), ss = aligned_src(s + row, left);
-      const RawChunks<2> ra = load_raw<2>(sa, sa.a0 + 32 * lane, 0);
-      const RawChunks<1> rs = load_raw<1>(ss, ss.a0 + 16 * lane, 0);
       v4i va[2], vs[1];
-      shift_raw<2>(ra, __builtin_amdgcn_readfirstlane(sa.a0), va);
-      shift_raw<1>(rs, __builtin_amdgcn_readfirstlane(ss.a0), vs);
+      shift_raw<2>(ra, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(a + row) & 15)), va);
+      shift_raw<1>(rs, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(s + row) & 15)), vs);
+      if (item + item_step < B) request(item + item_step);
       u32 xa[8];
 #pragma unroll
       for (int c = 0; c < 4; c++) { xa[c] = (u32)va[0][c]; xa[4 + c] = (u32)va[1][c]; }
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
         __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        if (want_q) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);   // (a store through an empty descriptor is dropped, but issued)
       }
     }
     wave_lds_fence();
@@ -472,86 +482,115 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
   diag_low_mask(lane, mlow);
   const bool stager = 16 * lane < 32 * NT;
   const bool one = q <= 256;                               // single int8 plane per operand (pi_digits)
+  const bool want_q = quot != nullptr;                     // the Newton rounds of the key inversion only need the remainder
   wave_lds_fence();
-  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += (long)gridDim.x * PI_WAVES) {
-    const long row = item * N, left = (B - item) * N;
+  const long item_step = (long)gridDim.x * PI_WAVES;         // the NEXT item's operands are requested early: see k_product_tern_m
+  RawChunks<2> rwa, rwb;
+  auto request = [&](long it) {
+    const long rw = it * N, lf = (B - it) * N;
+    const AlignedSrc sa = aligned_src(a + rw, 2 * lf), sb = aligned_src(b + rw, 2 * lf);
+    rwa = load_raw<2>(sa, sa.a0 + 32 * lane, 0);
+    rwb = load_raw<2>(sb, sb.a0 + 32 * lane, 0);
+  };
+  if ((long)blockIdx.x * PI_WAVES + wave < B) request((long)blockIdx.x * PI_WAVES + wave);
+  [[maybe_unused]] int stamp_iter = -1;                    // -DNTRU_STAMPS: phase stamps of the first items (tools/phase_stamps_peritem.py)
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
+    const long row = item * N;
+    stamp_iter++;
+    STAMP(0);
     {
-      auto fetch = [&](const u16 *base, u32 (&x)[8]) {
-        const AlignedSrc sr = aligned_src(base + row, 2 * left);
-        const RawChunks<2> rw = load_raw<2>(sr, sr.a0 + 32 * lane, 0);
-        v4i v[2];
-        shift_raw<2>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
-#pragma unroll
-        for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
-      };
       u32 xa[8], xb[8];
-      fetch(a, xa); fetch(b, xb);
+      {
+        v4i va[2], vb[2];
+        shift_raw<2>(rwa, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(a + row) & 15)), va);
+        shift_raw<2>(rwb, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(b + row) & 15)), vb);
+#pragma unroll
+        for (int c = 0; c < 4; c++) { xa[c] = (u32)va[0][c]; xa[4 + c] = (u32)va[1][c]; xb[c] = (u32)vb[0][c]; xb[4 + c] = (u32)vb[1][c]; }
+      }
+      STAMP(1);                                            // operands arrived
+      if (item + item_step < B) request(item + item_step);
       v4i a0, a1, b0, b1;
       pi_digits(xa, q, 1u, 16 * lane, N, a0, a1);
       pi_digits(xb, q, 1u, 16 * lane, N, b0, b1);
+      STAMP(2);                                            // digits
       pi_build_array(nat, T0, g, lane, b0);
       if (!one) pi_build_array(nat, T1, g, lane, b1);
+      STAMP(3);                                            // reversed arrays
       if (stager) {
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = a0;
         *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
       }
       wave_lds_fence();
     }
+    STAMP(4);                                              // chunk matrices
     v16i L0, L1, H0, H1;                                   // group 0: a0 b0; group 1: a0 b1 + a1 b0
 #pragma unroll
     for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
-    auto ld = [&](int d, v4i &x0, v4i &x1, v4i &w0, v4i &w1) {
-      const u32 *p0 = tb0 - 8 * d, *p1 = tb1 - 8 * d;
-      w0 = (v4i){(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3]};
-      w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
-      x0 = *(const v4i *)(pa0 - 32 * d);
-      x1 = *(const v4i *)(pa1 - 32 * d);
-    };
-    auto mm3 = [&](v16i &X0, v16i &X1, v4i x0, v4i x1, v4i w0, v4i w1) {
-      X0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w0, X0, 0, 0, 0);
-      if (!one) {                                          // q <= 256: both operands are single planes
-        X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w1, X1, 0, 0, 0);
-        X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1, w0, X1, 0, 0, 0);
+    // The loop lives on its LDS reads (phase stamps, profiles/r03_phase_stamps_peritem.txt: ~250 clocks per step = what 12 waves x 4 KB
+    // cost the CU's LDS), so the single-plane form (q <= 256: the early Newton rounds) must not read the second plane's operands.
+    auto loops = [&](auto one_c) {
+      constexpr bool ONE = decltype(one_c)::value;
+      auto ld = [&](int d, v4i &x0, v4i &x1, v4i &w0, v4i &w1) {
+        const u32 *p0 = tb0 - 8 * d;
+        w0 = (v4i){(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3]};
+        x0 = *(const v4i *)(pa0 - 32 * d);
+        if (!ONE) {
+          const u32 *p1 = tb1 - 8 * d;
+          w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+          x1 = *(const v4i *)(pa1 - 32 * d);
+        }
+      };
+      auto mm3 = [&](v16i &X0, v16i &X1, v4i x0, v4i x1, v4i w0, v4i w1) {
+        X0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w0, X0, 0, 0, 0);
+        if (!ONE) {                                        // q <= 256: both operands are single planes
+          X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w1, X1, 0, 0, 0);
+          X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1, w0, X1, 0, 0, 0);
+        }
+      };
+      v4i x0, x1 = {0, 0, 0, 0}, w0, w1 = {0, 0, 0, 0};
+      ld(-(NT - 1), x0, x1, w0, w1);
+      for (int d = -(NT - 1); d < 0; d++) {
+        v4i n0, n1 = {0, 0, 0, 0}, m0, m1 = {0, 0, 0, 0};
+        ld(d + 1, n0, n1, m0, m1);
+        mm3(H0, H1, x0, x1, w0, w1);
+        x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+      }
+      {
+        v4i n0, n1 = {0, 0, 0, 0}, m0, m1 = {0, 0, 0, 0};
+        ld(1, n0, n1, m0, m1);
+        u32 mhigh[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
+        mm3(L0, L1, x0, x1, and4(w0, mlow), and4(w1, mlow));
+        mm3(H0, H1, x0, x1, and4(w0, mhigh), and4(w1, mhigh));
+        x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+      }
+      for (int d = 1; d < NT; d++) {
+        v4i n0, n1 = {0, 0, 0, 0}, m0, m1 = {0, 0, 0, 0};
+        ld(d + 1, n0, n1, m0, m1);
+        mm3(L0, L1, x0, x1, w0, w1);
+        x0 = n0; x1 = n1; w0 = m0; w1 = m1;
       }
     };
-    v4i x0, x1, w0, w1;
-    ld(-(NT - 1), x0, x1, w0, w1);
-    for (int d = -(NT - 1); d < 0; d++) {
-      v4i n0, n1, m0, m1;
-      ld(d + 1, n0, n1, m0, m1);
-      mm3(H0, H1, x0, x1, w0, w1);
-      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
-    }
-    {
-      v4i n0, n1, m0, m1;
-      ld(1, n0, n1, m0, m1);
-      u32 mhigh[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
-      mm3(L0, L1, x0, x1, and4(w0, mlow), and4(w1, mlow));
-      mm3(H0, H1, x0, x1, and4(w0, mhigh), and4(w1, mhigh));
-      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
-    }
-    for (int d = 1; d < NT; d++) {
-      v4i n0, n1, m0, m1;
-      ld(d + 1, n0, n1, m0, m1);
-      mm3(L0, L1, x0, x1, w0, w1);
-      x0 = n0; x1 = n1; w0 = m0; w1 = m1;
-    }
+    if (one) loops(std::true_type{}); else loops(std::false_type{});
+    STAMP(5);                                              // matrix loops
     {
       const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
-      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N), rs_q = rows_rsrc(quot + row, 2L * N);
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
+      const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quot + row : nullptr, want_q ? 2L * N : 0L);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const u32 lo = (u32)L0[i] + 128u * (u32)L1[i], hi = (u32)H0[i] + 128u * (u32)H1[i];
         __builtin_amdgcn_raw_buffer_store_b16((u16)((lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)((0u - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        if (want_q) __builtin_amdgcn_raw_buffer_store_b16((u16)((0u - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
       }
     }
     wave_lds_fence();
+    STAMP(6);                                              // result stores issued
   }
 }
+NTRU_STAMPS_READER(ntru_debug_read_stamps_pi)
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static PGeom make_pgeom(int N) {

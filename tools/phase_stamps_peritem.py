@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Phase timeline of one item in k_polymul_m from a -DNTRU_STAMPS build (diagnostic, never shipped):
+     make -C ntru-circom_amd/csrc EXTRA=-DNTRU_STAMPS OBJDIR=../lib/ab/obj_stamps OUT=../lib/ab/libntru_stamps.so
+     NTRU_ENGINE_LIB=$PWD/ntru-circom_amd/lib/ab/libntru_stamps.so python tools/phase_stamps_peritem.py
+Median duration of each phase (shader clocks of s_memtime) over workgroups x waves for the 3rd-5th item of every wave."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+pkg = ge.load_package()
+eng = pkg.Engine(0)
+lib = C.CDLL(os.environ["NTRU_ENGINE_LIB"])
+dev = torch.device("cuda:0")
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+N, B = 821, 1 << 16
+buf = np.zeros((1024, 8, 6, 24), np.uint64)
+labels = [(0, 1, "operands arrive + shift"), (1, 2, "digit planes"), (2, 3, "reversed arrays"), (3, 4, "chunk matrices + fence"),
+          (4, 5, "matrix loops"), (5, 6, "result stores issued + fence")]
+for mod in (16, 4096):
+    a = torch.randint(0, mod, (B, N), dtype=torch.int32, device=dev).to(torch.int16)
+    b = torch.randint(0, mod, (B, N), dtype=torch.int32, device=dev).to(torch.int16)
+    quot = torch.empty_like(a); rem = torch.empty_like(a)
+    for _ in range(2):
+        eng.polymul_split_dev(N, mod, a.data_ptr(), b.data_ptr(), B, quot.data_ptr(), rem.data_ptr())
+    torch.cuda.synchronize()
+    assert lib.ntru_debug_read_stamps_pi(buf.ctypes.data_as(C.c_void_p)) == 0
+    st = buf[:768, :2].astype(np.int64)          # 6 workgroups per CU x 256 CUs > 1024: the first 768 workgroups, both waves
+    print("== k_polymul_m, N = %d, modulus %d (%s), kernel %s" % (N, mod, "one digit plane" if mod <= 256 else "two digit planes: three plane products", eng.last_kernel()))
+    for it in (2, 3, 4):
+        row = []
+        for x, y, lab in labels:
+            d = st[:, :, it, y] - st[:, :, it, x]
+            d = d[(st[:, :, it, x] > 0) & (st[:, :, it, y] > 0)]
+            row.append("%s %d" % (lab, int(np.median(d)) if d.size else -1))
+        tot = st[:, :, it + 1, 0] - st[:, :, it, 0]
+        print(" item", it, "|", " | ".join(row), "| whole item", int(np.median(tot[tot > 0])))
