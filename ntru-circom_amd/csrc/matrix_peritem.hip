@@ -220,9 +220,12 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       r_fq = PI_LOAD(2, s_fq, s_fq.a0 + 32 * lane); r_f = PI_LOAD(1, s_f, s_f.a0 + 16 * lane);
     }
   }
+  [[maybe_unused]] int stamp_iter = -1;                    // -DNTRU_STAMPS: phase stamps of the first items (tools/phase_stamps_peritem.py)
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
     const long row = item * N, left = (B - item) * N;
     u32 fl = 0;
+    stamp_iter++;
+    STAMP(0);
     // Every operand row is requested ahead of its use (rows at any alignment: aligned chunks + a wave-uniform byte shift at
     // use): fq, f and fp during the previous item, g and fq again (an L2 hit) before product 2, h before product 3.  A fetch
     // right where each product needs it left the wave idle for a round trip to HBM three times per item.
@@ -265,8 +268,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
       wave_lds_fence();
     }
+    STAMP(1);                                                             // product 1: operands in LDS (array of f, digit planes of fq)
     v16i L0, L1, H0, H1;
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    STAMP(2);                                                             // ... its matrix loops
     const RawChunks<1> r_fp = PI_LOAD(1, s_fp, s_fp.a0 + 16 * lane);     // product 2's operand: it has product 1's epilogue to arrive
     {
       // stores through one-row descriptors: index k = 32 kb + r is a per-lane offset (128 hh + r) plus a compile-time
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
     }
     wave_lds_fence();
+    STAMP(3);                                                             // ... its epilogue
     // ---- product 2: fp * f mod p (index.js:161-163): the array of f serves again, one plane of fp mod 3
     {
       const v4i vfp = bytes_of(r_fp, s_fp);
@@ -299,7 +305,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     wave_lds_fence();
     r_fq = PI_LOAD(2, s_fq, s_fq.a0 + 32 * lane);                           // for product 3, in flight during product 2
     const RawChunks<1> r_g = PI_LOAD(1, s_g, s_g.a0 + 16 * lane);
+    STAMP(4);                                                             // product 2: operand in LDS
     pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    STAMP(5);
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
       bool nz_hi = false, first_not_one = false;
@@ -319,6 +327,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
     }
     wave_lds_fence();
+    STAMP(6);
     // ---- product 3: ((p fq) mod q) * g mod q, compared with h below its trimmed length (index.js:155,164-166)
     {
       u32 xq[8];
@@ -336,7 +345,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     // h is requested before the product whose remainder it is compared with, as a row chunk (16 coefficients per lane);
     // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
     const AlignedSrc s_h = aligned_src(h + row, 2 * left);
+    STAMP(7);                                                             // product 3: operands in LDS (array of g, digit planes of p fq)
     pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    STAMP(8);
     const RawChunks<2> r_h = PI_LOAD(2, s_h, s_h.a0 + 32 * lane);          // (after the loop: its 9 registers are the loop's operand sets)
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
@@ -383,6 +394,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
     wave_lds_fence();
+    STAMP(9);                                                             // product 3's epilogue and the comparison with h
   }
 }
 

@@ -17,6 +17,33 @@ N, B = 821, 1 << 16
 buf = np.zeros((1024, 8, 6, 24), np.uint64)
 labels = [(0, 1, "operands arrive + shift"), (1, 2, "digit planes"), (2, 3, "reversed arrays"), (3, 4, "chunk matrices + fence"),
           (4, 5, "matrix loops"), (5, 6, "result stores issued + fence")]
+def show(name, st, labels, last):
+    print("==", name)
+    for it in (2, 3, 4):
+        row = []
+        for x, y, lab in labels:
+            d = st[:, :, it, y] - st[:, :, it, x]
+            d = d[(st[:, :, it, x] > 0) & (st[:, :, it, y] > 0)]
+            row.append("%s %d" % (lab, int(np.median(d)) if d.size else -1))
+        tot = st[:, :, it + 1, 0] - st[:, :, it, 0]
+        print(" item", it, "|", " | ".join(row), "| whole item", int(np.median(tot[tot > 0])))
+
+# k_verify_keys_m on synthetic per-item keys (values do not matter for the timeline)
+Bk, q = 1 << 16, 4096
+kf = torch.randint(-1, 2, (Bk, N), dtype=torch.int8, device=dev); kg = torch.randint(-1, 2, (Bk, N), dtype=torch.int8, device=dev)
+kfq = torch.randint(0, q, (Bk, N), dtype=torch.int32, device=dev).to(torch.int16); kfp = torch.randint(0, 3, (Bk, N), dtype=torch.uint8, device=dev)
+kh = torch.randint(0, q, (Bk, N), dtype=torch.int32, device=dev).to(torch.int16)
+o16 = [torch.empty((Bk, N), dtype=torch.int16, device=dev) for _ in range(4)]; o8 = [torch.empty((Bk, N), dtype=torch.uint8, device=dev) for _ in range(2)]
+fl = torch.empty(Bk, dtype=torch.uint8, device=dev)
+for _ in range(2):
+    eng.verify_keys_batch_dev(N, q, 3, kf.data_ptr(), kg.data_ptr(), kfq.data_ptr(), kfp.data_ptr(), kh.data_ptr(), Bk, o16[0].data_ptr(), o16[1].data_ptr(),
+                              o8[0].data_ptr(), o8[1].data_ptr(), o16[2].data_ptr(), o16[3].data_ptr(), fl.data_ptr())
+torch.cuda.synchronize()
+assert lib.ntru_debug_read_stamps_pi(buf.ctypes.data_as(C.c_void_p)) == 0
+show("k_verify_keys_m, N = %d, q = %d (%s)" % (N, q, eng.last_kernel()), buf[:768, :2].astype(np.int64),
+     [(0, 1, "P1 operands -> LDS"), (1, 2, "P1 loops (2 planes)"), (2, 3, "P1 epilogue"), (3, 4, "P2 operand -> LDS"), (4, 5, "P2 loops (1 plane)"),
+      (5, 6, "P2 epilogue"), (6, 7, "P3 operands -> LDS"), (7, 8, "P3 loops (2 planes)"), (8, 9, "P3 epilogue + h")], 9)
+
 for mod in (16, 4096):
     a = torch.randint(0, mod, (B, N), dtype=torch.int32, device=dev).to(torch.int16)
     b = torch.randint(0, mod, (B, N), dtype=torch.int32, device=dev).to(torch.int16)
