@@ -17,6 +17,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "ntru_engine.h"
@@ -95,8 +96,13 @@ NTRU_HIDDEN int ntru_scratch_release(ntru_engine *eng);
 
 static inline int fail(int code, const std::string &msg) { return ntru_fail(code, msg); }
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-static inline dim3 elementwise_grid(const ntru_engine *eng, long total) {
-  long blocks = (total + 255) / 256, cap = (long)eng->cus * 8;
+// Workgroups of 256 for an elementwise kernel.  Kernels that move 16 bytes per lane and access (streaming = true) get TWO per CU: more
+// resident waves lower the HBM rate (the add of two ciphertext batches: 5.0 TB/s with 8 per CU, 5.9 with 2, 4.8 with 1:
+// profiles/r03_ab_elementwise_grid.txt); element-per-lane kernels keep 8.  NTRU_EW_PER_CU overrides the streaming figure (experiments).
+static inline dim3 elementwise_grid(const ntru_engine *eng, long total, bool streaming = false) {
+  static const int ew_env = getenv("NTRU_EW_PER_CU") ? atoi(getenv("NTRU_EW_PER_CU")) : 0;
+  const int per_cu = streaming ? (ew_env > 0 ? ew_env : 2) : 8;
+  long blocks = (total + 255) / 256, cap = (long)eng->cus * per_cu;
   return dim3((unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks)));
 }
 // (N, q, B) of the packed kernels: q a power of two <= 65536, 2 <= N <= NTRU_MAX_N

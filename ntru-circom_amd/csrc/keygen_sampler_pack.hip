@@ -366,9 +366,13 @@ __global__ void k_signed_to_u16(const int8_t *__restrict__ f, long n, u32 q, u16
   }
 }
 // one Newton round of polyInv (index.js:499-506): v <- (2 v - u) mod q, u = f * v * v
-__global__ void k_newton_combine(u16 *__restrict__ v, const u16 *__restrict__ u, long n, u32 q) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+__global__ void k_newton_combine(u16 *__restrict__ v, const u16 *__restrict__ u, long first, long n, u32 q) {
+  for (long i = first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     v[i] = (u16)((2u * v[i] - u[i]) & (q - 1));
+}
+__global__ void k_newton_combine_vec(u16x8 *__restrict__ v, const u16x8 *__restrict__ u, long nvec, u32 q) {   // 16 bytes per lane
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x)
+    v[i] = ((u16)2 * v[i] - u[i]) & (u16)(q - 1);                        // q | 2^16: wrapped 16-bit arithmetic is exact mod q
 }
 
 // ---- BN254 field-element packing (index.js:572-620): elementwise, HBM-bound ---------------------------------------
@@ -444,10 +448,10 @@ extern "C" int ntru_add_batch_dev(ntru_engine_t *eng, int N, int mod, const uint
   const long nvec = aligned ? total / 8 : 0;
   if (nvec) {
     if (is_pow2(mod))
-      hipLaunchKernelGGL(k_add_mod_vec<true>, elementwise_grid(eng, nvec), dim3(256), 0, eng->stream, (u32)mod,
+      hipLaunchKernelGGL(k_add_mod_vec<true>, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u32)mod,
                          (const u16x8 *)d_a, (const u16x8 *)d_b, nvec, (u16x8 *)d_out);
     else
-      hipLaunchKernelGGL(k_add_mod_vec<false>, elementwise_grid(eng, nvec), dim3(256), 0, eng->stream, (u32)mod,
+      hipLaunchKernelGGL(k_add_mod_vec<false>, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u32)mod,
                          (const u16x8 *)d_a, (const u16x8 *)d_b, nvec, (u16x8 *)d_out);
   }
   if (nvec * 8 < total)
@@ -530,8 +534,14 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
           if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, (const uint16_t *)t.p, d_f + o * N, (long)n, nullptr, (uint16_t *)u.p)) return rc;
         } else if (int rc = ntru_polymul_split_dev(eng, N, mr, (const uint16_t *)f16.p, (const uint16_t *)t.p, n,
                                                    (uint16_t *)qs.p, (uint16_t *)u.p)) return rc;
-        hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, (u16 *)v,
-                           (const u16 *)u.p, (long)(n * N), (u32)mr);
+        {
+          const long tot = (long)(n * N);
+          const long nvec = ((((unsigned long long)v | (unsigned long long)u.p) & 15) == 0) ? tot / 8 : 0;
+          if (nvec) hipLaunchKernelGGL(k_newton_combine_vec, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u16x8 *)v,
+                                       (const u16x8 *)u.p, nvec, (u32)mr);
+          if (nvec * 8 < tot) hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, tot - nvec * 8), dim3(256), 0, eng->stream, (u16 *)v,
+                                                 (const u16 *)u.p, nvec * 8, tot, (u32)mr);
+        }
       }
       HIP_TRY(hipGetLastError());                          // the next chunk reuses the temporaries in stream order
     }
