@@ -46,7 +46,7 @@ def parse_args(argv=None):
                     help="witness: every array the reference returns; value: ciphertext / plaintext only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix", "lockstep", "rolesplit", "chunk", "dma", "lockstep-encrypt"], default="auto",
+    ap.add_argument("--kernel-path", choices=["auto", "mac", "add", "matrix", "lockstep", "rolesplit", "chunk", "dma", "lockstep-encrypt", "rowimage"], default="auto",
                     help="kernel family: packed-u16 MAC, ternary add path, matrix cores as two workgroups per CU / with the lock-step "
                          "decrypt, or the engine's choice (same results); rolesplit, chunk, dma, lockstep-encrypt need the library "
                          "built with `make experiments` (NTRU_ENGINE_LIB)")
@@ -344,7 +344,7 @@ def main():
             raise SystemExit("bench: --sample-r writes dense rows; use it with --row-pitch 0")
         eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
         torch.cuda.synchronize()
-    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4, "lockstep": 5, "rolesplit": 6, "chunk": 7, "dma": 8, "lockstep-encrypt": 9}[args.kernel_path])
+    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4, "lockstep": 5, "rolesplit": 6, "chunk": 7, "dma": 8, "lockstep-encrypt": 9, "rowimage": 10}[args.kernel_path])
 
     names = {}
 

@@ -157,7 +157,7 @@ static const int kMaxKernelPath = 5;
 
 extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
-  if (path < 0 || path > kMaxKernelPath)
+  if (path < 0 || (path > kMaxKernelPath && path != 10))
     return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8), 4 (matrix cores, two workgroups per CU) or "
                               "5 (matrix cores, lock-step decrypt); 6 (role-split encrypt), 7 (chunked encrypt stores), 8 (direct-to-LDS decrypt) "
                               "and 9 (lock-step encrypt) exist only in a library built with -DNTRU_EXPERIMENTS (make experiments)");
@@ -201,6 +201,10 @@ extern "C" int ntru_encrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
   if (B == 0) return NTRU_OK;
   if (!d_h || !d_r || !d_m || !d_e) return fail(NTRU_ERR_ARG, "ntru_encrypt_batch: NULL buffer");
   HIP_TRY(hipSetDevice(eng->device));
+  if (eng->path == 10) {                                       // row-image kernel (matrix_rowimage.hip) where it applies
+    const int rcw = ntru_launch_encrypt_rowimage(eng, N, q, ld, d_h, d_r, d_m, B, d_e, d_quotE);
+    if (rcw != NTRU_NOT_TAKEN) return rcw;
+  }
   const int rc = ntru_launch_encrypt_matrix(eng, N, q, ld, d_h, d_r, d_m, B, d_e, d_quotE);      // shared key: batch x Toeplitz on the matrix cores
   if (rc != NTRU_NOT_TAKEN) return rc;
   if (ld != N) return fail(NTRU_ERR_UNSUPPORTED, kPitchedOnly);

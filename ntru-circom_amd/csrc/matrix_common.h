@@ -90,16 +90,21 @@ static __device__ __forceinline__ v4i and4(v4i a, const u32 (&m)[4]) {
 // One strip of NT_S column tiles starting at tile kb0, all 32 rows of the staged row block.  st0 / st1: this lane's
 // row of the operand stage(s) (+ 16 bytes for the upper half-wave); tb0 / tb1: this lane's fragment bases.
 struct NoPause { __device__ __forceinline__ void operator()() const {} };
+// diag(u): called once per sub-step u (0 .. NT_S-1; a constant once the block is unrolled) of the strip's DIAGONAL block, which every strip runs
+// exactly once per product at a position that differs from wave to wave (contraction step kb0).  The row-image kernels
+// (matrix_rowimage.hip) drain the previous row block's result images there: work with compile-time register indices, spread over
+// the loop by the waves' different diagonals.
+struct NoDiag { __device__ __forceinline__ void operator()(int) const {} };
 // pause / pause_ib: pause() is called exactly once, before the first contraction step ib >= pause_ib is touched (at a
 // block boundary, so possibly a few steps early; after the loops when no such step exists).  The role-split decrypt
 // kernel waits there for the operand columns that are still being produced.
-template <int MODE, int NT_S, class Epi, class Pause = NoPause>
+template <int MODE, int NT_S, class Epi, class Pause = NoPause, class Diag = NoDiag>
 static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__restrict__ st0,
                                                       const unsigned char *__restrict__ st1,
                                                       const u32 *__restrict__ tb0, const u32 *__restrict__ tb1,
                                                       const MGeom &g, int kb0, const u32 (&mlow)[4], Epi epi,
                                                       int stamp_iter = 0, int stamp_base = 0, int pause_ib = 0x7fffffff,
-                                                      Pause pause = Pause()) {
+                                                      Pause pause = Pause(), Diag diag = Diag()) {
 #ifndef NTRU_ABLATE
 #define NTRU_ABLATE 0
 #endif
@@ -173,8 +178,11 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     for (int u = 0; u < NT_S; u++) {
       v4i n0, n1;
       load_a(ib + u + 1, n0, n1);
+      // Tile 0 works on the fragment that was requested at the end of the sub-step before (slot (NT_S - u) % NT_S): it goes LAST, so
+      // that the read has the other tiles' matrix instructions to land behind (as the first it exposed an LDS round trip per sub-step).
 #pragma unroll
-      for (int t = 0; t < NT_S; t++) {
+      for (int tt = 1; tt <= NT_S; tt++) {
+        const int t = tt % NT_S;
         constexpr int K = decltype(kind)::value;
         const int sl = (t - u + NT_S) % NT_S;
         if (K == 0 || (K == 2 && t > u)) mm(accL[t], a0, a1, W0[sl], W1[sl]);
@@ -185,6 +193,7 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
         }
       }
       load_w(kb0 - (ib + u + 1), W0[(NT_S - 1 - u) % NT_S], W1[(NT_S - 1 - u) % NT_S]);
+      if (decltype(kind)::value == 2) diag(u);
       a0 = n0; a1 = n1;
     }
   };

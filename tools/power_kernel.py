@@ -1,0 +1,38 @@
+# Socket power / shader clock while ONE kernel runs back to back for a few seconds (hwmon sampling as in bench.py):
+#   python tools/power_kernel.py encrypt|decrypt PATH [PATH ...]
+import importlib, sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+pkg = importlib.import_module('ntru-circom_amd')
+dev = torch.device('cuda:0')
+eng = pkg.Engine(0)
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+what = sys.argv[1]
+N, q, p, B = 821, 4096, 3, 1 << 20
+g = torch.Generator(device=dev); g.manual_seed(1)
+r = torch.randint(0, 3, (B, N), dtype=torch.uint8, device=dev, generator=g)
+m = torch.randint(0, 2, (B, N), dtype=torch.uint8, device=dev, generator=g)
+h = torch.randint(0, q, (N,), dtype=torch.int32, device=dev, generator=g).to(torch.int16)
+f = (torch.randint(0, 3, (N,), device=dev, generator=g) - 1).to(torch.int8)
+fp = torch.randint(0, 3, (N,), dtype=torch.uint8, device=dev, generator=g)
+e = torch.randint(0, q, (B, N), dtype=torch.int32, device=dev, generator=g).to(torch.int16); qe = torch.empty_like(e)
+v = torch.empty((B, N), dtype=torch.uint8, device=dev); q2 = torch.empty_like(v); q1 = torch.empty_like(e); r1 = torch.empty_like(e)
+e2 = torch.empty_like(e)
+def call():
+    if what == 'encrypt':
+        eng.encrypt_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e2.data_ptr(), qe.data_ptr())
+    else:
+        eng.decrypt_batch_dev(N, q, p, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr(), q1.data_ptr(), r1.data_ptr(), q2.data_ptr())
+for path in [int(x) for x in sys.argv[2:]]:
+    eng.set_kernel_path(path)
+    for _ in range(3): call()
+    torch.cuda.synchronize()
+    sampler = bench.PowerSampler(bench.device_sysfs_dir(0)); sampler.start()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 3.0:
+        for _ in range(50): call(); n += 1
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    pw = sampler.summary(t0, t1)
+    print('path %2d %-14s %.3f ms  %.0f W  %.0f MHz  -> %.2f J per launch (%.2f J above 300 W)' % (path, eng.last_kernel(), (t1 - t0) / n * 1e3, pw['socket_W'], pw['sclk_MHz'],
+          pw['socket_W'] * (t1 - t0) / n, (pw['socket_W'] - 300) * (t1 - t0) / n), flush=True)
