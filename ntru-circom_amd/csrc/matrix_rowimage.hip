@@ -10,18 +10,25 @@
 // 16-byte boundaries of LDS are 16-byte boundaries of global memory -- and copy it out flat: one ds_read_b128 + one
 // buffer_store_dwordx4 per 16 bytes, the (at most two) partial pieces at the ends of the run as 2-byte stores.
 //
-// How it fits.  An image of one uint16 array is 52.5 KB at N = 821; two of them + the operand stage + the key arrays leave room for ONE
-// row block per CU.  So: one workgroup of EIGHT waves per CU, every wave one strip of <= 4 column tiles (all 26 tiles in one round),
-// and the copy-out of row block k runs INSIDE the matrix loops of row block k + 1: each wave drains its share of the pieces in the
-// sub-steps of its strip's diagonal block (compile-time register indices; the eight diagonals sit at eight different contraction
-// steps, so the stores are spread over the loop).  The epilogue shrinks to one add and two ds_write_b16 per accumulator element
-// (the raw 16-bit low + high and high); "mod q", the negation and the plaintext add are packed 16-bit operations on the 8 elements
-// of a piece at drain time (the plaintext bytes of a piece are 8 consecutive bytes of m, requested a whole loop ahead).
-// Per row block: barrier (images + stage complete) -> loops [drain previous images; next r rows requested into registers]
-// -> barrier (stage and images free) -> epilogue into the images, next r rows into the stage.
-// Dense rows only (ld == N) and 2-byte aligned result arrays; everything else takes the kernels of matrix_encrypt.hip.
+// How it fits.  The image of a row block (one dword per element: low + high | high << 16, both result arrays come out of it) is
+// 105 KB at N = 821; with the operand stage and the key arrays that leaves room for ONE row block per CU.  So: one workgroup of
+// EIGHT waves per CU, every wave one strip of <= 4 column tiles (all 26 tiles in one round), and the copy-out of row block k runs
+// INSIDE the matrix loops of row block k + 1: each wave drains its share of the pieces in the sub-steps of its strip's diagonal
+// block (compile-time register indices; the eight diagonals sit at eight different contraction steps, so the stores are spread
+// over the loop).  The epilogue shrinks to one add, one v_perm and one ds_write_b32 per accumulator element; "mod q", the negation
+// and the plaintext add are packed 16-bit operations on the 8 elements of a piece at drain time (the plaintext bytes of a piece
+// are 8 consecutive bytes of m, requested a whole loop ahead).
+// Per row block: barrier (image + stage complete) -> loops [drain the previous image; next r rows requested into registers]
+// -> barrier (stage and image free) -> epilogue into the image, next r rows into the stage.
+// Dense rows only (ld == N), 2-byte aligned result arrays that share their 16-byte phase; everything else takes matrix_encrypt.hip.
+//
+// MEASURED (profiles/r04_rowimage_encrypt.txt): bit-exact, and exactly as fast as k_encrypt_md (1.50 against 1.51 ms per 2^20 at
+// N = 821; 1.58 against 1.58 ms in a sustained loop) at exactly the same energy (1.74 J dynamic per launch, both at the 1400 W cap):
+// inside a kernel the store pattern does not change what an HBM byte costs.  Kept as an experiment (kernel path 10 of a library built
+// with -DNTRU_EXPERIMENTS); -DRI_ABL=bits builds timing-only variants of it (1 no drain, 2 drain without stores, 4 no image writes).
 #include "matrix_common.h"
 
+#ifdef NTRU_EXPERIMENTS
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 constexpr int RI_WAVES = 8, RI_THREADS = RI_WAVES * 64;
@@ -258,11 +265,16 @@ __global__ __launch_bounds__(RI_THREADS, 2) void k_encrypt_w(MGeom g, u32 q, con
 
 NTRU_STAMPS_READER(ntru_debug_read_stamps_rowimage)
 
+#endif   // NTRU_EXPERIMENTS
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
-// Kernel path 10 (and auto-selection where it applies): dense rows, 2-byte aligned result arrays, N <= 1024 columns in 8 strips
+// Kernel path 10 of a -DNTRU_EXPERIMENTS library: dense rows, 2-byte aligned result arrays, N <= 1024 columns in 8 strips
 // of <= 4 tiles, images + stage + key arrays within 160 KB of LDS.
 int ntru_launch_encrypt_rowimage(ntru_engine *eng, int N, int q, int ld, const uint16_t *d_h, const uint8_t *d_r, const uint8_t *d_m,
                                  int64_t B, uint16_t *d_e, uint16_t *d_quotE) {
+#ifndef NTRU_EXPERIMENTS
+  return NTRU_NOT_TAKEN;
+#else
   MGeom mg;
   if (ld != N || !make_mgeom(eng, N, q, ld, &mg)) return NTRU_NOT_TAKEN;
   if (((uintptr_t)d_e & 1) != 0 || (d_quotE && (((uintptr_t)d_e ^ (uintptr_t)d_quotE) & 15) != 0) || mg.NT > 4 * RI_WAVES) return NTRU_NOT_TAKEN;
@@ -275,4 +287,5 @@ int ntru_launch_encrypt_rowimage(ntru_engine *eng, int N, int q, int ld, const u
   hipLaunchKernelGGL(k_encrypt_w, grid, dim3(RI_THREADS), lds, eng->stream, mg, (u32)q, d_h, d_r, d_m, (long)B, d_e, d_quotE);
   HIP_TRY(hipGetLastError());
   return NTRU_OK;
+#endif
 }

@@ -16,6 +16,9 @@ int ntru_launch_encrypt_matrix(ntru_engine *eng, int N, int q, int ld, const uin
   fake_enqueue(eng->stream, [=] { fake_encrypt(N, q, d_h, d_r, d_m, B, d_e, d_quotE); });
   return NTRU_OK;
 }
+int ntru_launch_encrypt_rowimage(ntru_engine *, int, int, int, const uint16_t *, const uint8_t *, const uint8_t *, int64_t, uint16_t *, uint16_t *) {
+  return NTRU_NOT_TAKEN;
+}
 int ntru_launch_encrypt_valu(ntru_engine *, int, int, const uint16_t *, const uint8_t *, const uint8_t *, int64_t, uint16_t *, uint16_t *) {
   return ntru_fail(NTRU_ERR_UNSUPPORTED, "fake device: matrix launcher only");
 }

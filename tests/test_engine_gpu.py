@@ -257,7 +257,7 @@ def test_kernel_families_agree(eng):
                                    (1021, 4096, 300), (1022, 2048, 300), (1023, 8192, 300), (1024, 8192, 300)])
 @pytest.mark.parametrize("path", [4, 5] + EXPERIMENT_PATHS)
 def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
-    """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step decrypt; 6-9: the variants of the experiments build), including sizes the
+    """Family 4 forced (ntru_engine_set_kernel_path 4: two workgroups per CU; 5: lock-step decrypt; 6-10: the variants of the experiments build), including sizes the
     automatic choice leaves to other families, batches that do not fill a 32-row block, and h at the corners of the
     digit-plane range."""
     rng = np.random.default_rng(N * 31 + q)
@@ -276,7 +276,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: dma, 6: ("k_encrypt_m2",),
                                          7: ("k_encrypt_mc",) if two_groups_fit else dma, 8: dma,
-                                         9: ("k_encrypt_m8",)}[path]                       # (two encrypt groups fit 160 KB at every N <= 1024)
+                                         9: ("k_encrypt_m8",), 10: ("k_encrypt_w",) + dma}[path]           # (two encrypt groups fit 160 KB at every N <= 1024)
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -318,7 +318,8 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_md", "k_encrypt_m"), 6: ("k_encrypt_m2",),
                                          7: ("k_encrypt_mc", "k_encrypt_md", "k_encrypt_m"), 8: ("k_encrypt_md", "k_encrypt_m"),
-                                         9: ("k_encrypt_m8", "k_encrypt_md", "k_encrypt_m")}[path]
+                                         9: ("k_encrypt_m8", "k_encrypt_md", "k_encrypt_m"),
+                                         10: ("k_encrypt_w", "k_encrypt_md", "k_encrypt_m")}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
             ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])

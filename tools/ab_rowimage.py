@@ -24,7 +24,7 @@ def carve(nbytes_list, off):
 def check_encrypt():
     bad = 0
     for N, q in ((821, 4096), (701, 8192), (509, 2048), (167, 128), (64, 16), (255, 512), (257, 1024), (800, 4096)):
-        for B in (1, 31, 32, 33, 500, 8195):
+        for B in (1, 31, 32, 33, 500, 8195, 32 * 256 * 3 + 5):
             for off in (0, 2, 6, 14):
                 g = torch.Generator(device=dev); g.manual_seed(N * 7 + B + off)
                 r = torch.randint(0, 3, (B, N), dtype=torch.uint8, device=dev, generator=g)
