@@ -2,6 +2,7 @@
 """Headline benchmark: NTRU encrypt+decrypt round trips per second at N=821, q=4096 (BASELINE.json).
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --workload {roundtrip,encrypt_n701,verify_keys} ...   (BASELINE.json configs 3 [default], 4 and 5, same launcher)
   python bench.py --gpus N --steps K --warmup W          (no RANK in the environment: bench.py starts the N ranks itself, as
                                                           a CHILD `python -m torch.distributed.run`, before anything touches HIP)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -35,13 +36,25 @@ DOT8_PEAK_T = 302.0            # measured v_dot8_u32_u4 roof: 37.9 T lane-instr/
 ADD_PEAK_T = 134.0             # measured v_add_u32 roof 67 T lane-adds/s x 2 packed 16-bit coefficients per add
 
 
+# BASELINE.json configs that have a multi-rank entry point here; per-GPU batch sizes (weak scaling)
+WORKLOADS = {
+    "roundtrip": {"profile": "n821_q4096", "batch_log2": 20},
+    "encrypt_n701": {"profile": "n701_q8192", "batch_log2": 20},
+    "verify_keys": {"profile": "n821_q4096", "batch_log2": 18},
+}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-log2", type=int, default=20, help="round trips per GPU per step (2^k)")
-    ap.add_argument("--profile", default="n821_q4096", help="golden key / parameter set under tests/golden")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="roundtrip",
+                    help="roundtrip: BASELINE.json's metric (config 3: N=821 q=4096 encryptBits + decryptBits); encrypt_n701: config 4 "
+                         "(N=701 q=8192 encryptBits, 2^20 per GPU); verify_keys: config 5 (N=821 verifyKeysInputs with per-item keys, "
+                         "2^18 per GPU)")
+    ap.add_argument("--batch-log2", type=int, default=None, help="items per GPU per step (2^k); default: the workload's")
+    ap.add_argument("--profile", default=None, help="golden key / parameter set under tests/golden; default: the workload's")
     ap.add_argument("--mode", choices=["witness", "value"], default="witness",
                     help="witness: every array the reference returns; value: ciphertext / plaintext only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
@@ -60,16 +73,23 @@ def parse_args(argv=None):
                     help="draw r with the engine's on-device sampler (generateCustomArray on a ChaCha20 stream) "
                          "instead of torch; the timed region is unchanged")
     ap.add_argument("--gather", action="store_true",
-                    help="after timing, gather the decrypted values of every rank onto rank 0 (one gather-to-root, RCCL over "
-                         "xGMI; with gloo through host memory); reported under `gather`")
+                    help="after timing, gather the workload's result rows of every rank onto rank 0 (one gather-to-root, RCCL over "
+                         "xGMI; with gloo through host memory); reported under `gather`.  Always on with more than one rank")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the timing all_reduce / barrier / gather even with ONE rank "
                          "(RCCL refuses two ranks on one device, so this is how the RCCL code path is exercised on a 1-GPU box)")
     ap.add_argument("--check-rows", type=int, default=1 << 14, help="rows of the batch verified against the CPU oracle")
-    ap.add_argument("--power-seconds", type=float, default=1.5,
-                    help="after the timed region, keep stepping for this long while socket power and shader clock are sampled "
-                         "from sysfs (reported under `power`; 0 = skip)")
-    return ap.parse_args(argv)
+    ap.add_argument("--power-seconds", type=float, default=6.0,
+                    help="LAST phase of the run: keep stepping for this long while socket power and shader clock are sampled "
+                         "from sysfs (reported under `power`; 0 = skip).  Several seconds, so that a coarse external GPU-activity "
+                         "sampler sees the GPU busy too")
+    args = ap.parse_args(argv)
+    w = WORKLOADS[args.workload]
+    if args.batch_log2 is None:
+        args.batch_log2 = w["batch_log2"]
+    if args.profile is None:
+        args.profile = w["profile"]
+    return args
 
 
 def launcher_command(args, argv, environ, port=None):
@@ -239,48 +259,70 @@ class PowerSampler(threading.Thread):
                 "samples": len(pw), "window_s": t1 - t0}
 
 
-def cpu_baseline(N, q, p, h, f, fp, r, m, seconds):
-    """Times the CPU oracle on this host: (a) reference-equivalent algorithm, 1 thread; (b) exact-integer, all
-    threads we may use.  Bounded sample of the same workload, scaled to round trips/s."""
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+GPU_SHARE_CORES = 16           # the pool's rule of thumb for worker pools next to ONE GPU; reported beside the all-cores figure
+
+
+def cpu_baseline(unit, n_rows, seconds, what):
+    """Times the CPU oracle on this host, on a bounded sample of the same workload, scaled to items/s:
+    (a) reference-equivalent algorithm (double FFT product + long division with per-step brute-force inverse), 1 thread;
+    (b) the same on GPU_SHARE_CORES threads and on EVERY core this process may use (measured, not assumed);
+    (c) exact-integer restatement on every core.  unit(rows, mode) runs the workload's CPU path on rows `rows` of the sample."""
     from oracle import ntru_oracle as orc
 
-    def rt(rows, mode):
-        e, _ = orc.encrypt_batch(N, q, h, r[rows], m[rows], mode)
-        orc.decrypt_batch(N, q, p, f, fp, e, mode)
+    unit(slice(0, 2), orc.FAITHFUL)
+    t0 = time.perf_counter(); unit(slice(0, 8), orc.FAITHFUL); per = (time.perf_counter() - t0) / 8
+    n = int(max(8, min(n_rows, seconds / max(per, 1e-9))))
+    t0 = time.perf_counter(); unit(slice(0, n), orc.FAITHFUL); dt = time.perf_counter() - t0
+    per = dt / n
+    faithful = {"value": n / dt, "unit": what + "/s", "cores": 1, "kind": "port",
+                "sample": "%d %s of the same workload, oracle in reference-equivalent mode (double FFT product + long division "
+                          "with per-step brute-force inverse), %.1f s" % (n, what, dt)}
+    avail = usable_cores()
 
-    rt(slice(0, 2), orc.FAITHFUL)
-    t0 = time.perf_counter(); rt(slice(0, 8), orc.FAITHFUL); per = (time.perf_counter() - t0) / 8
-    n = int(max(8, min(len(r), seconds / max(per, 1e-9))))
-    t0 = time.perf_counter(); rt(slice(0, n), orc.FAITHFUL); dt = time.perf_counter() - t0
-    faithful = {"value": n / dt, "unit": "round_trips/s", "cores": 1, "kind": "port",
-                "sample": "%d round trips of the same workload, oracle in reference-equivalent mode (double FFT "
-                          "product + long division with per-step brute-force inverse), %.1f s" % (n, dt)}
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, min(16, avail))                          # the GPU box's CPU share for one GPU is 16
-    # the same reference-equivalent algorithm on every core we may use (SURVEY.md 8d (i): "single thread and all cores")
-    per_thread = int(max(4, min(len(r) // threads, (seconds / 2) * faithful["value"])))
-    ths = [threading.Thread(target=rt, args=(slice(i * per_thread, (i + 1) * per_thread), orc.FAITHFUL))
-           for i in range(threads)]
-    t0 = time.perf_counter()
-    [t.start() for t in ths]; [t.join() for t in ths]
-    dt = time.perf_counter() - t0
-    faithful_all = {"value": threads * per_thread / dt, "unit": "round_trips/s", "cores": threads, "kind": "port",
-                    "sample": "%d round trips, oracle in reference-equivalent mode, %d threads (host has %d usable), %.1f s"
-                              % (threads * per_thread, threads, avail, dt)}
-    t0 = time.perf_counter(); rt(slice(0, 8), orc.EXACT); per = (time.perf_counter() - t0) / 8
-    per_thread = int(max(8, min(len(r) // threads, (seconds / 3) / max(per, 1e-9))))
-    ths = [threading.Thread(target=rt, args=(slice(i * per_thread, (i + 1) * per_thread), orc.EXACT))
-           for i in range(threads)]
-    t0 = time.perf_counter()
-    [t.start() for t in ths]; [t.join() for t in ths]
-    dt = time.perf_counter() - t0
-    optimized = {"value": threads * per_thread / dt, "unit": "round_trips/s", "cores": threads, "kind": "port",
-                 "sample": "%d round trips, oracle in exact-integer mode (schoolbook + closed-form split), "
-                           "%d threads, %.1f s" % (threads * per_thread, threads, dt)}
-    return faithful, faithful_all, optimized
+    def threaded(threads, mode, budget_s, per_item):
+        per_thread = int(max(2, min(n_rows // threads, budget_s / max(per_item, 1e-9))))
+        ths = [threading.Thread(target=unit, args=(slice(i * per_thread, (i + 1) * per_thread), mode)) for i in range(threads)]
+        t0 = time.perf_counter()
+        [t.start() for t in ths]; [t.join() for t in ths]
+        return threads * per_thread, time.perf_counter() - t0
+
+    share = max(1, min(GPU_SHARE_CORES, avail))
+    n_s, dt_s = threaded(share, orc.FAITHFUL, seconds / 4, per)
+    faithful_share = {"value": n_s / dt_s, "unit": what + "/s", "cores": share, "kind": "port",
+                      "sample": "%d %s, oracle in reference-equivalent mode, %d threads, %.1f s" % (n_s, what, share, dt_s)}
+    n_a, dt_a = threaded(avail, orc.FAITHFUL, seconds / 4, per)
+    faithful_all = {"value": n_a / dt_a, "unit": what + "/s", "cores": avail, "kind": "port",
+                    "sample": "%d %s, oracle in reference-equivalent mode, one thread per usable core (%d), %.1f s"
+                              % (n_a, what, avail, dt_a)}
+    t0 = time.perf_counter(); unit(slice(0, 8), orc.EXACT); per_x = (time.perf_counter() - t0) / 8
+    n_x, dt_x = threaded(avail, orc.EXACT, seconds / 6, per_x)
+    optimized = {"value": n_x / dt_x, "unit": what + "/s", "cores": avail, "kind": "port",
+                 "sample": "%d %s, oracle in exact-integer mode (schoolbook + closed-form split), %d threads, %.2f s"
+                           % (n_x, what, avail, dt_x)}
+    return faithful, faithful_share, faithful_all, optimized
+
+
+def hbm_roofline(kernel, bytes_per_item, items, ms, traffic, traffic_note, int8_macs_per_item=None):
+    """ALGORITHMIC bytes of one launch over its HIP-event time, against the 8 TB/s HBM3E roof; beside it the
+    algorithmic int8 rate (2 ops per MAC of the reference's products) against the dense int8 MFMA peak."""
+    s = ms * 1e-3
+    gbs = bytes_per_item * items / s / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": traffic_note, "algorithmic_bytes_per_item": bytes_per_item,
+         "algorithmic_bytes_per_launch": bytes_per_item * items, "ms_per_launch": ms}
+    if int8_macs_per_item:
+        tops = 2.0 * int8_macs_per_item * items / s / 1e12
+        r["int8"] = {"achieved": tops, "peak": MFMA_I8_PEAK_T, "unit": "TOP/s (int8)", "frac": tops / MFMA_I8_PEAK_T,
+                     "note": "algorithmic: 2 ops per multiply-accumulate of the reference's products (%d MACs per item), against the "
+                             "dense int8 MFMA peak" % int8_macs_per_item}
+    return r
 
 
 def main():
@@ -294,9 +336,12 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("NTRU_BENCH_ABLATION") == "1":
+        os.environ["NTRU_ALLOW_TIMING_ONLY"] = "1"  # tools/ablate.sh: the library under test is a timing-only build and says so
     import torch
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    from oracle import ntru_oracle as orc          # the checker and the cpu_baseline leg; never inside the timed region
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -324,92 +369,150 @@ def main():
     seed = sh.shard_seed(20240, rank)
     LD = N if args.row_pitch == 0 else ((N + 63) // 64 * 64 if args.row_pitch < 0 else args.row_pitch)
     pitched = LD != N
-    r, m = make_inputs(torch, dev, B, N, d, seed, LD)
-    h = torch.from_numpy(h_np.view(np.int16)).to(dev)
-    f = torch.from_numpy(f_np).to(dev)
-    fp = torch.from_numpy(fp_np).to(dev)
     witness = args.mode == "witness"
-    b16 = lambda: torch.empty((B, LD), dtype=torch.int16, device=dev)    # raw uint16 patterns
-    b8 = lambda: torch.empty((B, LD), dtype=torch.uint8, device=dev)
-    e, value = b16(), b8()
-    quotE, quot1, rem1, quot2 = (b16(), b16(), b16(), b8()) if witness else (None, None, None, None)
+    wl = args.workload
+    if wl != "roundtrip" and (pitched or args.sample_r or not witness):
+        raise SystemExit("bench: --row-pitch / --sample-r / --mode value belong to --workload roundtrip")
     ptr = lambda t: t.data_ptr() if t is not None else None
+    b16 = lambda n=B: torch.empty((n, LD), dtype=torch.int16, device=dev)    # raw uint16 patterns
+    b8 = lambda n=B: torch.empty((n, LD), dtype=torch.uint8, device=dev)
 
     eng = pkg.Engine(dev_index)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
-    if args.sample_r:
-        key = np.arange(8, dtype=np.uint32) * 0x9E3779B1 + 20240
-        if pitched:
-            raise SystemExit("bench: --sample-r writes dense rows; use it with --row-pitch 0")
-        eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
-        torch.cuda.synchronize()
-    eng.set_kernel_path({"auto": 0, "mac": 1, "add": 2, "matrix": 4, "lockstep": 5, "rolesplit": 6, "chunk": 7, "dma": 8, "lockstep-encrypt": 9, "rowimage": 10}[args.kernel_path])
-
+    path_no = {"auto": 0, "mac": 1, "add": 2, "matrix": 4, "lockstep": 5, "rolesplit": 6, "chunk": 7, "dma": 8, "lockstep-encrypt": 9,
+               "rowimage": 10}[args.kernel_path]
     names = {}
+    to_u16 = lambda a: a.view(np.uint16) if a.dtype == np.int16 else a
 
-    bufs = (r, m, e, quotE, value, quot1, rem1, quot2)
+    # ---- the workload: device-resident inputs and outputs, step(ev), what is gathered, what the CPU does for one item --------
+    if wl in ("roundtrip", "encrypt_n701"):
+        r, m = make_inputs(torch, dev, B, N, d, seed, LD)
+        h = torch.from_numpy(h_np.view(np.int16)).to(dev)
+        f = torch.from_numpy(f_np).to(dev)
+        fp = torch.from_numpy(fp_np).to(dev)
+        if args.sample_r:
+            key = np.arange(8, dtype=np.uint32) * 0x9E3779B1 + 20240
+            if pitched:
+                raise SystemExit("bench: --sample-r writes dense rows; use it with --row-pitch 0")
+            eng.sample_ternary_dev(N, d, d, p - 1, key, rank * B, B, r.data_ptr())
+            torch.cuda.synchronize()
+        e = b16()
+        quotE = b16() if witness else None
+        if wl == "roundtrip":
+            value = b8()
+            quot1, rem1, quot2 = (b16(), b16(), b8()) if witness else (None, None, None)
+            bufs = (r, m, e, quotE, value, quot1, rem1, quot2)
+        else:
+            bufs = (r, m, e, quotE)
+        n_ev = 3 if wl == "roundtrip" else 2
 
-    def step(ev=None, bufs=bufs, ld=LD if pitched else None):
-        r_, m_, e_, qe_, v_, q1_, r1_, q2_ = bufs
-        if ev: ev[0].record(stream)
-        eng.encrypt_batch_dev(N, q, ptr(h), ptr(r_), ptr(m_), B, ptr(e_), ptr(qe_), ld=ld)
-        names["encrypt"] = eng.last_kernel()
-        if ev: ev[1].record(stream)
-        eng.decrypt_batch_dev(N, q, p, ptr(f), ptr(fp), ptr(e_), B, ptr(v_), ptr(q1_), ptr(r1_), ptr(q2_), ld=ld)
-        names["decrypt"] = eng.last_kernel()
-        if ev: ev[2].record(stream)
+        def step(ev=None, bufs=bufs, ld=LD if pitched else None):
+            if ev: ev[0].record(stream)
+            eng.encrypt_batch_dev(N, q, ptr(h), ptr(bufs[0]), ptr(bufs[1]), B, ptr(bufs[2]), ptr(bufs[3]), ld=ld)
+            names["encrypt"] = eng.last_kernel()
+            if ev: ev[1].record(stream)
+            if wl == "roundtrip":
+                eng.decrypt_batch_dev(N, q, p, ptr(f), ptr(fp), ptr(bufs[2]), B, ptr(bufs[4]), ptr(bufs[5]), ptr(bufs[6]), ptr(bufs[7]), ld=ld)
+                names["decrypt"] = eng.last_kernel()
+                if ev: ev[2].record(stream)
+
+        gather_src = lambda: value if wl == "roundtrip" else e.view(torch.uint8)
+        unit_name = "round_trips" if wl == "roundtrip" else "encrypts"
+
+        def cpu_unit_factory(n_cpu):
+            rr, mm = r[:n_cpu, :N].contiguous().cpu().numpy(), m[:n_cpu, :N].contiguous().cpu().numpy()
+
+            def unit(rows, mode):
+                e_c, _ = orc.encrypt_batch(N, q, h_np, rr[rows], mm[rows], mode)
+                if wl == "roundtrip":
+                    orc.decrypt_batch(N, q, p, f_np, fp_np, e_c, mode)
+            return unit
+    else:       # verify_keys: per-item operands.  2^18 TRUE key pairs would take the reference ~100 h, so the operands are synthetic
+        gk = torch.Generator(device=dev); gk.manual_seed(seed + 5)          # (SURVEY.md 8d config 5): every output is still defined
+        tern = lambda: (torch.randint(0, 3, (B, N), device=dev, generator=gk) - 1).to(torch.int8)
+        kf, kg = tern(), tern()
+        kfq = torch.randint(0, q, (B, N), device=dev, generator=gk).to(torch.int16)
+        kh = torch.randint(0, q, (B, N), device=dev, generator=gk).to(torch.int16)
+        kfp = torch.randint(0, p, (B, N), device=dev, generator=gk).to(torch.uint8)
+        kouts = [b16(), b16(), b8(), b8(), b16(), b16()]           # quotient / remainder of fq * f, fp * f, (p fq) * g
+        kflags = torch.empty(B, dtype=torch.uint8, device=dev)
+        n_ev = 2
+
+        def step(ev=None):
+            if ev: ev[0].record(stream)
+            eng.verify_keys_batch_dev(N, q, p, kf.data_ptr(), kg.data_ptr(), kfq.data_ptr(), kfp.data_ptr(), kh.data_ptr(), B,
+                                      *[t.data_ptr() for t in kouts], kflags.data_ptr())
+            names["verify_keys"] = eng.last_kernel()
+            if ev: ev[1].record(stream)
+
+        gather_src = lambda: kouts[5].view(torch.uint8)            # remainderI of the h case
+        unit_name = "key_pairs"
+
+        def cpu_unit_factory(n_cpu):
+            hs = [t[:n_cpu].contiguous().cpu().numpy() for t in (kf, kg, kfq, kfp, kh)]
+            hs[2], hs[4] = to_u16(hs[2]), to_u16(hs[4])
+
+            def unit(rows, mode):
+                orc.verify_keys_batch(N, q, p, hs[0][rows], hs[1][rows], hs[2][rows], hs[3][rows], hs[4][rows], mode)
+            return unit
+    eng.set_kernel_path(path_no)
+
+    # ---- CPU baseline FIRST (rank 0 at N = 1): the GPU phases then run back to back until the end of the process ----------------
+    out_cpu = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_cpu = max(4096, 64 * usable_cores())
+        n_cpu = min(n_cpu, B)
+        faithful, faithful_share, faithful_all, optimized = cpu_baseline(cpu_unit_factory(n_cpu), n_cpu, args.cpu_seconds, unit_name)
+        out_cpu = {"cpu_baseline": faithful, "cpu_baseline_gpu_share": faithful_share, "cpu_baseline_all_cores": faithful_all,
+                   "cpu_baseline_optimized": optimized}
 
     for _ in range(args.warmup):
         step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
 
     def run_steps():
         for k in range(args.steps):
             step(events[k])
 
     elapsed = sh.timed_region(run_steps, torch.cuda.synchronize, dist, red_dev, always=args.force_dist)
-    enc_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events]))
-    dec_ms = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in events]))
-
-    # ---- what limits the kernels: socket power against its cap and the shader clock, over a sustained run of the same steps
-    # (outside the timed region; the 40 ms of the timed steps are shorter than the driver's averaging window)
-    power = None
-    if rank == 0 and args.power_seconds > 0:
-        sampler = PowerSampler(device_sysfs_dir(dev_index))
-        sampler.start()
-        tp0 = time.perf_counter(); n_sus = 0
-        while time.perf_counter() - tp0 < args.power_seconds:
-            for _ in range(20):
-                step(); n_sus += 1
-            torch.cuda.synchronize()
-        tp1 = time.perf_counter()
-        power = sampler.summary(tp0, tp1)
-        if power:
-            power["sustained_ms_per_step"] = (tp1 - tp0) / n_sus * 1e3
-            power["note"] = ("encrypt + decrypt steps back to back; both kernels run against the socket power cap with the shader clock "
-                             "pulled below its 2.4 GHz top (profiles/r03_clock_power.txt, r03_power_ablations.txt)")
+    seg_ms = [float(np.mean([ev[i].elapsed_time(ev[i + 1]) for ev in events])) for i in range(n_ev - 1)]
 
     # ---- bit-exact check of a strided sample against the CPU oracle (outside the timed region): every output array ---
-    from oracle import ntru_oracle as orc
     n_chk = max(1, min(B, args.check_rows))
     rows = torch.tensor(sorted(set(list(range(0, B, max(1, B // n_chk))) + [B - 1])), device=dev)
-    host = lambda t: (lambda a: a.view(np.uint16) if a.dtype == np.int16 else a)(t[rows][:, :N].contiguous().cpu().numpy())
-    r_h, m_h = host(r), host(m)
-    got = {"e": host(e), "value": host(value)}
-    if witness:
-        got.update(quotE=host(quotE), quot1=host(quot1), rem1=host(rem1), quot2=host(quot2))
-    try:
-        n_thr = max(1, min(16, len(os.sched_getaffinity(0))))
-    except AttributeError:
-        n_thr = max(1, min(16, os.cpu_count() or 1))
-    bad = []
+    host = lambda t: to_u16(t[rows][:, :N].contiguous().cpu().numpy())
+    if wl in ("roundtrip", "encrypt_n701"):
+        ins = (host(r), host(m))
+        got = {"e": host(e)}
+        if witness:
+            got["quotE"] = host(quotE)
+        if wl == "roundtrip":
+            got["value"] = host(value)
+            if witness:
+                got.update(quot1=host(quot1), rem1=host(rem1), quot2=host(quot2))
+
+        def oracle_rows(lo, hi):
+            e_o, qe_o = orc.encrypt_batch(N, q, h_np, ins[0][lo:hi], ins[1][lo:hi])
+            want = {"e": e_o, "quotE": qe_o}
+            if wl == "roundtrip":
+                v_o, q1_o, r1_o, q2_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)
+                want.update(value=v_o, quot1=q1_o, rem1=r1_o, quot2=q2_o)
+            return want
+    else:
+        ins = tuple(host(t) for t in (kf, kg, kfq, kfp, kh))
+        knames = ("quot_fq", "rem_fq", "quot_fp", "rem_fp", "quot_h", "rem_h")
+        got = {n_: host(t) for n_, t in zip(knames, kouts)}
+        got["flags"] = kflags[rows].cpu().numpy()
+
+        def oracle_rows(lo, hi):
+            return orc.verify_keys_batch(N, q, p, *[a[lo:hi] for a in ins])
+    n_thr = max(1, min(GPU_SHARE_CORES, usable_cores()))
+    bad, done = [], []
 
     def check(lo, hi):
         try:
-            e_o, qe_o = orc.encrypt_batch(N, q, h_np, r_h[lo:hi], m_h[lo:hi])
-            v_o, q1_o, r1_o, q2_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)
-            want = {"e": e_o, "value": v_o, "quotE": qe_o, "quot1": q1_o, "rem1": r1_o, "quot2": q2_o}
+            want = oracle_rows(lo, hi)
             for k, a in got.items():
                 if not np.array_equal(a[lo:hi], want[k]):
                     bad.append(k)
@@ -417,23 +520,37 @@ def main():
         except BaseException as exc:        # a worker that dies must not read as "nothing differed"
             bad.append("check(%d, %d) raised %r" % (lo, hi, exc))
 
-    done = []
-    cuts = np.linspace(0, len(r_h), n_thr + 1).astype(int)
+    cuts = np.linspace(0, len(ins[0]), n_thr + 1).astype(int)
     ths = [threading.Thread(target=check, args=(int(cuts[i]), int(cuts[i + 1]))) for i in range(n_thr) if cuts[i] < cuts[i + 1]]
     [t.start() for t in ths]; [t.join() for t in ths]
-    if sum(done) != len(r_h) and not bad:
-        bad.append("only %d of %d rows were compared" % (sum(done), len(r_h)))
+    if sum(done) != len(ins[0]) and not bad:
+        bad.append("only %d of %d rows were compared" % (sum(done), len(ins[0])))
     ok = not bad
     ablation = bool(os.environ.get("NTRU_ENGINE_LIB")) and os.environ.get("NTRU_BENCH_ABLATION") == "1"
     if not ok and not ablation:
-        raise SystemExit("bench: GPU results differ from the oracle -- refusing to report a number")
+        raise SystemExit("bench: GPU results differ from the oracle (%s) -- refusing to report a number" % sorted(set(bad)))
 
-    gathered = None
-    if args.gather and dist:
-        # The final gather: every rank's decrypted values onto rank 0, once (gather-to-root; nccl = RCCL over xGMI, GPU
-        # memory to GPU memory; gloo = through host memory).  Outside the timed region; its time is reported, not hidden.
+    # ---- multi-rank evidence: who took part, and the final gather-to-root (outside the timed region) --------------------------
+    dist_info, gathered = None, None
+    if dist:
+        me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "pid": os.getpid(),
+              "pci_bus_id": os.path.basename(os.path.realpath(device_sysfs_dir(dev_index) or "?")),
+              "name": torch.cuda.get_device_name(dev_index)}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:                                   # noqa: BLE001 -- reporting only
+            rccl = None
+        dist_info = {"backend": args.dist_backend, "world": world, "rccl_version": rccl if args.dist_backend == "nccl" else None,
+                     "ranks": sorted(everyone, key=lambda x: x["rank"]),
+                     "timing": "barrier + synchronize on both sides of the K steps, all_reduce(MAX) of the ranks' seconds"}
+    if dist and (args.gather or world > 1):
+        # The final gather: every rank's result rows onto rank 0, once (gather-to-root; nccl = RCCL over xGMI, GPU
+        # memory to GPU memory; gloo = through host memory).  Its time is reported, not hidden.
         on_dev = args.dist_backend == "nccl"
-        local = value if on_dev else value.cpu()
+        src = gather_src()
+        local = src if on_dev else src.cpu()
         sums = sh.shard_checksums(local, dist, always=args.force_dist)
         torch.cuda.synchronize(); dist.barrier(); tg = time.perf_counter()
         allv = sh.gather_rows(local, dist, always=args.force_dist, root=0)
@@ -441,20 +558,24 @@ def main():
         if rank == 0:
             per = [sh.shard_checksums(allv[k * B:(k + 1) * B], None)[0].item() for k in range(world)]
             gathered = {"kind": "gather_to_root", "root": 0, "consumed_on": "GPU 0 (HBM)" if on_dev else "host memory of rank 0",
-                        "rows": int(allv.shape[0]), "bytes_per_rank": int(value.numel()), "seconds": tgather,
+                        "rows": int(allv.shape[0]), "bytes_per_rank": int(src.numel() * src.element_size()), "seconds": tgather,
                         "backend": args.dist_backend, "ranks": world,
-                        "rows_equal_local_shard": bool(torch.equal(allv[:B].to(value.device), value)),
+                        "rows_equal_local_shard": bool(torch.equal(allv[:B].to(src.device), src)),
                         "every_shard_checksum_matches_its_owner": per == [int(x) for x in sums.tolist()]}
             if not (gathered["rows_equal_local_shard"] and gathered["every_shard_checksum_matches_its_owner"]):
                 raise SystemExit("bench: gathered rows differ from what the ranks computed")
         del allv
 
+    out = None
     if rank == 0:
         total = world * B * args.steps
-        # algorithmic bytes per item of the dominant kernel (decrypt): SURVEY.md 8(d)
-        dec_bytes = (8 if witness else 3) * N
-        enc_bytes = (6 if witness else 4) * N
-        dec_gbs = dec_bytes * B / (dec_ms * 1e-3) / 1e9
+        common = {"value": total / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                  "data": "synthetic", "verified_bit_exact_rows": int(rows.numel()), "verified_arrays": sorted(got.keys())}
+        par = "batch-sharded x%d, no collective" % world
+    if rank == 0 and wl == "roundtrip":
+        enc_ms, dec_ms = seg_ms
+        dec_bytes, enc_bytes = (8 if witness else 3) * N, (6 if witness else 4) * N
         dec_s = dec_ms * 1e-3
         dname = names.get("decrypt", "k_decrypt")
         traffic, traffic_note = pmc_traffic(dname, args.mode, args.batch_log2)
@@ -466,13 +587,12 @@ def main():
             NT = (N + 31) // 32
             n_mfma = 3.0 * NT * (NT + 1) * ((B + 31) // 32)
             ops = 2.0 * 32768 * n_mfma
-            mfma = {"kernel": dname, "achieved": ops / dec_s / 1e12, "peak": MFMA_I8_PEAK_T, "unit": "TOP/s (int8, executed)",
-                    "frac": ops / dec_s / 1e12 / MFMA_I8_PEAK_T, "instructions_per_launch": n_mfma,
-                    "algorithmic_TOPs_per_s": 2.0 * 2.0 * N * N * B / dec_s / 1e12,
-                    "note": "v_mfma_i32_32x32x32_i8; peak = dense int8 (2x bf16, MI355X_MICROARCH.md); measured issue roof "
-                            "4400 TOP/s (profiles/r01_microbench_mfma_i8.txt); algorithmic = 2 N^2 MACs per decrypt"}
-            valu = {"kernel": dname, "achieved": mfma["achieved"], "peak": MFMA_I8_PEAK_T, "unit": mfma["unit"],
-                    "note": "see `mfma`"}
+            mfma = {"kernel": dname, "executed": ops / dec_s / 1e12, "peak": MFMA_I8_PEAK_T, "unit": "TOP/s (int8, executed)",
+                    "executed_frac": ops / dec_s / 1e12 / MFMA_I8_PEAK_T, "instructions_per_launch": n_mfma,
+                    "note": "v_mfma_i32_32x32x32_i8 instructions actually issued (three digit-plane products on a 32-padded tile grid, "
+                            "1.6x the algorithmic MACs): a utilisation figure, not a roofline fraction; = SQ_INSTS_MFMA of the PMC "
+                            "pass; the instruction's measured issue roof is 75.4 G/s = 4.94 POP/s (profiles/r03_clock_power.txt)"}
+            valu = {"kernel": dname, "note": "matrix-core path: see `mfma`"}
         elif "+dot8" in dname:
             # product 1 steps over f (adds), product 2 is all N^2 nibble MACs on v_dot8_u32_u4
             w1, w2 = float(np.count_nonzero(f_np)) * N * B, float(N) * N * B
@@ -483,7 +603,6 @@ def main():
                             "stepping product, v_dot8_u32_u4 302 T nibble-MAC/s for the dot8 product "
                             "(profiles/r01_microbench_valu_lds.txt); frac = ideal issue time / measured time"}
         elif add_path:
-            # work actually issued by the ternary add path: one packed coefficient-add per (non-zero step, output)
             nz_f = float(np.count_nonzero(f_np)) / N
             nz_b = 2.0 / 3.0                                  # the lifted message is ~uniform over {0,1,2}
             valu = {"kernel": dname, "achieved": (nz_f + nz_b) * N * N * B / dec_s / 1e12, "peak": ADD_PEAK_T,
@@ -494,48 +613,30 @@ def main():
         else:
             valu = {"kernel": dname, "achieved": 2.0 * N * N * B / dec_s / 1e12, "peak": PK_MAC_PEAK_T,
                     "unit": "T MAC/s", "note": "2*N^2 MACs per decrypt; peak = measured v_pk_mad_u16 issue roof"}
-        valu["frac"] = valu["achieved"] / valu["peak"]
-        # The HBM side (BASELINE.json asks for it on every line): algorithmic bytes of the dominant kernel over its HIP-event time.
-        hbm_roof = {"bound": "hbm", "kernel": dname, "achieved": dec_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                    "algorithmic_bytes_per_item": dec_bytes, "algorithmic_bytes_per_launch": dec_bytes * B}
-        if mfma:
-            # Matrix-core path: value-only decrypt writes 3N instead of 8N bytes and is only 25 % faster, so HBM is not what binds it;
-            # the executed int8 matrix rate is the primary roof, the HBM fraction stays beside it (roofline_hbm), and `power` says
-            # what actually limits both: the kernels run at the socket power cap.
-            roofline = {"bound": "mfma", "kernel": dname, "achieved": mfma["achieved"], "peak": MFMA_I8_PEAK_T, "unit": "TFLOP/s",
-                        "frac": mfma["frac"], "traffic": traffic, "traffic_source": traffic_note,
-                        "unit_note": "int8 TOP/s executed (2 x 32768 per v_mfma_i32_32x32x32_i8), against the dense int8 peak",
-                        "instructions_per_launch": mfma["instructions_per_launch"],
-                        "note": "measured issue roof of this instruction: 75.4 G/s = 4.94 POP/s at 2.38 GHz and 1160 W "
-                                "(profiles/r03_clock_power.txt); HBM side in roofline_hbm"}
-        else:
-            roofline = dict(hbm_roof, note="the path is VALU/scalar-issue bound (O(N^2) integer work on O(N) bytes); see `valu`")
-        valu["mac_equivalent_T_per_s"] = 2.0 * N * N * B / dec_s / 1e12
-        out = {
-            "metric": "NTRU encrypt+decrypt round trips per second at N=%d, q=%d" % (N, q),
-            "value": total / elapsed, "unit": "round_trips/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8" if mfma else "u16", "data": "synthetic",
+        if "achieved" in valu:
+            valu["frac"] = valu["achieved"] / valu["peak"]
+        # `roofline`: the dominant kernel (decrypt), ALGORITHMIC: 8N (3N value-only) bytes per item over its HIP-event time
+        # against 8 TB/s, with the algorithmic int8 rate (2 N^2 MACs per decrypt) beside it
+        roofline = hbm_roofline(dname, dec_bytes, B, dec_ms, traffic, traffic_note, 2 * N * N)
+        roofline["note"] = ("decrypt is the longer of the step's two kernels; what binds both is the 1400 W socket power cap (see `power` and "
+                            "profiles/r04_rowimage_encrypt.txt): their time is their energy over the cap")
+        out = dict(common)
+        out.update({
+            "metric": "NTRU encrypt+decrypt round trips per second at N=%d, q=%d" % (N, q), "unit": "round_trips/s",
+            "dtype": "i8" if mfma else "u16",
             "config": {"workload": "N=%d q=%d p=%d d=%d, batch=2^%d round trips per GPU per step, shared golden key, "
-                                   "%s outputs" % (N, q, p, d, args.batch_log2,
-                                                   "full-witness" if witness else "value-only"),
-                       "mode": args.mode, "kernel_path": args.kernel_path,
-                       "row_pitch_elements": LD,
-                       "arithmetic": "int8 digit planes on the matrix cores, int32 accumulation (exact)" if mfma else "exact u16 vector ALU", "seed": 20240, "r_source": "device sampler" if args.sample_r else "torch",
-                       "parallelism": "batch-sharded x%d, no collective" % world},
-            "verified_bit_exact_rows": int(rows.numel()),
-            "verified_arrays": sorted(got.keys()),
+                                   "%s outputs" % (N, q, p, d, args.batch_log2, "full-witness" if witness else "value-only"),
+                       "mode": args.mode, "kernel_path": args.kernel_path, "row_pitch_elements": LD,
+                       "arithmetic": "int8 digit planes on the matrix cores, int32 accumulation (exact)" if mfma else "exact u16 vector ALU",
+                       "seed": 20240, "r_source": "device sampler" if args.sample_r else "torch", "parallelism": par},
             "kernels_ms": {names.get("encrypt", "k_encrypt"): enc_ms, dname: dec_ms},
             "roofline": roofline,
-            "roofline_hbm": hbm_roof,
-            "power": power,
-            "valu": valu,
-            "mfma": mfma,
+            "roofline_encrypt": hbm_roofline(names.get("encrypt", "k_encrypt"), enc_bytes, B, enc_ms, None,
+                                             "no PMC pass on record for this kernel in this line", N * N),
+            "valu": valu, "mfma": mfma,
             "hbm_gbs_round_trip": (dec_bytes + enc_bytes) * B / ((dec_ms + enc_ms) * 1e-3) / 1e9,
-        }
-        if world == 1 and args.kernel_path == "auto" and names.get("decrypt", "").startswith("k_decrypt_m"):
+        })
+        if world == 1 and args.kernel_path == "auto" and dname.startswith("k_decrypt_m"):
             # The wavefront-per-ciphertext VALU families (BASELINE north_star's design), same buffers, outside the timed
             # region: a few steps, and their outputs must equal the ones just verified.
             cmp_names = ("e", "quotientE", "value", "quotient1", "remainder1", "quotient2") if witness else ("e", "value")
@@ -547,8 +648,7 @@ def main():
                 alt = (r[:, :N].contiguous(), m[:, :N].contiguous()) + tuple(dense(t) for t in bufs[2:])
             eng.set_kernel_path(2)
             step(None, alt, None); torch.cuda.synchronize()
-            differ = [n for n, a, i in zip(cmp_names, ref_out, cmp_idx) if not bool(torch.equal(a, alt[i][:, :N]))]
-            same = not differ
+            differ = [n_ for n_, a, i in zip(cmp_names, ref_out, cmp_idx) if not bool(torch.equal(a, alt[i][:, :N]))]
             alt_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(3)]
             for ev in alt_ev:
                 step(ev, alt, None)
@@ -557,15 +657,17 @@ def main():
             a_dec = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in alt_ev]))
             out["valu_families"] = {"value": B / ((a_enc + a_dec) * 1e-3), "unit": "round_trips/s",
                                     "kernels_ms": {names["encrypt"]: a_enc, names["decrypt"]: a_dec},
-                                    "outputs_equal_matrix_path": same, "arrays_compared_on_whole_batch": list(cmp_names),
+                                    "outputs_equal_matrix_path": not differ, "arrays_compared_on_whole_batch": list(cmp_names),
                                     "rows_compared": B,
                                     "note": "ntru_engine_set_kernel_path(2): one ciphertext per wavefront, no MFMA; kernel "
                                             "times only, 3 steps"}
+            names["encrypt"], names["decrypt"] = list(out["kernels_ms"])
             eng.set_kernel_path(0)
+            del ref_out
         if world == 1 and args.kernel_path == "auto" and not ablation:
             # The other function of the path with per-item operands, verifyKeysInputs (index.js:141-197, BASELINE config 5),
             # outside the timed region: 2^18 synthetic key pairs (config 5's size), kernel time of 3 launches
-            # (tools/bench_configs.py is the full secondary table).
+            # (`--workload verify_keys` is the same thing as a bench line of its own, oracle-checked).
             Bk = 1 << 18
             gk = torch.Generator(device=dev); gk.manual_seed(5)
             tern = lambda: (torch.randint(0, 3, (Bk, N), device=dev, generator=gk) - 1).to(torch.int8)
@@ -588,19 +690,66 @@ def main():
             vms = float(np.mean([kev[i].elapsed_time(kev[i + 1]) for i in range(3)]))
             out["verify_keys"] = {"value": Bk / (vms * 1e-3), "unit": "key_pairs/s", "kernel": eng.last_kernel(), "ms": vms,
                                   "batch": Bk, "hbm_gbs": 17.0 * N * Bk / (vms * 1e-3) / 1e9,
+                                  "roofline": hbm_roofline(eng.last_kernel(), 17 * N, Bk, vms, None,
+                                                           "PMC passes: profiles/*_secondary_pmc_hbm.json", 3 * N * N),
                                   "note": "verifyKeysInputs with per-item keys (synthetic operands), kernel time only"}
+            del kf, kg, kfq, kh, kfp, kouts
+    elif rank == 0 and wl == "encrypt_n701":
+        enc_ms = seg_ms[0]
+        ename = names.get("encrypt", "k_encrypt")
+        out = dict(common)
+        out.update({
+            "metric": "NTRU encryptBits operations per second at N=%d, q=%d (BASELINE.json config 4)" % (N, q), "unit": "encrypts/s",
+            "dtype": "i8" if ename.startswith("k_encrypt_m") or ename == "k_encrypt_w" else "u16",
+            "config": {"workload": "N=%d q=%d d=%d, batch=2^%d encryptBits per GPU per step (config 4: 2^23 over 8 GPUs), shared golden "
+                                   "key, full-witness outputs" % (N, q, d, args.batch_log2),
+                       "kernel_path": args.kernel_path, "seed": 20240, "parallelism": par},
+            "kernels_ms": {ename: enc_ms},
+            "roofline": hbm_roofline(ename, 6 * N, B, enc_ms, None, "PMC passes: profiles/*_secondary_pmc_hbm.json", N * N),
+        })
+    elif rank == 0:
+        vms = seg_ms[0]
+        vname = names.get("verify_keys", "k_verify_keys")
+        out = dict(common)
+        out.update({
+            "metric": "NTRU verifyKeysInputs key pairs per second at N=%d, q=%d (BASELINE.json config 5)" % (N, q), "unit": "key_pairs/s",
+            "dtype": "i8" if vname.startswith("k_verify_keys_m") else "u16",
+            "config": {"workload": "N=%d q=%d p=%d, batch=2^%d key pairs per GPU per step with PER-ITEM operands (config 5: 2^18 keys; "
+                                   "synthetic operands -- f, g ternary, fq, h uniform mod q, fp uniform mod p -- every witness array)"
+                                   % (N, q, p, args.batch_log2),
+                       "kernel_path": args.kernel_path, "seed": 20240, "parallelism": par},
+            "kernels_ms": {vname: vms},
+            "roofline": hbm_roofline(vname, 17 * N, B, vms, None, "PMC passes: profiles/*_secondary_pmc_hbm.json", 3 * N * N),
+        })
+
+    # ---- LAST phase: what limits the kernels -- socket power against its cap and the shader clock over a sustained run of the
+    # same steps (outside the timed region; also long enough for a coarse external GPU-activity sampler to see the GPU busy)
+    power = None
+    if args.power_seconds > 0:
+        sampler = PowerSampler(device_sysfs_dir(dev_index)) if rank == 0 else None
+        if sampler: sampler.start()
+        tp0 = time.perf_counter(); n_sus = 0
+        while time.perf_counter() - tp0 < args.power_seconds:
+            for _ in range(20):
+                step(); n_sus += 1
+            torch.cuda.synchronize()
+        tp1 = time.perf_counter()
+        if sampler:
+            power = sampler.summary(tp0, tp1)
+        if power:
+            power["sustained_ms_per_step"] = (tp1 - tp0) / n_sus * 1e3
+            power["note"] = ("the workload's steps back to back; the matrix-core kernels run against the socket power cap with the shader "
+                             "clock pulled below its 2.4 GHz top (profiles/r03_clock_power.txt, r04_rowimage_encrypt.txt)")
+    if rank == 0:
+        out["power"] = power
         if ablation:       # timing-only build of the engine (tools/ablate.sh): results are NOT checked, not a benchmark line
             out = {"ABLATION_NOT_A_RESULT": os.environ["NTRU_ENGINE_LIB"], "results_match_oracle": bool(ok),
                    "kernels_ms": out["kernels_ms"], "ms_per_step": out["ms_per_step"]}
+        if dist_info:
+            out["dist"] = dist_info
         if gathered:
             out["gather"] = gathered
-        if world == 1 and not args.no_cpu_baseline:
-            n_cpu = 4096
-            rr, mm = r[:n_cpu, :N].contiguous().cpu().numpy(), m[:n_cpu, :N].contiguous().cpu().numpy()
-            faithful, faithful_all, optimized = cpu_baseline(N, q, p, h_np, f_np, fp_np, rr, mm, args.cpu_seconds)
-            out["cpu_baseline"] = faithful
-            out["cpu_baseline_all_cores"] = faithful_all
-            out["cpu_baseline_optimized"] = optimized
+        out.update(out_cpu)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:

@@ -66,6 +66,10 @@ typedef struct ntru_engine ntru_engine_t;
 
 /* Number of HIP devices visible to the process (0 if none / runtime unusable). */
 int ntru_engine_device_count(void);
+/* 1 when this library is a TIMING-ONLY build (-DNTRU_ABLATE / -DRI_ABL: kernels with parts compiled out, wrong values on purpose;
+ * tools/ablate.sh).  ntru_engine_create refuses such a build unless NTRU_ALLOW_TIMING_ONLY=1 is in the environment, and
+ * ntru_engine_last_kernel prefixes every name with "TIMING-ONLY ".  0 for every library that is shipped. */
+int ntru_engine_is_timing_only_build(void);
 
 /* Create an engine bound to HIP device `device`.  Work is enqueued on the NULL stream until
  * ntru_engine_set_stream is called. */
@@ -102,7 +106,7 @@ const char *ntru_last_error(void);
 /* ---- device-resident use from a host language without HIP of its own (the N-API addon) --------------------------------------
  * ntru_pipeline_batch chains generateCustomArray (index.js:461-488: the r of encryptBits, drawn on the device from a ChaCha20
  * stream) -> encryptBits (index.js:87-110) -> decryptBits (index.js:111-140) -> packOutput (index.js:572-596) for a batch of HOST
- * plaintexts m [B][N]; the intermediates stay on the GPU, chunk by chunk through the engine's two streams.
+ * plaintexts m [B][N]; the intermediates stay on the GPU, chunk by chunk through the engine's three stage streams (upload, compute, download).
  *   key != NULL: r is sampled (n1 ones, n2 entries p - 1, item b from stream position first_item + b); else r [B][N] is read.
  *   f, fp both NULL: encrypt only.
  *   outputs, each optional (at least one): r_out [B][N] (the sampled r, to replay), e [B][N], value [B][N] (needs f, fp),

@@ -91,6 +91,18 @@ NTRU_HIDDEN int ntru_scratch_acquire(ntru_engine *eng, size_t bytes, char **p);
 // Marks the end of the work enqueued since ntru_scratch_acquire (records the event the next other-stream user waits for).
 NTRU_HIDDEN int ntru_scratch_release(ntru_engine *eng);
 
+// Scope guard around the two calls above: acquires now, releases on EVERY way out of the caller (an early error return must still
+// record the event: kernels that are already enqueued keep using the buffer, and the next call on another stream has to wait for them).
+struct ScratchHold {
+  ntru_engine *eng;
+  char *p = nullptr;
+  int rc;
+  ScratchHold(ntru_engine *e, size_t bytes) : eng(e) { rc = ntru_scratch_acquire(e, bytes, &p); }
+  ~ScratchHold() { if (rc == NTRU_OK) (void)ntru_scratch_release(eng); }
+  ScratchHold(const ScratchHold &) = delete;
+  ScratchHold &operator=(const ScratchHold &) = delete;
+};
+
 // ---- host helpers shared by the translation units ---------------------------------------------------------------------------
 #define NTRU_NOT_TAKEN (-1000)      // a launcher's "not my parameter range"; never leaves the library
 

@@ -515,8 +515,9 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   if (rounds > 0) {
     const int64_t C = B < INVERT_CHUNK ? B : INVERT_CHUNK;     // temporaries for C keys at a time
     const size_t row = (size_t)N * 2, part = ((size_t)C * row + 255) & ~(size_t)255;
-    char *sc = nullptr;                                                    // engine-owned, grown on demand, never per call
-    if (int rc = ntru_scratch_acquire(eng, 4 * part, &sc)) return rc;
+    ScratchHold hold(eng, 4 * part);                                       // engine-owned, grown on demand, never per call; released
+    if (hold.rc) return hold.rc;                                           // (event recorded) on every way out of this block
+    char *const sc = hold.p;
     struct { void *p; } f16{sc}, t{sc + part}, u{sc + 2 * part}, qs{sc + 3 * part};
     for (int64_t o = 0; o < B; o += C) {
       const int64_t n = B - o < C ? B - o : C;
@@ -545,7 +546,6 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
       }
       HIP_TRY(hipGetLastError());                          // the next chunk reuses the temporaries in stream order
     }
-    if (int rc = ntru_scratch_release(eng)) return rc;
   }
   if (d_fp) if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");

@@ -302,8 +302,11 @@ int run_generic(ntru_engine *eng, int op, int la, int lb, int64_t mod, const int
   const size_t o_a = 0, o_b = o_a + up(in_a), o_w = o_b + up(in_b), o_0 = o_w + up((size_t)blocks * NBUF * cap * 8),
                o_1 = o_0 + up(rows), o_l0 = o_1 + up(rows), o_l1 = o_l0 + up(lens), o_st = o_l1 + up(lens),
                total = o_st + up((size_t)B);
-  if (int rc = ntru_grow_dev(eng->cur_scratch, total)) return rc;
-  char *const d = (char *)eng->cur_scratch->p;
+  // the engine's shared scratch buffer, ordered against its last user on another stream (key inversion on stream A, then this
+  // call after ntru_engine_set_stream(B): B waits for A's event before the first copy below lands in the buffer)
+  ScratchHold hold(eng, total);
+  if (hold.rc) return hold.rc;
+  char *const d = hold.p;
   hipStream_t s = eng->stream;
   if (in_a) HIP_TRY(hipMemcpyAsync(d + o_a, a, in_a, hipMemcpyHostToDevice, s));
   if (in_b) HIP_TRY(hipMemcpyAsync(d + o_b, b, in_b, hipMemcpyHostToDevice, s));

@@ -389,8 +389,9 @@ extern "C" int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bit
 // ---- device-resident stages for a caller without HIP of its own (Node.js) -------------------------------------------------------
 // ntru_pipeline_batch: sampler -> encryptBits -> decryptBits -> packOutput per chunk, the intermediates (r, e, value) staying in the
 // slot's device arena; only m (and r when the caller supplies it) crosses PCIe upwards and only the outputs asked for come back
-// (index.js:461-488, :87-140, :572-620 chained).  The chunks flow through the same two-slot pipeline as every host-pointer entry
-// point, so the upload of chunk k+1 and the download of chunk k-1 overlap the kernels of chunk k.
+// (index.js:461-488, :87-140, :572-620 chained).  The chunks flow through the same three-stage pipeline (upload / compute / download
+// streams, three buffer sets) as every host-pointer entry point, so the upload of chunk k+1 and the download of chunk k-1 overlap
+// the kernels of chunk k.
 extern "C" int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *h, const int8_t *f, const uint8_t *fp,
                                    const uint32_t *key, uint64_t first_item, int n1, int n2, const uint8_t *r, const uint8_t *m,
                                    int64_t B, uint8_t *r_out, uint16_t *e, uint8_t *value, uint64_t *packed) {
@@ -399,7 +400,7 @@ extern "C" int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, cons
   if (decrypt && (!f || !fp)) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: the decrypt stage needs both f and fp");
   if (!decrypt && value) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: `value` needs the decrypt stage (f, fp)");
   if ((key != nullptr) == (r != nullptr)) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: give either a sampler key or r");
-  if (!e && !value && !packed) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: no output asked for");
+  if (!e && !value && !packed && !(r_out && key)) return ntru_fail(NTRU_ERR_ARG, "ntru_pipeline_batch: no output asked for");
   // parameter checks of every stage (B = 0 calls return after them)
   if (int rc = ntru_encrypt_batch_dev(eng, N, q, nullptr, nullptr, nullptr, 0, nullptr, nullptr)) return rc;
   if (decrypt) if (int rc = ntru_decrypt_batch_dev(eng, N, q, p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr)) return rc;
@@ -468,7 +469,7 @@ extern "C" int ntru_dev_download(ntru_engine_t *eng, void *dst, const void *d_sr
   return NTRU_OK;
 }
 
-// ---- several devices in ONE process: contiguous shards, one host thread + engine (with its two streams) per device ------
+// ---- several devices in ONE process: contiguous shards, one host thread + engine (with its three stage streams) per device ------
 // item b depends only on (key, m[b], r[b]) / (key, e[b]) / key[b], so a host batch is cut into contiguous
 // slices [g B / G, (g + 1) B / G) and every slice runs the single-device pipeline above on its own thread; nothing is exchanged
 // between devices.  (The benchmark's multi-GPU mode is one PROCESS per GPU instead -- bench.py under torchrun; this is for a

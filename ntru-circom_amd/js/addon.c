@@ -415,11 +415,29 @@ static napi_value PipelineBatch(napi_env env, napi_callback_info info) {
   return rc ? throw_engine(env, rc) : undefined(env);
 }
 
-typedef struct { void *p; size_t bytes; } DevBuf;
+typedef struct DevBuf { void *p; size_t bytes; struct DevBuf *next; } DevBuf;
+/* Every live handle of THIS addon.  An external value made by anybody else (another addon, a foreign napi_external) carries a data
+ * pointer that is not in this list and is refused by get_dev without ever being dereferenced. */
+static DevBuf *g_devs = NULL;
+static pthread_mutex_t g_devs_lock = PTHREAD_MUTEX_INITIALIZER;
+static void devs_add(DevBuf *b) { pthread_mutex_lock(&g_devs_lock); b->next = g_devs; g_devs = b; pthread_mutex_unlock(&g_devs_lock); }
+static void devs_remove(DevBuf *b) {
+  pthread_mutex_lock(&g_devs_lock);
+  for (DevBuf **pp = &g_devs; *pp; pp = &(*pp)->next) if (*pp == b) { *pp = b->next; break; }
+  pthread_mutex_unlock(&g_devs_lock);
+}
+static int devs_has(const void *data) {
+  int found = 0;
+  pthread_mutex_lock(&g_devs_lock);
+  for (DevBuf *b = g_devs; b; b = b->next) if ((const void *)b == data) { found = 1; break; }
+  pthread_mutex_unlock(&g_devs_lock);
+  return found;
+}
 
 static void devbuf_finalize(napi_env env, void *data, void *hint) {
   (void)env; (void)hint;
   DevBuf *b = (DevBuf *)data;
+  devs_remove(b);
   if (b->p) {                       /* not freed explicitly: release it with the handle (the engine may be gone already: then leak) */
     pthread_mutex_lock(&g_lock);
     if (g_engine) (void)ntru_dev_free(g_engine, b->p);
@@ -435,7 +453,7 @@ static DevBuf *get_dev(napi_env env, napi_value v, size_t need, int optional, in
   if (vt == napi_null || vt == napi_undefined) { *ok = optional; return NULL; }
   if (vt != napi_external) return NULL;
   void *data = NULL;
-  if (napi_get_value_external(env, v, &data) != napi_ok || !data) return NULL;
+  if (napi_get_value_external(env, v, &data) != napi_ok || !data || !devs_has(data)) return NULL;   /* not one of ours: refused */
   DevBuf *b = (DevBuf *)data;
   if (!b->p || b->bytes < need) return NULL;
   *ok = 1;
@@ -454,8 +472,10 @@ static napi_value DevAlloc(napi_env env, napi_callback_info info) {
   ENGINE_CALL(rc, ntru_dev_alloc(g_engine, (size_t)bytes, &b->p));
   if (rc) { free(b); return throw_engine(env, rc); }
   b->bytes = (size_t)bytes;
+  devs_add(b);
   napi_value ext;
   if (napi_create_external(env, b, devbuf_finalize, NULL, &ext) != napi_ok) {
+    devs_remove(b);
     ENGINE_CALL(rc, ntru_dev_free(g_engine, b->p)); free(b);
     napi_throw_error(env, NULL, "napi_create_external failed"); return NULL;
   }

@@ -1,6 +1,6 @@
 // Test doubles of the kernel launchers (ntru_launch_*) and of the *_dev entry points that live next to their kernels: each enqueues,
 // on the engine's current stream, a closure that computes a cheap deterministic function of ALL its inputs into ALL its outputs --
-// enough for the driver to tell whether the host pipeline (chunking, two slots, pinned / pageable staging, shards on several
+// enough for the driver to tell whether the host pipeline (chunking, three buffer sets, pinned / pageable staging, shards on several
 // threads) moved every byte to the right place.  No NTRU arithmetic here: the product kernels are tested on the GPU.
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 // Host-side sanitizer driver: the real abi.hip + ntru_host.hip, compiled as plain C++ against the fake HIP runtime and the fake
 // device (fake_hip.cpp, fake_device.cpp), run under AddressSanitizer + UBSan and under ThreadSanitizer.  What is exercised: engine
-// life cycle, the two-slot chunk pipeline (pinned and pageable buffers, single chunk / many chunks / ragged last chunk / empty batch),
+// life cycle, the three-stage chunk pipeline (pinned and pageable buffers, single chunk / many chunks / ragged last chunk / empty batch),
 // optional outputs, the shared scratch buffer across two user streams, ntru_multi_* (one host thread per shard, unequal and empty
 // shards), two engines driven from two threads, error paths.  Expected values come from the same formulas applied to the whole batch.
 #include <hip/hip_runtime.h>

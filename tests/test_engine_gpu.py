@@ -956,7 +956,7 @@ def test_full_size_batch_properties(eng, profile, logB):
 
 @pytest.mark.parametrize("pinned", [False, True])
 def test_host_pipeline_many_chunks_equal_oracle(eng, pinned):
-    """The host-pointer entry points (ntru_host.hip) cut a batch into chunks that alternate between two slots (stream, pinned
+    """The host-pointer entry points (ntru_host.hip) cut a batch into chunks that rotate through three buffer sets (pinned
     arena, device arena): 150 001 items = five chunks, ragged last one, with pageable numpy arrays (staged through the pinned
     arenas) and with arrays from ntru_host_alloc (DMA'd in place); every output array against the oracle.  Then a smaller and a
     larger batch through the same engine: the arenas only grow and are reused."""
@@ -1149,7 +1149,7 @@ def test_chunked_result_stores_at_every_base_alignment(eng, N, q):
 @pytest.mark.parametrize("N,q,d,B", [(167, 128, 18, 9001), (821, 4096, 273, 300), (509, 2048, 169, 1)])
 def test_pipeline_batch_equals_oracle_stage_by_stage(eng, N, q, d, B):
     """ntru_pipeline_batch (sampler -> encryptBits -> decryptBits -> packOutput, device-resident between the stages, chunked through
-    the two-slot host pipeline) against the oracle's replay of every stage; every combination of optional outputs."""
+    the three-stage host pipeline) against the oracle's replay of every stage; every combination of optional outputs."""
     rng = np.random.default_rng(N + B)
     p = 3
     h = rng.integers(0, q, N); fp = rng.integers(0, p, N)
@@ -1211,3 +1211,46 @@ def test_python_mirror_pipeline_equals_oracle(eng):
     assert list(n.pipeline(m, r=r_o)) == ["e"]
     packed = n.pipeline(m, r=r_o, decrypt=True, pack=True)
     assert list(packed) == ["packed"] and np.array_equal(packed["packed"], orc.pack_batch(n.p - 1, N, v_o.astype(np.uint16)))
+
+
+def test_generic_family_waits_for_the_scratch_buffers_previous_stream(eng):
+    """The engine's temporaries are ONE buffer shared by every *_dev call that needs them.  Key inversion enqueued on stream A
+    (Newton rounds: milliseconds of work that reads and writes the buffer), then ntru_engine_set_stream(B) and a generic product
+    whose staging copies land in the same bytes: stream B has to wait for A's use (ntru_scratch_acquire / _release in
+    run_generic), or the inverses come out wrong."""
+    import torch
+    N, q, p, B = 821, 4096, 3, 1 << 14
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    f = torch.zeros((B, N), dtype=torch.int8, device=dev)
+    idx = torch.rand((B, N), device=dev, generator=g).argsort(dim=1)
+    f.scatter_(1, idx[:, :274], 1)
+    f.scatter_(1, idx[:, 274:547], -1)
+    fq = torch.empty((B, N), dtype=torch.int16, device=dev); fq2 = torch.empty_like(fq)
+    flags = torch.empty(B, dtype=torch.uint8, device=dev); flags2 = torch.empty_like(flags)
+    rng = np.random.default_rng(5)
+    ga, gb = rng.integers(-1000, 1000, (4096, 64)), rng.integers(-1000, 1000, (4096, 64))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        eng.set_stream(sa.cuda_stream)
+        eng.invert_key_batch_dev(N, q, p, f.data_ptr(), B, fq2.data_ptr(), None, flags2.data_ptr())   # reference run, alone
+        torch.cuda.synchronize()
+        want = eng.generic_multiply(ga, gb, 1 << 20)
+        torch.cuda.synchronize()
+        eng.set_stream(sa.cuda_stream)
+        eng.invert_key_batch_dev(N, q, p, f.data_ptr(), B, fq.data_ptr(), None, flags.data_ptr())     # in flight on A ...
+        eng.set_stream(sb.cuda_stream)
+        got = eng.generic_multiply(ga, gb, 1 << 20)                                                    # ... while B wants the buffer
+        torch.cuda.synchronize()
+        assert torch.equal(fq, fq2) and torch.equal(flags, flags2)
+        assert got == want
+        a0, b0 = [int(x) for x in ga[0]], [int(x) for x in gb[0]]
+        ref = [0] * 127
+        for i, x in enumerate(a0):
+            for j, y in enumerate(b0):
+                ref[i + j] = (ref[i + j] + x * y) % (1 << 20)
+        while len(ref) > 1 and ref[-1] == 0:
+            ref.pop()
+        assert got[0] == ref
+    finally:
+        eng.set_stream(None)

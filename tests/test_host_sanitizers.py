@@ -1,5 +1,5 @@
 """Sanitizer builds of the HOST side of the engine (sanitizers belong on the CPU build; GPU ASan is not
-available on the pool).  abi.hip and ntru_host.hip -- engine life cycle, the two-slot chunk pipeline with its pinned arenas and
+available on the pool).  abi.hip and ntru_host.hip -- engine life cycle, the three-stage chunk pipeline with its pinned arenas and
 staging threads, ntru_multi_* with one host thread per shard, the scratch buffer shared across streams -- are compiled as plain C++
 against a test double of the HIP runtime whose streams are asynchronous worker threads (tests/hostcheck/), and a driver pushes
 batches through every host-pointer entry point under AddressSanitizer + UBSan and under ThreadSanitizer."""

@@ -79,7 +79,7 @@ def test_generic_exports_reproduce_reference():
 def test_device_resident_pipeline_through_the_shim_equals_oracle_replay(profile, B, tmp_path):
     """ntru.pipeline({sampleR, decrypt, pack}) keeps r, e and value on the GPU between the stages (index.js:461-488 -> :87-110 ->
     :111-140 -> :572-596); the CPU oracle replays the ChaCha20 draw stream and every stage from m alone.  B = 9001 runs as four
-    chunks through the two-slot pipeline; the script also composes the stages by hand on device-buffer handles."""
+    chunks through the three-stage pipeline; the script also composes the stages by hand on device-buffer handles."""
     import json
     import numpy as np
     from oracle import ntru_oracle as orc

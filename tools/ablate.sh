@@ -6,6 +6,7 @@
 #   ABL_SET="3 7 11 15" selects the combinations (default 1 2 3).
 # Build here:   tools/ablate.sh build      -> ntru-circom_amd/lib/ab/libntru_abl{1,2,3}.so
 # Run on a GPU: tools/ablate.sh run [bench.py args]
+export NTRU_ALLOW_TIMING_ONLY=1      # the libraries these scripts time compute wrong values on purpose (ntru_engine_create asks)
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
