@@ -115,13 +115,33 @@ def _run_bench(extra, env_extra=None):
 
 def test_bench_gpus_2_starts_two_ranks_by_itself_and_gathers():
     """`python bench.py --gpus 2` (the driver's command shape without a launcher) must really run two ranks."""
-    d = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--gather", "--batch-log2", "16"])
+    d = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--batch-log2", "16", "--power-seconds", "0"])   # no --gather: it runs anyway
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["dist"]["backend"] == "gloo" and d["dist"]["world"] == 2 and len(d["dist"]["ranks"]) == 2
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s" and d["mfma"]["unit"].startswith("TOP/s")
     g = d["gather"]
     assert g["kind"] == "gather_to_root" and g["ranks"] == 2 and g["rows"] == 2 << 16
     assert g["rows_equal_local_shard"] and g["every_shard_checksum_matches_its_owner"]
     # whole-job value: both ranks' items over the slowest rank's time
     assert abs(d["value"] - 2 * (1 << 16) * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
+
+
+def test_bench_workloads_config_4_and_5_have_a_multi_rank_entry():
+    """BASELINE.json configs 4 (N=701 encryptBits) and 5 (verifyKeysInputs with per-item keys) under the same launcher: two ranks
+    on device 0 over gloo, oracle-checked rows, the gather-to-root runs without being asked for, and the line says who took part."""
+    for wl, unit, kern in (("verify_keys", "key_pairs/s", "k_verify_keys_m"), ("encrypt_n701", "encrypts/s", "k_encrypt_m")):
+        d = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--workload", wl, "--batch-log2", "14",
+                        "--power-seconds", "0"])
+        assert d["n_gpus"] == 2 and d["unit"] == unit and d["scaling"] == "weak"
+        assert any(k.startswith(kern) for k in d["kernels_ms"]), d["kernels_ms"]
+        assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["int8"]["unit"].startswith("TOP/s")
+        assert d["verified_bit_exact_rows"] >= 500
+        ranks = d["dist"]["ranks"]
+        assert d["dist"]["world"] == 2 and [r["rank"] for r in ranks] == [0, 1] and ranks[0]["pid"] != ranks[1]["pid"]
+        g = d["gather"]
+        assert g["kind"] == "gather_to_root" and g["ranks"] == 2 and g["rows"] == 2 << 14
+        assert g["rows_equal_local_shard"] and g["every_shard_checksum_matches_its_owner"]
+        assert abs(d["value"] - 2 * (1 << 14) * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
 
 
 def test_bench_refuses_gpus_that_do_not_match_the_world():
@@ -134,7 +154,8 @@ def test_bench_refuses_gpus_that_do_not_match_the_world():
 def test_rccl_one_rank_process_group_times_and_gathers():
     """RCCL (backend nccl) with the one rank this box allows: init, barrier, all_reduce(MAX), the checksum all_gather and the
     gather-to-root all go through the library."""
-    d = _run_bench(["--gpus", "1", "--force-dist", "--gather", "--batch-log2", "16"])
+    d = _run_bench(["--gpus", "1", "--force-dist", "--gather", "--batch-log2", "16", "--power-seconds", "0"])
     g = d["gather"]
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["rccl_version"] and d["dist"]["ranks"][0]["device"] == 0
     assert d["n_gpus"] == 1 and g["backend"] == "nccl" and g["consumed_on"].startswith("GPU 0")
     assert g["rows_equal_local_shard"] and g["every_shard_checksum_matches_its_owner"]
