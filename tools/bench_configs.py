@@ -142,6 +142,81 @@ def keygen_config(profile, logB):
             "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
 
 
+def pipeline_dev_config(profile, logB, log_chunk=17):
+    """Device-resident sampled round trip (no PCIe): generateCustomArray -> encryptBits -> decryptBits (value only), chunk by
+    chunk; m and every result stay in HBM.  "serial": the three kernels of a chunk one after the other on ONE stream (what
+    ntru_pipeline_batch enqueues on its compute stream); "overlapped": the sampler of chunk k+1 on a SECOND stream next to the
+    encrypt / decrypt of chunk k (events both ways).  Socket power and shader clock over 2 s of each are reported: the
+    matrix kernels run at the power cap, so a co-running VALU-bound sampler has no free watts to run on."""
+    import time
+    o, h_np, f_np, fp_np = bench.load_key(profile)
+    N, q, p, d = o["N"], o["q"], o["p"], o["dr"]
+    B, C = 1 << logB, 1 << log_chunk
+    key = np.arange(8, dtype=np.uint32) + 11
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    m = torch.randint(0, 2, (B, N), dtype=torch.uint8, device=dev, generator=gen)
+    h = torch.from_numpy(h_np.view(np.int16)).to(dev); f = torch.from_numpy(f_np).to(dev); fp = torch.from_numpy(fp_np).to(dev)
+    r = [torch.empty((C, N), dtype=torch.uint8, device=dev) for _ in range(2)]          # two r buffers: chunk k and chunk k+1
+    e = torch.empty((C, N), dtype=torch.int16, device=dev)
+    value = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    s_main, s_samp = torch.cuda.Stream(), torch.cuda.Stream()
+    nch = B // C
+
+    def chunk_rest(k):
+        eng.encrypt_batch_dev(N, q, h.data_ptr(), r[k & 1].data_ptr(), m[k * C:].data_ptr(), C, e.data_ptr(), None)
+        eng.decrypt_batch_dev(N, q, p, f.data_ptr(), fp.data_ptr(), e.data_ptr(), C, value[k * C:].data_ptr())
+
+    def serial():
+        eng.set_stream(s_main.cuda_stream)
+        for k in range(nch):
+            eng.sample_ternary_dev(N, d, d, p - 1, key, k * C, C, r[k & 1].data_ptr())
+            chunk_rest(k)
+
+    def overlapped():
+        sampled = [torch.cuda.Event() for _ in range(nch)]
+        used = [torch.cuda.Event() for _ in range(nch)]
+        for k in range(nch):
+            eng.set_stream(s_samp.cuda_stream)
+            if k >= 2:
+                s_samp.wait_event(used[k - 2])                 # r[k & 1] is free once chunk k-2 has been encrypted
+            eng.sample_ternary_dev(N, d, d, p - 1, key, k * C, C, r[k & 1].data_ptr())
+            sampled[k].record(s_samp)
+            eng.set_stream(s_main.cuda_stream)
+            s_main.wait_event(sampled[k])
+            eng.encrypt_batch_dev(N, q, h.data_ptr(), r[k & 1].data_ptr(), m[k * C:].data_ptr(), C, e.data_ptr(), None)
+            used[k].record(s_main)
+            eng.decrypt_batch_dev(N, q, p, f.data_ptr(), fp.data_ptr(), e.data_ptr(), C, value[k * C:].data_ptr())
+
+    def wall(fn, seconds=2.0):
+        fn(); torch.cuda.synchronize()
+        sampler = bench.PowerSampler(bench.device_sysfs_dir(0)); sampler.start()
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds:
+            fn(); n += 1
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pw = sampler.summary(t0, t1) or {}
+        return (t1 - t0) / n * 1e3, pw.get("socket_W"), pw.get("sclk_MHz")
+    ms_s, w_s, f_s = wall(serial)
+    v_serial = value.clone()
+    ms_o, w_o, f_o = wall(overlapped)
+    same = bool(torch.equal(v_serial, value))
+    eng.set_stream(stream.cuda_stream)
+    # oracle replay of a few rows of the last chunk: the sampler's stream position is the item index
+    rows = torch.tensor([0, 1, C - 1], device=dev)
+    k = nch - 1
+    r_o = orc.sample_ternary_batch(N, d, d, p - 1, key, k * C, C)[rows.cpu().numpy()]
+    e_o, _ = orc.encrypt_batch(N, q, h_np, r_o, host(m[k * C:(k + 1) * C], rows))
+    v_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)[0]
+    ok = bool(np.array_equal(host(value[k * C:(k + 1) * C], rows), v_o))
+    return {"config": "N=%d q=%d batch=2^%d device-resident sampled round trip (sampler -> encryptBits -> decryptBits, value only), "
+                      "chunks of 2^%d, 1 GPU" % (N, q, logB, log_chunk),
+            "serial": {"ms": ms_s, "round_trips_per_s": B / (ms_s * 1e-3), "socket_W": w_s, "sclk_MHz": f_s},
+            "sampler_on_second_stream": {"ms": ms_o, "round_trips_per_s": B / (ms_o * 1e-3), "socket_W": w_o, "sclk_MHz": f_o,
+                                         "values_equal_serial": same},
+            "rows_equal_oracle": ok, "rows_checked": 3}
+
+
 def add_config(N, q, logB):
     B = 1 << logB
     gen = torch.Generator(device=dev); gen.manual_seed(9)
@@ -181,3 +256,5 @@ if __name__ == "__main__":
     for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
                 verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), keygen_config("n821_q4096", 18), polymul_config(821, 4096, 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20)):
         print(json.dumps(res), flush=True)
+    if "--no-pipeline" not in sys.argv:       # (uses its own streams: kept out of the rocprofv3 passes of tools/collect_profiles.sh)
+        print(json.dumps(pipeline_dev_config("n821_q4096", 20)), flush=True)

@@ -1,0 +1,7 @@
+import sys, json
+sys.argv=['x']
+sys.path.insert(0,'tools'); sys.path.insert(0,'.')
+import importlib.util
+spec = importlib.util.spec_from_file_location('bc','tools/bench_configs.py'); bc = importlib.util.module_from_spec(spec); spec.loader.exec_module(bc)
+for lc in (15, 17, 18):
+    print(json.dumps(bc.pipeline_dev_config('n821_q4096', 20, lc)), flush=True)
