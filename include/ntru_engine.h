@@ -87,7 +87,8 @@ int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
  * whose matrix-loop and epilogue phases are interleaved by barriers (k_decrypt_m8; k_decrypt_m where 160 KB of LDS do not hold
  * two groups), encrypt with direct-to-LDS operand loads (k_encrypt_md; k_encrypt_m for rows that do not fit one such
  * instruction).  0 picks k_encrypt_md and, for N > 512 with every witness array, k_decrypt_m8.  Results are identical on every
- * path.  Paths 6-10 (role-split / chunked-store / lock-step / row-image encrypt, direct-to-LDS decrypt: built, bit-exact, measured slower or equal)
+ * path.  Paths 6-11 (role-split / chunked-store / lock-step / row-image encrypt, direct-to-LDS decrypt, decrypt with an fp4 second product: built,
+ * bit-exact, measured slower or equal)
  * exist only in a library built with -DNTRU_EXPERIMENTS (`make -C ntru-circom_amd/csrc experiments`); this call refuses them
  * otherwise.
  * Streams: the *_dev calls that need temporaries (key inversion, the generic family) share one engine-owned scratch buffer.

@@ -258,6 +258,163 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
 #endif
 }
 
+#ifdef NTRU_EXPERIMENTS
+// ---- product of two SMALL-alphabet operands on the block-scaled fp4 matrix instruction -------------------------------------------------
+// decryptBits' second product is ternary x ternary: both operands are exact in fp4 (e2m1: 0, 1, 2 = codes 0, 2, 4), the sums stay
+// below 4 N < 2^24 (exact in the fp32 accumulators), and v_mfma_scale_f32_32x32x64_f8f6f4 contracts K = 64 per instruction in the
+// clocks the int8 instruction takes for K = 32: half the matrix instructions, half the operand reads (scales 2^0).
+// Same tile geometry (rows = the 32 items of a row block, 32-column tiles); a contraction BLOCK is 64 coefficients = two tiles:
+// lane (r = lane & 31, h = lane >> 5) holds the 32 nibbles k = 32 h .. 32 h + 31 of its row (A) / column (B), low nibble first
+// (both operands use the same order, which is all the instruction needs).  Operand stage: [32 rows][pitch4] bytes, two columns per
+// byte.  Key array: reversed and cyclic as before, as a NIBBLE stream in 8 nibble-shifted copies (a lane's 32-nibble fragment
+// starts at an arbitrary nibble; copy y & 7 holds it as 4 aligned dwords): rev4[y] = code(s[(32 NT - 1 - y) mod N]).
+// Tile kb against block s: G = kb - 2 s >= 2 -> all of it is `low`, G < 0 -> `high`, G = 0 / 1 -> the diagonal runs through the
+// lower / upper half of the block (two instructions with complementary nibble masks).
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+struct FGeom { int NT2, pitch4, tp4; };
+static __host__ __device__ inline FGeom make_fgeom(int NT) {
+  FGeom f;
+  f.NT2 = (NT + 1) / 2;
+  f.pitch4 = 32 * f.NT2 + 16;                              // an odd multiple of 16 bytes: conflict-free ds_read_b128
+  const int L = 32 * NT + 64 * f.NT2 + 64;                 // nibbles a fragment request can touch (one block of run-ahead included)
+  f.tp4 = ((L / 8 + 4 + 31) / 32) * 32 + 4;                // dwords per copy
+  return f;
+}
+static __host__ __device__ inline size_t fp4_array_bytes(int NT) { return (size_t)32 * make_fgeom(NT).tp4; }
+
+template <class D>
+static __device__ __forceinline__ void build_toeplitz_array4(u32 *T4, const MGeom &g, const FGeom &f4, D value, int tid, int nthr) {
+  const int Y0 = 32 * g.NT - 1;
+  for (int x = tid; x < 8 * f4.tp4; x += nthr) {
+    const int c = x / f4.tp4, w = x - c * f4.tp4;
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      int idx = (Y0 - (8 * w + c + j)) % g.N;             // remainder takes the dividend's sign
+      idx += idx < 0 ? g.N : 0;
+      v |= (((u32)value(idx) & 3u) << 1) << (4 * j);      // fp4 e2m1 codes of 0, 1, 2
+    }
+    T4[x] = v;
+  }
+}
+// Per-lane pointer to the fragment of G = 0 (the fragment of G starts 4 G dwords below it).
+static __device__ __forceinline__ const u32 *frag4_lane_base(const u32 *T4, const MGeom &g, const FGeom &f4, int lane) {
+  const int yb = 32 * g.NT - 1 - (lane & 31) + 32 * (lane >> 5);
+  return T4 + (yb & 7) * f4.tp4 + (yb >> 3);
+}
+// Nibble masks of the `low` part when the diagonal runs through this block: m0: G = 0 (lower half diagonal, upper half all high),
+// m1: G = 1 (lower half all low, upper half diagonal).  Nibble j of a lane is contraction index j of its half; low iff j <= column.
+static __device__ __forceinline__ void diag_low_mask4(int lane, u32 (&m0)[4], u32 (&m1)[4]) {
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    u32 mk = 0;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) mk |= (8 * c + jj <= n) ? (0xFu << (4 * jj)) : 0u;
+    m0[c] = h == 0 ? mk : 0u;
+    m1[c] = h == 0 ? 0xFFFFFFFFu : mk;
+  }
+}
+
+// One strip of NT_S <= 4 column tiles from tile kb0, every contraction block; st: this lane's row of the nibble stage (+ 16 bytes for
+// the upper half-wave), tb4: its fragment base.  epi(lo, hi) gets the two halves as int32 tiles, like toeplitz_strip's.
+// Three regions, each with compile-time kinds per tile (runtime kinds cost a second copy of every accumulator): blocks below the
+// strip's diagonals (all `low`, a loop), the 1-3 blocks the diagonals run through (unrolled; two variants by the parity of kb0),
+// blocks above (all `high`, a loop).  Fragment window: inside a region tile t works on slot (t + 2 parity) & 3 and the fragments
+// tiles 0, 1 need in the NEXT block go into the slots tiles 2, 3 have just used (G drops by two per block, so tiles 2, 3 inherit the
+// fragments of tiles 0, 1); a region of odd length ends with the two slot pairs exchanged, so every region starts at parity 0.
+template <int NT_S, class Epi>
+static __device__ __forceinline__ void toeplitz_strip_fp4(const unsigned char *__restrict__ st, const u32 *__restrict__ tb4,
+                                                          const FGeom &f4, int kb0, int lane_, Epi epi) {
+  v16f accL[NT_S], accH[NT_S];
+#pragma unroll
+  for (int t = 0; t < NT_S; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { accL[t][i] = 0.f; accH[t][i] = 0.f; }
+  v4i W[4];
+  const int Gmin = -2 * f4.NT2;
+  auto load_w = [&](int G, v4i &w) {
+    G = G < Gmin ? Gmin : G;                               // run-ahead past the last block: inside the array, never used
+    const u32 *p = tb4 - 4 * G;
+    w = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+  };
+  auto mm = [&](v16f &acc, const v4i &a, const v4i &w) {
+    const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, w8 = {w[0], w[1], w[2], w[3], 0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8, acc, 4, 4, 0, 127, 0, 127);   // fp4 x fp4, scales 2^0
+  };
+#pragma unroll
+  for (int t = 0; t < NT_S; t++) load_w(kb0 + t, W[t]);
+  for (int t = NT_S; t < 4; t++) W[t] = (v4i){0, 0, 0, 0};
+  v4i a = *(const v4i *)st;
+  enum { LOW = 0, HIGH = 1, MIX0 = 2, MIX1 = 3 };
+  u32 m0[4], m1[4];                                        // nibble masks of the diagonal blocks: made right before those blocks
+  auto tile = [&](auto kind, int t, int slot, const v4i &av) {
+    constexpr int K = decltype(kind)::value;
+    if (K == LOW) mm(accL[t], av, W[slot]);
+    else if (K == HIGH) mm(accH[t], av, W[slot]);
+    else {
+      v4i wl, wh;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const u32 mk = K == MIX0 ? m0[c] : m1[c];
+        wl[c] = (int)((u32)W[slot][c] & mk); wh[c] = (int)((u32)W[slot][c] & ~mk);
+      }
+      mm(accL[t], av, wl);
+      mm(accH[t], av, wh);
+    }
+  };
+#define FP4_KIND(G) std::integral_constant<int, ((G) >= 2 ? LOW : ((G) < 0 ? HIGH : ((G) == 0 ? MIX0 : MIX1)))>{}
+  // one block; FIX = 0: every tile low, 1: every tile high, 2: tile t has G = G0 + t (G0 a compile-time constant)
+  auto block = [&](int s, auto par, auto fix, auto g0) {
+    constexpr int P = decltype(par)::value, FIX = decltype(fix)::value, G0 = decltype(g0)::value;
+    const v4i an = *(const v4i *)(st + 32 * (s + 1));      // (past the last block: the row's pad / the next row, never used)
+    if (NT_S > 2) tile(FP4_KIND(FIX == 0 ? 2 : (FIX == 1 ? -1 : G0 + 2)), 2, (2 + 2 * P) & 3, a);
+    if (NT_S > 3) tile(FP4_KIND(FIX == 0 ? 2 : (FIX == 1 ? -1 : G0 + 3)), 3, (3 + 2 * P) & 3, a);
+    load_w(kb0 - 2 * (s + 1), W[(2 * P + 2) & 3]);
+    if (NT_S > 1) load_w(kb0 + 1 - 2 * (s + 1), W[(2 * P + 3) & 3]);
+    tile(FP4_KIND(FIX == 0 ? 2 : (FIX == 1 ? -1 : G0 + 0)), 0, (0 + 2 * P) & 3, a);
+    if (NT_S > 1) tile(FP4_KIND(FIX == 0 ? 2 : (FIX == 1 ? -1 : G0 + 1)), 1, (1 + 2 * P) & 3, a);
+    a = an;
+  };
+  auto swap_pairs = [&]() { const v4i x0 = W[0], x1 = W[1]; W[0] = W[2]; W[1] = W[3]; W[2] = x0; W[3] = x1; };
+  using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
+  auto uniform_region = [&](int s0, int s1, auto fix) {    // blocks s0 .. s1-1, all tiles of one kind
+    int s = s0;
+    for (; s + 1 < s1; s += 2) { block(s, C0{}, fix, C0{}); block(s + 1, C1{}, fix, C0{}); }
+    if (s < s1) { block(s, C0{}, fix, C0{}); swap_pairs(); }
+  };
+  __builtin_amdgcn_s_setprio(3);
+  const int sa = kb0 >> 1;
+  uniform_region(0, sa, C0{});
+  int s_next;
+  asm volatile("" : "+v"(lane_));                          // (made here: eight registers that need not live through the loops)
+  diag_low_mask4(lane_, m0, m1);
+  if ((kb0 & 1) == 0) {                                    // tile 0 has G = 0 in block sa
+    block(sa, C0{}, C2{}, std::integral_constant<int, 0>{});
+    if (NT_S > 2) { block(sa + 1, C1{}, C2{}, std::integral_constant<int, -2>{}); s_next = sa + 2; }
+    else { swap_pairs(); s_next = sa + 1; }
+  } else {                                                 // tile 0 has G = 1 in block sa
+    block(sa, C0{}, C2{}, std::integral_constant<int, 1>{});
+    if (NT_S > 1) {
+      block(sa + 1, C1{}, C2{}, std::integral_constant<int, -1>{});
+      if (NT_S > 3) { block(sa + 2, C0{}, C2{}, std::integral_constant<int, -3>{}); swap_pairs(); s_next = sa + 3; }
+      else s_next = sa + 2;
+    } else { swap_pairs(); s_next = sa + 1; }
+  }
+  uniform_region(s_next, f4.NT2, C1{});
+  __builtin_amdgcn_s_setprio(0);
+#undef FP4_KIND
+  v16i lo[NT_S], hi[NT_S];
+#pragma unroll
+  for (int t = 0; t < NT_S; t++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo[t][i] = (int)accL[t][i]; hi[t][i] = (int)accH[t][i]; }
+  epi(lo, hi);
+}
+
+#endif   // NTRU_EXPERIMENTS (fp4 second product: bit-exact, measured 5 % slower, profiles/r04_fp4_product2.txt)
+
 // The NT column tiles are cut into 4 R strips of at most 4 tiles (sizes as even as possible, in column order); in round
 // rho the four waves take the adjacent strips 4 rho .. 4 rho + 3, so neighbouring strips are stored at about the same
 // time and the cache lines they share are completed in L2 instead of being written to HBM twice.  body(kb0, nt).

@@ -30,7 +30,17 @@ static __host__ __device__ inline int dec_dma_m3_bytes(int N, int p) {
   return (((span + 4) & ~3) + span + 1 + 15) & ~15;
 }
 
-template <int GROUPS, bool DMA = false>
+// FP4: product 2 (ternary x ternary) on the block-scaled fp4 matrix instruction, K = 64 per instruction (matrix_common.h,
+// toeplitz_strip_fp4): the lifted message is expanded into a NIBBLE stage, fp's key array is a nibble stream in 8 shifted copies.
+#ifndef NTRU_EXPERIMENTS       // the fp4 machinery lives in the experiments build only: inert stand-ins so that decrypt_m_body<.., false> compiles
+struct FGeom { int NT2, pitch4, tp4; };
+static __host__ __device__ inline FGeom make_fgeom(int) { return FGeom{0, 0, 0}; }
+template <class D> static __device__ __forceinline__ void build_toeplitz_array4(u32 *, const MGeom &, const FGeom &, D, int, int) {}
+static __device__ __forceinline__ const u32 *frag4_lane_base(const u32 *T4, const MGeom &, const FGeom &, int) { return T4; }
+template <int NT_S, class Epi>
+static __device__ __forceinline__ void toeplitz_strip_fp4(const unsigned char *, const u32 *, const FGeom &, int, int, Epi) {}
+#endif
+template <int GROUPS, bool DMA = false, bool FP4 = false>
 static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
                                                       const uint8_t *__restrict__ fp,
                                                       const u16 *__restrict__ e, long B,
@@ -48,6 +58,8 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
   // LDS layout: per group [e_hi stage][e_lo stage][packed image], then the shared key arrays and the lift table.  Group 0's
   // e_hi stage is at LDS address 0: the mod-p tables of product 2 are overlaid on it and their lookups need no base add.
   static_assert(!DMA || GROUPS == 2, "the direct-to-LDS variant is the lock-step kernel");
+  static_assert(!(DMA && FP4), "the fp4 second product is built on the register-staged kernels");
+  const FGeom f4 = make_fgeom(g.NT);
   const int RP = DMA ? dec_dma_row_pitch(g.NT) : g.pitchA;                       // row pitch of the operand stage(s)
   const int m3b = DMA ? dec_dma_m3_bytes(g.N, (int)p) : 0;
   const int gbytes = (DMA ? 32 * RP : 64 * g.pitchA) + 256 * g.NT;
@@ -55,7 +67,7 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
   unsigned char *stLo = DMA ? lds + m3b + group * gbytes : stHi + 32 * g.pitchA;
   unsigned char *blp = DMA ? stLo + 32 * RP : stLo + 32 * g.pitchA;              // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
   u32 *TF = (u32 *)(lds + m3b + GROUPS * gbytes), *TP = TF + 4 * g.tpitch;
-  unsigned char *lift_lut = (unsigned char *)(TP + 4 * g.tpitch);   // [q]: centred lift followed by mod p, index.js:117 verbatim
+  unsigned char *lift_lut = (unsigned char *)(TP + (FP4 ? 8 * f4.tp4 : 4 * g.tpitch));   // [q]: centred lift followed by mod p, index.js:117 verbatim
   // mod-p tables of product 2, rebuilt per row block once the e stages are dead: (-x) mod p at LDS address x, so that
   // the quotient lookup's address IS the `high` accumulator; x mod p at M3V + x, the base folded into the low + high add
   const int M3V = __builtin_amdgcn_readfirstlane(((int)((p - 1) * (p - 1)) * g.N + 4) & ~3);   // both tables inside the e_hi stage
@@ -68,7 +80,8 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
       m3_lut[M3V + x] = (unsigned char)rm;
     }
   build_toeplitz_array(TF, g, [&](int i) { return (int)f[i]; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
-  build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
+  if (FP4) build_toeplitz_array4(TP, g, f4, [&](int i) { return (int)fp[i]; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
+  else build_toeplitz_array(TP, g, [&](int i) { return (int)fp[i]; }, (int)threadIdx.x, GROUPS * BLOCK_THREADS);
   for (u32 x = threadIdx.x; x < q; x += GROUPS * BLOCK_THREADS) lift_lut[x] = (unsigned char)mod_small(2 * x > q ? x + 1 : x, p);
 #ifndef NTRU_PHASE_MASK
 #define NTRU_PHASE_MASK 15       // which boundaries of the lock-step schedule are barriers (tuning experiments): 1 = product 1 loop | epilogue,
@@ -120,7 +133,8 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
     STAMP(0);
     int lane = lane0, N = g.N, LD = g.ld;                // see k_encrypt_m
     asm volatile("" : "+v"(lane), "+s"(N), "+s"(LD));
-    const u32 *tbf = frag_lane_base(TF, g, lane), *tbp = frag_lane_base(TP, g, lane);
+    const u32 *tbf = frag_lane_base(TF, g, lane), *tbp = FP4 ? nullptr : frag_lane_base(TP, g, lane);
+
     const unsigned char *st0 = stLo + (lane & 31) * RP + 16 * (lane >> 5);
     const unsigned char *st1 = stHi + (lane & 31) * RP + 16 * (lane >> 5);
     u32 mlow[4];
@@ -283,12 +297,35 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
 #pragma unroll
         for (int it = 0; it < 4; it++) pv[j][it] = src[(lane + 64 * it) < 8 * g.NT ? lane + 64 * it : 0];
       }
+      if (!FP4) {
 #pragma unroll
-      for (int j = 0; j < RPW; j++) {
-        const int row = wave + WAVES_PER_BLOCK * j, sh = 2 * (row & 3);
+        for (int j = 0; j < RPW; j++) {
+          const int row = wave + WAVES_PER_BLOCK * j, sh = 2 * (row & 3);
 #pragma unroll
-        for (int it = 0; it < 4; it++)
-          if (lane + 64 * it < 8 * g.NT) *(u32 *)(stLo + row * RP + 4 * (lane + 64 * it)) = (pv[j][it] >> sh) & 0x03030303u;
+          for (int it = 0; it < 4; it++)
+            if (lane + 64 * it < 8 * g.NT) *(u32 *)(stLo + row * RP + 4 * (lane + 64 * it)) = (pv[j][it] >> sh) & 0x03030303u;
+        }
+      } else {
+        // nibble stage: 8 columns per dword, fp4 codes (value << 1).  pv[.][it] of lane l is the packed dword u = 64 it + l = columns
+        // 4 u .. 4 u + 3 of four rows; the dword of the four columns after them sits in lane l + 1 (in pv[.][it + 1] of lane 0 for
+        // lane 63).  Even lanes write dword u / 2 of the row; what lies beyond the last tile (half a block when NT is odd) is zero.
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+          const int row = wave + WAVES_PER_BLOCK * j, sh = 2 * (row & 3);
+#pragma unroll
+          for (int it = 0; it < 4; it++) {
+            const int u = lane + 64 * it;
+            const u32 own = u < 8 * g.NT ? pv[j][it] : 0u;
+            const u32 nx = it < 3 ? pv[j][it + 1] : 0u;
+            const u32 up = (u32)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, (int)pv[j][it]);      // lane l + 1's dword
+            const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)nx);                                // lane 0's next dword
+            const u32 d1 = u + 1 < 8 * g.NT ? (lane == 63 ? first : up) : 0u;
+            const u32 v0 = (own >> sh) & 0x03030303u, v1 = (d1 >> sh) & 0x03030303u;
+            const u32 n0 = v0 | (v0 >> 4), n1 = v1 | (v1 >> 4);       // bytes 0 and 2: (c0 | c1 << 4), (c2 | c3 << 4)
+            const u32 nib = __builtin_amdgcn_perm(n1, n0, 0x06040200u) << 1;
+            if ((lane & 1) == 0 && u < 16 * f4.NT2) *(u32 *)(stLo + row * f4.pitch4 + 2 * u) = nib;
+          }
+        }
       }
     }
 #endif
@@ -297,6 +334,10 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
     STAMP(10);
     // ---- product 2: c = fp * lifted mod p
     sidx = 0;
+    int lane2 = lane0;                                   // FP4: this lane's nibble-stage row and fragment base, made here (held from the
+    asm volatile("" : "+v"(lane2));                      // top of the trip they cost four registers the first product has no room for)
+    const unsigned char *st4 = stLo + (lane2 & 31) * f4.pitch4 + 16 * (lane2 >> 5);
+    const u32 *tbp4 = frag4_lane_base(TP, g, f4, lane2);
     for_each_strip<4>(g.NT, GROUPS == 2 ? wave ^ (2 * group) ^ (2 * blockIdx.x >= gridDim.x ? 2 : 0) : wave, [&](int kb0, int nt) {
       auto epi = [&](auto &lo, auto &hi) {
         constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
@@ -359,10 +400,10 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
             __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));                       // vmcnt(0): it stores nothing behind them
           }
           break;
-        case 1: toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
-        case 2: toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
-        case 3: toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
-        default: toeplitz_strip<M_DEC2, 4>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 1: if (FP4) toeplitz_strip_fp4<1>(st4, tbp4, f4, kb0, lane, epi); else toeplitz_strip<M_DEC2, 1>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 2: if (FP4) toeplitz_strip_fp4<2>(st4, tbp4, f4, kb0, lane, epi); else toeplitz_strip<M_DEC2, 2>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        case 3: if (FP4) toeplitz_strip_fp4<3>(st4, tbp4, f4, kb0, lane, epi); else toeplitz_strip<M_DEC2, 3>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
+        default: if (FP4) toeplitz_strip_fp4<4>(st4, tbp4, f4, kb0, lane, epi); else toeplitz_strip<M_DEC2, 4>(st0, st0, tbp, tbp, g, kb0, mlow, epi, stamp_iter, 11 + 2 * sidx); break;
       }
       sidx++;
       if (sidx < rounds) phase(8);
@@ -388,6 +429,23 @@ __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8(MGeom g, u3
 }
 
 #ifdef NTRU_EXPERIMENTS
+// The same two kernels with product 2 on the fp4 matrix instruction (kernel path 11): bit-exact, 5 % slower (profiles/r04_fp4_product2.txt).
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_mq(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                              const uint8_t *__restrict__ fp,
+                                                              const u16 *__restrict__ e, long B,
+                                                              uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                              u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  decrypt_m_body<1, false, true>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
+}
+
+__global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8q(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                                   const uint8_t *__restrict__ fp,
+                                                                   const u16 *__restrict__ e, long B,
+                                                                   uint8_t *__restrict__ value, u16 *__restrict__ quot1,
+                                                                   u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+  decrypt_m_body<2, false, true>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
+}
+
 __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8d(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
                                                                    const uint8_t *__restrict__ fp,
                                                                    const u16 *__restrict__ e, long B,
@@ -413,6 +471,29 @@ int ntru_launch_decrypt_matrix(ntru_engine *eng, int N, int q, int p, int ld, co
   const long nrb = (long)((B + 31) / 32);
   dim3 grid;
 #ifdef NTRU_EXPERIMENTS
+  if (eng->path == 11) {                                 // product 2 on the fp4 matrix instruction (K = 64): fp's array is 8 nibble-shifted copies
+    const size_t keys = (size_t)16 * mg.tpitch + fp4_array_bytes(mg.NT);
+    const size_t lut = ((size_t)q + 15) & ~(size_t)15, per_group = (size_t)64 * mg.pitchA + (size_t)256 * mg.NT;
+    const bool lockstep = mg.NT > 16 && d_quot1 && d_rem1 && d_quot2 && keys + lut + 2 * per_group <= 160 * 1024;
+    if (lockstep) {
+      const size_t l8 = keys + lut + 2 * per_group;
+      if (int rc = resident_grid(eng, k_decrypt_m8q, l8, (nrb + 1) / 2, &grid, 2 * BLOCK_THREADS)) return rc;
+      snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_decrypt_m8q");
+      hipLaunchKernelGGL(k_decrypt_m8q, grid, dim3(2 * BLOCK_THREADS), l8, eng->stream, mg, (u32)q, (u32)p, d_f, d_fp, d_e,
+                         (long)B, d_value, d_quot1, d_rem1, d_quot2);
+      HIP_TRY(hipGetLastError());
+      return NTRU_OK;
+    }
+    const size_t l4 = keys + lut + per_group;
+    if (l4 <= 160 * 1024) {
+      if (int rc = resident_grid(eng, k_decrypt_mq, l4, nrb, &grid)) return rc;
+      snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_decrypt_mq");
+      hipLaunchKernelGGL(k_decrypt_mq, grid, dim3(BLOCK_THREADS), l4, eng->stream, mg, (u32)q, (u32)p, d_f, d_fp, d_e,
+                         (long)B, d_value, d_quot1, d_rem1, d_quot2);
+      HIP_TRY(hipGetLastError());
+      return NTRU_OK;
+    }
+  }
   if (eng->path == 8) {                                  // lock-step + direct-to-LDS loads of the next row block
     const size_t ldsd = (size_t)dec_dma_m3_bytes(N, p) + 2 * ((size_t)32 * dec_dma_row_pitch(mg.NT) + (size_t)256 * mg.NT) +
                         (size_t)32 * mg.tpitch + (((size_t)q + 15) & ~(size_t)15);

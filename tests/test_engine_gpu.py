@@ -276,7 +276,7 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             e, quot = eng.encrypt_batch(N, q, h, r, m)
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: dma, 6: ("k_encrypt_m2",),
                                          7: ("k_encrypt_mc",) if two_groups_fit else dma, 8: dma,
-                                         9: ("k_encrypt_m8",), 10: ("k_encrypt_w",) + dma}[path]           # (two encrypt groups fit 160 KB at every N <= 1024)
+                                         9: ("k_encrypt_m8",), 10: ("k_encrypt_w",) + dma, 11: dma}[path]  # (two encrypt groups fit 160 KB at every N <= 1024)
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), B
             e_only, _ = eng.encrypt_batch(N, q, h, r, m, want_quot=False)
@@ -286,7 +286,9 @@ def test_matrix_core_path_equals_oracle(eng, N, q, d, path):
             ein[0, :4] = (q - 1, 0, q // 2, q // 2 + 1)
             got = eng.decrypt_batch(N, q, p, f, fp, ein)
             assert eng.last_kernel() == ("k_decrypt_m8" if path in (5, 9) and two_groups_fit else
-                                         "k_decrypt_m8d" if path == 8 and two_groups_fit else "k_decrypt_m")
+                                         "k_decrypt_m8d" if path == 8 and two_groups_fit else
+                                         "k_decrypt_m8q" if path == 11 and two_groups_fit and N > 512 else
+                                         "k_decrypt_mq" if path == 11 else "k_decrypt_m")
             want = orc.decrypt_batch(N, q, p, f, fp, ein)
             for g_, w_, name in zip(got, want, ("value", "quotient1", "remainder1", "quotient2")):
                 assert np.array_equal(g_, w_), (B, name)
@@ -319,7 +321,7 @@ def test_matrix_core_path_random_parameter_sweep(eng, path):
             assert eng.last_kernel() in {4: ("k_encrypt_m",), 5: ("k_encrypt_md", "k_encrypt_m"), 6: ("k_encrypt_m2",),
                                          7: ("k_encrypt_mc", "k_encrypt_md", "k_encrypt_m"), 8: ("k_encrypt_md", "k_encrypt_m"),
                                          9: ("k_encrypt_m8", "k_encrypt_md", "k_encrypt_m"),
-                                         10: ("k_encrypt_w", "k_encrypt_md", "k_encrypt_m")}[path]
+                                         10: ("k_encrypt_w", "k_encrypt_md", "k_encrypt_m"), 11: ("k_encrypt_md", "k_encrypt_m")}[path]
             e_o, quot_o = orc.encrypt_batch(N, q, h, r, m)
             assert np.array_equal(e, e_o) and np.array_equal(quot, quot_o), (N, q, B)
             ein = np.concatenate([e_o, rng.integers(0, q, (3, N))])

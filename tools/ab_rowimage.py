@@ -1,4 +1,5 @@
-# Row-image kernels (kernel path 10, matrix_rowimage.hip) against the default matrix kernels: bit-exactness on ragged batches and
+# Experimental kernel paths (AB_NEW_PATH: 10 = row-image kernels of matrix_rowimage.hip [default], 11 = decrypt with the fp4 second
+# product) against the default matrix kernels: bit-exactness on ragged batches and
 # misaligned arrays, then same-device timing at 2^20 items (HIP events, interleaved rounds).
 #   python tools/ab_rowimage.py [check|time|all] [encrypt|decrypt|both]
 import importlib, sys, numpy as np, torch
@@ -9,7 +10,9 @@ eng = pkg.Engine(0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
 which = sys.argv[2] if len(sys.argv) > 2 else 'both'
-NEW = 10
+import os
+NEW = int(os.environ.get('AB_NEW_PATH', '10'))
+DEC_NAMES = ('k_decrypt_w',) if NEW == 10 else ('k_decrypt_m8q', 'k_decrypt_mq')
 
 
 def carve(nbytes_list, off):
@@ -107,7 +110,7 @@ def check_decrypt():
                     if not torch.equal(vb2, vb):
                         print('MISMATCH value-only', N, q, B, off, path); bad += 1
                 same = all(torch.equal(res[4][i], res[NEW][i]) for i in range(4))
-                if not same or res[NEW][4] != 'k_decrypt_w':
+                if not same or res[NEW][4] not in DEC_NAMES:
                     bad += 1
                     print('MISMATCH decrypt', N, q, B, off, res[NEW][4],
                           [int((res[4][i] != res[NEW][i]).sum()) for i in range(4)],
