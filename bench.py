@@ -609,7 +609,7 @@ def main():
                     "unit": "T coefficient-adds/s",
                     "note": "ternary add path: (non-zero steps) x N packed 16-bit adds per product; peak = measured "
                             "v_add_u32 issue roof x 2 coefficients; the scalar-issued step control is what keeps it "
-                            "below that roof (DESIGN.md section 4)"}
+                            "below that roof (DESIGN.md section 4.3)"}
         else:
             valu = {"kernel": dname, "achieved": 2.0 * N * N * B / dec_s / 1e12, "peak": PK_MAC_PEAK_T,
                     "unit": "T MAC/s", "note": "2*N^2 MACs per decrypt; peak = measured v_pk_mad_u16 issue roof"}

@@ -8,7 +8,7 @@
 // h is taken in the representative hs = d0 + 128 d1, d0 in [-64,63], 4 d1 in [-128,124]; planes [r | 32 r] x [d0 ; 4 d1].
 // MAXT: widest strip.  8 (one workgroup per CU, 512 registers per wave, one strip per wave and row block) was measured at
 // 2.28 ms per 2^20 against 1.51-1.58 ms for 4: with one wave per SIMD nothing overlaps the matrix loops
-// (DESIGN.md section 5b); only 4 is instantiated.
+// (EXPERIMENTS.md, round 2); only 4 is instantiated.
 // Result chunk of one wave (CHUNK variants): 8 rows x OC_PITCH bytes = a strip's <= 128 u16 columns of 8 rows, each row
 // at the 16-byte phase it has in global memory (<= 14 bytes of slack in front).
 constexpr int OC_PITCH = 272, OC_BYTES = 8 * OC_PITCH;
@@ -380,7 +380,7 @@ NTRU_STAMPS_READER(ntru_debug_read_stamps_enc)
 // ---- family 4, role-split variants ----------------------------------------------------------------------------------
 // k_encrypt_m / k_decrypt_m above give every wave the whole job of its column strips: stage, matrix loops, epilogue
 // arithmetic, table lookups and 2-byte result stores, phase after phase; the two co-resident workgroups of a CU overlap
-// almost none of it (the ablation times are additive).  The role-split kernels run ONE workgroup
+// almost none of it (EXPERIMENTS.md, round 1: the ablation times are additive).  The role-split kernels run ONE workgroup
 // of eight waves per CU, two per SIMD with complementary jobs at all times:
 //   waves 0-3, MATRIX waves: the strip loops of toeplitz_strip and nothing else -- their "epilogue" is one add and one
 //     ds_write_b32 per accumulator register: the raw pair (low + high | high << 16) goes into an LDS chunk;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void k_encrypt_m2(MGeom g, u32 q, const u16
 // ---- host side ----------------------------------------------------------------------------------------------------------
 // Kernel paths (ntru_engine_set_kernel_path): 0 = auto and 5 -> k_encrypt_md where a row fits one direct-to-LDS instruction, else
 // k_encrypt_m; 4 -> k_encrypt_m.  -DNTRU_EXPERIMENTS builds add 6 (k_encrypt_m2, role split), 7 (k_encrypt_mc, results through LDS
-// chunks), 9 (k_encrypt_m8, lock-step groups): built, bit-exact, measured slower or equal (DESIGN.md sections 4a, 5b).
+// chunks), 9 (k_encrypt_m8, lock-step groups): built, bit-exact, measured slower or equal (EXPERIMENTS.md, round 2).
 int ntru_launch_encrypt_matrix(ntru_engine *eng, int N, int q, int ld, const uint16_t *d_h, const uint8_t *d_r, const uint8_t *d_m,
                                int64_t B, uint16_t *d_e, uint16_t *d_quotE) {
   MGeom mg;
