@@ -131,6 +131,8 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
   eng->n_occ = 0;
   eng->cur_scratch = &eng->scratch_dev;
   eng->st_up = eng->st_comp = eng->st_down = nullptr;
+  eng->st_aux = nullptr;
+  eng->ev_fork = eng->ev_join = nullptr;
   eng->scratch_stream = nullptr;
   eng->scratch_event = nullptr;
   eng->scratch_used = false;
@@ -146,8 +148,9 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
 extern "C" void ntru_engine_destroy(ntru_engine_t *eng) {
   if (!eng) return;
   (void)hipSetDevice(eng->device);
-  for (hipStream_t st : {eng->st_up, eng->st_comp, eng->st_down})
+  for (hipStream_t st : {eng->st_up, eng->st_comp, eng->st_down, eng->st_aux})
     if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (hipEvent_t ev : {eng->ev_fork, eng->ev_join}) if (ev) (void)hipEventDestroy(ev);
   for (HostSlot &s : eng->slot) {
     for (hipEvent_t ev : {s.up_done, s.comp_done, s.down_done}) if (ev) (void)hipEventDestroy(ev);
     if (s.pinned.p) (void)hipHostFree(s.pinned.p);

@@ -66,6 +66,8 @@ struct ntru_engine {
   char last_kernel[64];     // name of the kernel the last *_dev call launched (reporting only)
   HostSlot slot[NTRU_HOST_SLOTS];
   hipStream_t st_up, st_comp, st_down;   // the three stage streams of the host path (created at first use)
+  hipStream_t st_aux;       // forked from / joined back into the caller's stream inside ONE *_dev call (key inversion: the mod-p inversion,
+  hipEvent_t ev_fork, ev_join;   // vector-ALU bound, runs beside the Newton chain on the matrix cores); created at first use
   GrowBuf shared_dev;       // shared key rows of the host path (h, f, fp)
   GrowBuf scratch_dev;      // temporaries of *_dev calls (Newton rounds, generic family) on the caller's stream
   hipStream_t scratch_stream;   // the stream whose work used scratch_dev last, and an event recorded behind that work: a call on

@@ -370,6 +370,11 @@ __global__ void k_newton_combine(u16 *__restrict__ v, const u16 *__restrict__ u,
   for (long i = first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     v[i] = (u16)((2u * v[i] - u[i]) & (q - 1));
 }
+// flags |= extra, bytewise (the mod-p inversion's flag bits, collected on a stream of their own)
+__global__ void k_or_bytes(uint8_t *__restrict__ flags, const uint8_t *__restrict__ extra, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    flags[i] = (uint8_t)(flags[i] | extra[i]);
+}
 __global__ void k_newton_combine_vec(u16x8 *__restrict__ v, const u16x8 *__restrict__ u, long nvec, u32 q) {   // 16 bytes per lane
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x)
     v[i] = ((u16)2 * v[i] - u[i]) & (u16)(q - 1);                        // q | 2^16: wrapped 16-bit arithmetic is exact mod q
@@ -505,19 +510,53 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
     snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");
     return NTRU_OK;
   }
-  // mod 2 inverse straight into d_fq (as 0/1 coefficients), then Newton rounds v <- 2v - f v^2 mod q (index.js:499-506;
-  // the reference runs log2(q) - 1 of them, the unique inverse mod q is reached once 2^rounds >= log2(q))
-  if (int rc = launch_invert<2>(eng, N, d_f, (long)B, d_fq, nullptr, d_flags, NTRU_FLAG_NOT_UNIT_MOD2)) return rc;
+  // The mod-p inversion (k_invert_key<3>: bit-sliced division steps, vector-ALU bound, no LDS at the usual sizes) depends on f only, and
+  // the chain for fq -- mod-2 inversion, then Newton rounds on the per-item matrix kernels (matrix cores + LDS) -- does not depend on
+  // it: the two run SIDE BY SIDE, the mod-p inversion on an engine-owned stream forked from the caller's stream and joined back into it
+  // before this call returns.  Its flag bits go to a byte array of their own (two kernels must not read-modify-write the same bytes
+  // at the same time) and are OR-ed into d_flags behind the join.
   int k = 0;
   while ((1 << k) < q) k++;
   int rounds = 0;
   while ((1 << rounds) < k) rounds++;
+  const int64_t C = B < INVERT_CHUNK ? B : INVERT_CHUNK;     // Newton temporaries for C keys at a time
+  const size_t row = (size_t)N * 2, part = rounds > 0 ? ((size_t)C * row + 255) & ~(size_t)255 : 0;
+  const size_t fl_bytes = d_fp ? ((size_t)B + 255) & ~(size_t)255 : 0;
+  ScratchHold hold(eng, 4 * part + fl_bytes + 256);          // engine-owned, grown on demand, never per call; released (event
+  if (hold.rc) return hold.rc;                               // recorded) on every way out of this function
+  char *const sc = hold.p;
+  uint8_t *const flags_p = (uint8_t *)(sc + 4 * part);
+  hipStream_t main_stream = eng->stream;
+  bool forked = false;
+  if (d_fp) {
+    if (!eng->st_aux) HIP_TRY(hipStreamCreateWithFlags(&eng->st_aux, hipStreamNonBlocking));
+    if (!eng->ev_fork) HIP_TRY(hipEventCreateWithFlags(&eng->ev_fork, hipEventDisableTiming));
+    if (!eng->ev_join) HIP_TRY(hipEventCreateWithFlags(&eng->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(eng->ev_fork, main_stream));      // f is ready, the scratch buffer is ours (behind the memset above)
+    HIP_TRY(hipStreamWaitEvent(eng->st_aux, eng->ev_fork, 0));
+    HIP_TRY(hipMemsetAsync(flags_p, 0, (size_t)B, eng->st_aux));
+    eng->stream = eng->st_aux;
+    const int rc3 = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, flags_p, NTRU_FLAG_NOT_UNIT_MODP);
+    eng->stream = main_stream;
+    // (joined below even when a launch fails: what is enqueued on the forked stream must not outlive this call)
+    const hipError_t ej = hipEventRecord(eng->ev_join, eng->st_aux);
+    forked = ej == hipSuccess;
+    if (rc3) { if (forked) (void)hipStreamWaitEvent(main_stream, eng->ev_join, 0); return rc3; }
+    HIP_TRY(ej);
+  }
+  auto join = [&]() -> int {
+    if (!forked) return NTRU_OK;
+    forked = false;
+    HIP_TRY(hipStreamWaitEvent(main_stream, eng->ev_join, 0));
+    hipLaunchKernelGGL(k_or_bytes, elementwise_grid(eng, B), dim3(256), 0, main_stream, d_flags, (const uint8_t *)flags_p, (long)B);
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  };
+  struct Joiner { decltype(join) &j; ~Joiner() { (void)j(); } } joiner{join};      // every early return below joins first
+  // mod 2 inverse straight into d_fq (as 0/1 coefficients), then Newton rounds v <- 2v - f v^2 mod q (index.js:499-506;
+  // the reference runs log2(q) - 1 of them, the unique inverse mod q is reached once 2^rounds >= log2(q))
+  if (int rc = launch_invert<2>(eng, N, d_f, (long)B, d_fq, nullptr, d_flags, NTRU_FLAG_NOT_UNIT_MOD2)) return rc;
   if (rounds > 0) {
-    const int64_t C = B < INVERT_CHUNK ? B : INVERT_CHUNK;     // temporaries for C keys at a time
-    const size_t row = (size_t)N * 2, part = ((size_t)C * row + 255) & ~(size_t)255;
-    ScratchHold hold(eng, 4 * part);                                       // engine-owned, grown on demand, never per call; released
-    if (hold.rc) return hold.rc;                                           // (event recorded) on every way out of this block
-    char *const sc = hold.p;
     struct { void *p; } f16{sc}, t{sc + part}, u{sc + 2 * part}, qs{sc + 3 * part};
     for (int64_t o = 0; o < B; o += C) {
       const int64_t n = B - o < C ? B - o : C;
@@ -547,7 +586,7 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
       HIP_TRY(hipGetLastError());                          // the next chunk reuses the temporaries in stream order
     }
   }
-  if (d_fp) if (int rc = launch_invert<3>(eng, N, d_f, (long)B, nullptr, d_fp, d_flags, NTRU_FLAG_NOT_UNIT_MODP)) return rc;
+  if (int rc = join()) return rc;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_invert_key");
   return NTRU_OK;
 }

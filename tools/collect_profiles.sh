@@ -9,7 +9,7 @@ set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 B="python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 --power-seconds 0"
-S="python3 tools/bench_configs.py"
+S="python3 tools/bench_configs.py --no-pipeline"
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"
 SQ2="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 # NTRU_LAUNCH_LOG: the engine's Python binding appends (kernel, N, items, bytes per item) of every launch, in order, so that
