@@ -738,6 +738,21 @@ def main():
             power = sampler.summary(tp0, tp1)
         if power:
             power["sustained_ms_per_step"] = (tp1 - tp0) / n_sus * 1e3
+            if wl == "roundtrip" and out and out.get("mfma"):
+                # Energy view of the step (what the power cap turns into time): measured dynamic energy against the floor that the
+                # matrix instructions and the HBM bytes alone would cost, priced with this round's measurements
+                # (profiles/r04_rowimage_encrypt.txt: 17.6 nJ per v_mfma_i32_32x32x32_i8 on live operands, 113 pJ per byte stored,
+                # ~60 pJ per byte loaded; idle socket 300 W).
+                NTt = (N + 31) // 32
+                n_mfma_step = 5.0 * NTt * (NTt + 1) * ((B + 31) // 32)          # 2 planes encrypt + 3 planes decrypt
+                stored = ((4 if witness else 2) + (6 if witness else 1)) * N * B
+                loaded = (2 + 2) * N * B
+                floor_j = n_mfma_step * 17.6e-9 + stored * 113e-12 + loaded * 60e-12
+                dyn_j = (power["socket_W"] - 300.0) * power["sustained_ms_per_step"] * 1e-3
+                power["energy"] = {"dynamic_J_per_step": dyn_j, "floor_J_per_step": floor_j, "frac": floor_j / dyn_j,
+                                   "floor_ms_per_step_at_the_cap": floor_j / ((power["cap_W"] or 1400.0) - 300.0) * 1e3,
+                                   "note": "floor = matrix instructions on live operands + HBM bytes only; frac = floor / measured: how "
+                                           "close the step is to what the socket power cap allows for this instruction mix"}
             power["note"] = ("the workload's steps back to back; the matrix-core kernels run against the socket power cap with the shader "
                              "clock pulled below its 2.4 GHz top (profiles/r03_clock_power.txt, r04_rowimage_encrypt.txt)")
     if rank == 0:

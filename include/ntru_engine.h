@@ -302,6 +302,12 @@ int ntru_pack_batch(ntru_engine_t *eng, int max_val, int data_len, const uint16_
 int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint16_t *d_data, int64_t B, uint64_t *d_out);
 /* packOutput of an array of BYTES (values <= 255: decryptBits' value and quotient2, r, m) without widening it to uint16 first. */
 int ntru_pack_bytes_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint8_t *d_data, int64_t B, uint64_t *d_out);
+/* decryptBits (index.js:111-140) + packOutput(p - 1, N, value) (index.js:572-596) of its result, value-only mode, device pointers:
+ * d_packed [B][output_size][4] (sizes from ntru_pack_params(p - 1, N, ...)).  Where the matrix-core decrypt applies (shared key, p == 3,
+ * q <= 8192, N <= 1024, d_packed 16-byte aligned) this is ONE kernel -- the field elements come straight out of the second product's
+ * epilogue and d_value may be NULL (nothing but the packed rows is written); elsewhere it is decrypt + pack and d_value is needed. */
+int ntru_decrypt_pack_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp,
+                                const uint16_t *d_e, int64_t B, uint8_t *d_value, uint64_t *d_packed);
 int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *in, int packed_size, int64_t B,
                       uint16_t *out);
 int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *d_in, int packed_size,

@@ -259,6 +259,28 @@ extern "C" int ntru_decrypt_batch_pitched_dev(ntru_engine_t *eng, int N, int q, 
   return ntru_launch_decrypt_valu(eng, N, q, p, d_f, d_fp, d_e, B, d_value, d_quot1, d_rem1, d_quot2);
 }
 
+// decryptBits (index.js:111-140) followed by packOutput(p - 1, N, value) (index.js:572-596), value-only mode: ONE kernel where the
+// matrix path applies (the packed field elements come out of the second product's epilogue), else decrypt + pack as two launches
+// (then d_value is needed as the intermediate: NTRU_ERR_ARG without it).
+extern "C" int ntru_decrypt_pack_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp,
+                                           const uint16_t *d_e, int64_t B, uint8_t *d_value, uint64_t *d_packed) {
+  if (int rc = ntru_check_common(eng, N, q, B)) return rc;
+  if (is_pow2(p) || !ntru_engine_supports(N, p))
+    return fail(NTRU_ERR_UNSUPPORTED, "unsupported p: need a small non-power-of-two modulus with N*(p-1)^2 < 65536");
+  int bits, per, al, os;
+  if (int rc = ntru_pack_params(p - 1, N, &bits, &per, &al, &os)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!d_f || !d_fp || !d_e || !d_packed) return fail(NTRU_ERR_ARG, "ntru_decrypt_pack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  if (eng->path == 0 || eng->path >= 4) {
+    const int rc = ntru_launch_decrypt_pack_matrix(eng, N, q, p, d_f, d_fp, d_e, B, d_value, d_packed, os);
+    if (rc != NTRU_NOT_TAKEN) return rc;
+  }
+  if (!d_value) return fail(NTRU_ERR_ARG, "ntru_decrypt_pack_batch: outside the fused kernel's range d_value is needed as the intermediate");
+  if (int rc = ntru_decrypt_batch_dev(eng, N, q, p, d_f, d_fp, d_e, B, d_value, nullptr, nullptr, nullptr)) return rc;
+  return ntru_pack_bytes_batch_dev(eng, p - 1, N, d_value, B, d_packed);
+}
+
 extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b,
                                       int64_t B, uint16_t *d_quot, uint16_t *d_rem) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");

@@ -129,6 +129,9 @@ NTRU_HIDDEN int ntru_launch_encrypt_matrix(ntru_engine *eng, int N, int q, int l
 NTRU_HIDDEN int ntru_launch_decrypt_matrix(ntru_engine *eng, int N, int q, int p, int ld, const int8_t *d_f, const uint8_t *d_fp,
                                            const uint16_t *d_e, int64_t B, uint8_t *d_value, uint16_t *d_quot1, uint16_t *d_rem1,
                                            uint8_t *d_quot2);
+// decryptBits + packOutput(p - 1, N, value) in one kernel; d_value may be NULL (NTRU_NOT_TAKEN outside the matrix path's range)
+NTRU_HIDDEN int ntru_launch_decrypt_pack_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp,
+                                                const uint16_t *d_e, int64_t B, uint8_t *d_value, uint64_t *d_packed, int out_size);
 // the row-image variants (matrix_rowimage.hip): dense rows, one eight-wave workgroup per CU, results leave through LDS images
 NTRU_HIDDEN int ntru_launch_encrypt_rowimage(ntru_engine *eng, int N, int q, int ld, const uint16_t *d_h, const uint8_t *d_r,
                                              const uint8_t *d_m, int64_t B, uint16_t *d_e, uint16_t *d_quotE);

@@ -40,12 +40,21 @@ static __device__ __forceinline__ const u32 *frag4_lane_base(const u32 *T4, cons
 template <int NT_S, class Epi>
 static __device__ __forceinline__ void toeplitz_strip_fp4(const unsigned char *, const u32 *, const FGeom &, int, int, Epi) {}
 #endif
-template <int GROUPS, bool DMA = false, bool FP4 = false>
+// PACK (k_decrypt_mp): packOutput(p - 1, N, value) (index.js:572-596: 2 bits per value, 126 values per 252-bit field element, four
+// little-endian 64-bit limbs per element) comes out of the same kernel: product 2's epilogue drops its values into a 2-bit packed
+// LDS image [8 row groups][columns] (4 rows per byte -- the layout product 1 uses for the lifted message: one ds_write_b8 per four
+// accumulator registers), and at the top of the next trip every thread turns 16 columns of one row into one dword of the packed
+// row (the row block's packed rows are contiguous: consecutive threads store consecutive dwords).  `value` itself is optional
+// then: the pipeline's pack mode writes 32 ceil(N / 126) bytes per item instead of N + 32 ceil(N / 126).
+// (First version: DPP gather + ds_or_b32 into an image of the packed rows: bit-exact, 3.65 ms per 2^20 against 1.83 ms for the
+// plain value-only kernel -- 1248 LDS atomics per row block with 4 active lanes each.)
+template <int GROUPS, bool DMA = false, bool FP4 = false, bool PACK = false>
 static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
                                                       const uint8_t *__restrict__ fp,
                                                       const u16 *__restrict__ e, long B,
                                                       uint8_t *__restrict__ value, u16 *__restrict__ quot1,
-                                                      u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
+                                                      u16 *__restrict__ rem1, uint8_t *__restrict__ quot2,
+                                                      unsigned long long *__restrict__ packed = nullptr, int pack_os = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // DMA: a barrier that orders LDS traffic only.  With direct-to-LDS loads in flight the compiler puts s_waitcnt vmcnt(0) in front of
   // every __syncthreads() -- which also waits for every outstanding STORE, the very queue the early loads are meant to get ahead of.
@@ -59,6 +68,7 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
   // e_hi stage is at LDS address 0: the mod-p tables of product 2 are overlaid on it and their lookups need no base add.
   static_assert(!DMA || GROUPS == 2, "the direct-to-LDS variant is the lock-step kernel");
   static_assert(!(DMA && FP4), "the fp4 second product is built on the register-staged kernels");
+  static_assert(!PACK || (GROUPS == 1 && !DMA && !FP4), "fused packOutput is built on the plain four-wave kernel");
   const FGeom f4 = make_fgeom(g.NT);
   const int RP = DMA ? dec_dma_row_pitch(g.NT) : g.pitchA;                       // row pitch of the operand stage(s)
   const int m3b = DMA ? dec_dma_m3_bytes(g.N, (int)p) : 0;
@@ -68,6 +78,37 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
   unsigned char *blp = DMA ? stLo + 32 * RP : stLo + 32 * g.pitchA;              // [8 row groups][32 NT columns]: 4 rows x 2 bits per byte
   u32 *TF = (u32 *)(lds + m3b + GROUPS * gbytes), *TP = TF + 4 * g.tpitch;
   unsigned char *lift_lut = (unsigned char *)(TP + (FP4 ? 8 * f4.tp4 : 4 * g.tpitch));   // [q]: centred lift followed by mod p, index.js:117 verbatim
+  // PACK: 2-bit image of product 2's values, [8 row groups][pcols] bytes, pcols = 126 pack_os + 16 >= 32 NT (zero beyond N).  It lives
+  // in the e_hi stage behind the mod-p tables (dead between product 1's last loop and the next trip's staging: no LDS of its own --
+  // 7 KB more would cost the second workgroup of the CU); it is turned into packed dwords at the top of the next trip, and a barrier
+  // separates that from the staging writes.
+  const int pcols = 126 * pack_os + 16, pimg_bytes = (8 * pcols + 15) & ~15;
+  unsigned char *pimg = stHi + ((((int)((p - 1) * (p - 1)) * g.N + 4) & ~3) + (int)((p - 1) * (p - 1)) * g.N + 1 + 15 & ~15);
+  auto pack_flush = [&](long rbx) {                      // the image of row block rbx -> packed[32 rbx ..]; thread = one dword of one row
+    const long b0x = rbx << 5;
+    const int rows_left = (int)(B - b0x < 32 ? B - b0x : 32);
+    u32 *dst = (u32 *)packed + b0x * 8 * pack_os;
+    const int per_row = 8 * pack_os;
+    for (int x = (int)threadIdx.x; x < rows_left * per_row; x += BLOCK_THREADS) {
+      const int R = x / per_row, dw = x - R * per_row, o = dw >> 3, k = dw & 7;
+      const unsigned char *src = pimg + (2 * (R >> 3) + ((R >> 2) & 1)) * pcols + 126 * o + 16 * k;
+      const int sh = 2 * (R & 3);
+      u32 out = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        u32 d;                                               // four columns; the address is only 2-byte aligned
+        __builtin_memcpy(&d, src + 4 * c, 4);
+        u32 t = (d >> sh) & 0x03030303u;
+        t |= t >> 6;
+        t = (t | (t >> 12)) & 0xFFu;
+        out |= t << (8 * c);
+      }
+      dst[x] = k == 7 ? out & 0x0FFFFFFFu : out;             // 126 = 7 x 16 + 14: the eighth dword of an element holds 14 values
+    }
+  };
+  auto pack_wipe = [&]() {                               // the staging of product 1 has been here since: columns >= N must read zero again
+    for (int x = (int)threadIdx.x; x < pimg_bytes / 16; x += BLOCK_THREADS) *(uint4 *)(pimg + 16 * x) = make_uint4(0u, 0u, 0u, 0u);
+  };
   // mod-p tables of product 2, rebuilt per row block once the e stages are dead: (-x) mod p at LDS address x, so that
   // the quotient lookup's address IS the `high` accumulator; x mod p at M3V + x, the base folded into the low + high add
   const int M3V = __builtin_amdgcn_readfirstlane(((int)((p - 1) * (p - 1)) * g.N + 4) & ~3);   // both tables inside the e_hi stage
@@ -161,6 +202,10 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
     wg_barrier();
     STAMP(1);
     if (!DMA) request_rows();
+    if (PACK && it > 0) {                                // every wave has left the previous trip's epilogues; this trip's rows are in flight
+      pack_flush((long)blockIdx.x * GROUPS + group + (it - 1) * stride);
+      wg_barrier();                                      // ... before the staging below overwrites the image
+    }
     if (DMA) {                                           // the rows are in their slots (every wave waited for its own loads)
       const int a0 = (int)((unsigned long long)(e + b0 * LD) & 3);
 #pragma unroll
@@ -278,6 +323,7 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
     }, GROUPS == 2);
     wg_barrier();                                    // every wave is done with the e stages; packed image complete
     STAMP(8);
+    if (PACK) pack_wipe();
 #if !(NTRU_ABLATE & 64)
     if (!DMA) for (int x = tid0; x <= (int)((p - 1) * (p - 1)) * N; x += BLOCK_THREADS) {
       const u32 rm = mod_small((u32)x, p);
@@ -349,7 +395,7 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
         long bb = b0;                                    // see product 1
         asm volatile("" : "+s"(bb));
         const long lf = (B - bb) * LD;
-        const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value + bb * LD, lf);
+        const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(value ? value + bb * LD : nullptr, value ? lf : 0);
         const __amdgpu_buffer_rsrc_t rs_q2 = rows_rsrc(want_q2 ? quot2 + bb * LD : nullptr, want_q2 ? lf : 0);
         int voff[NTS];                                   // see k_encrypt_m
 #pragma unroll
@@ -369,8 +415,17 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
                 vb[t][ii] = decltype(wq)::value ? (u32)m3_lut[(u32)hi[t][4 * j + ii]] : 0u;
 #endif
               }
+            if (PACK) {
+#pragma unroll
+              for (int t = 0; t < NTS; t++) {
+                const int col = 32 * (kb0 + t) + (lane & 31);
+                const u32 pk = va[t][0] | (va[t][1] << 2) | (va[t][2] << 4) | (va[t][3] << 6);
+                if (col < N) pimg[((lane >> 5) + 2 * j) * pcols + col] = (unsigned char)pk;   // [row group 2j+hh][column]; columns >= N stay zero
+              }
+            }
 #pragma unroll
             for (int ii = 0; ii < 4; ii++) {
+              if (PACK && value == nullptr) break;         // pack mode without the plain values
 #pragma unroll
               for (int t = 0; t < NTS; t++) {
                 const int so = (ii + 8 * j) * LD + 32 * (kb0 + t);
@@ -410,6 +465,11 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
     }, GROUPS == 2);
   }
   if (GROUPS == 2 && group == 0) wg_barrier();        // group 1's last phase
+  if (PACK && iters > 0) {
+    wg_barrier();                                       // the last trip's epilogues
+    const long last = (long)blockIdx.x + (iters - 1) * stride;
+    if (last < nrb) pack_flush(last);
+  }
 }
 
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_m(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
@@ -426,6 +486,14 @@ __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8(MGeom g, u3
                                                                   uint8_t *__restrict__ value, u16 *__restrict__ quot1,
                                                                   u16 *__restrict__ rem1, uint8_t *__restrict__ quot2) {
   decrypt_m_body<2>(g, q, p, f, fp, e, B, value, quot1, rem1, quot2);
+}
+
+// decryptBits + packOutput(p - 1, N, value) in one kernel (decrypt_m_body<.., PACK>); `value` may be NULL.
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void k_decrypt_mp(MGeom g, u32 q, u32 p, const int8_t *__restrict__ f,
+                                                              const uint8_t *__restrict__ fp,
+                                                              const u16 *__restrict__ e, long B,
+                                                              uint8_t *__restrict__ value, unsigned long long *__restrict__ packed, int pack_os) {
+  decrypt_m_body<1, false, false, true>(g, q, p, f, fp, e, B, value, nullptr, nullptr, nullptr, packed, pack_os);
 }
 
 #ifdef NTRU_EXPERIMENTS
@@ -458,6 +526,25 @@ __global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void k_decrypt_m8d(MGeom g, u
 NTRU_STAMPS_READER(ntru_debug_read_stamps_dec)
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
+// decryptBits + packOutput fused (k_decrypt_mp): p == 3, the matrix path's range, a 16-byte aligned packed array.
+int ntru_launch_decrypt_pack_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp, const uint16_t *d_e,
+                                    int64_t B, uint8_t *d_value, uint64_t *d_packed, int out_size) {
+  MGeom mg;
+  if (p != 3 || ((uintptr_t)d_packed & 15) != 0 || !make_mgeom(eng, N, q, N, &mg)) return NTRU_NOT_TAKEN;
+  const size_t lds = (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA + (size_t)256 * mg.NT + (((size_t)q + 15) & ~(size_t)15);
+  // the 2-bit image of the values lives in the e_hi stage behind the mod-p tables
+  const size_t m3_end = ((((size_t)4 * N + 4) & ~(size_t)3) + (size_t)4 * N + 1 + 15) & ~(size_t)15, img = ((size_t)8 * (126 * out_size + 16) + 15) & ~(size_t)15;
+  if (lds > 160 * 1024 || m3_end + img > (size_t)32 * mg.pitchA || 126 * out_size + 16 < 32 * mg.NT) return NTRU_NOT_TAKEN;
+  const long nrb = (long)((B + 31) / 32);
+  dim3 grid;
+  if (int rc = resident_grid(eng, k_decrypt_mp, lds, nrb, &grid)) return rc;
+  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_decrypt_mp");
+  hipLaunchKernelGGL(k_decrypt_mp, grid, dim3(BLOCK_THREADS), lds, eng->stream, mg, (u32)q, (u32)p, d_f, d_fp, d_e, (long)B, d_value,
+                     (unsigned long long *)d_packed, out_size);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
 // Kernel paths: 4 -> k_decrypt_m (two free-running workgroups per CU); 5 -> k_decrypt_m8 (one workgroup of two lock-step groups)
 // wherever its LDS fits; 0 = auto -> k_decrypt_m8 where a product takes two rounds of strips (N > 512) and every witness array is
 // asked for: 2.52 against 2.63 ms per 2^20 at N = 821 (profiles/r02_ab_lockstep_phase_masks.txt), 2.16 against 2.24 ms at N = 701;

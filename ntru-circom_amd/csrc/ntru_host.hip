@@ -421,12 +421,13 @@ extern "C" int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, cons
     if (key) if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, p - 1, key, first_item + (uint64_t)o, n, (uint8_t *)d[ir])) return rc;
     if (int rc = ntru_encrypt_batch_dev(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
                                         (uint16_t *)d[ie], nullptr)) return rc;
+    if (decrypt && packed)      // packOutput fused into the decrypt kernel's second epilogue where the matrix path applies (no k_pack launch)
+      return ntru_decrypt_pack_batch_dev(eng, N, q, p, (const int8_t *)d[jf], (const uint8_t *)d[jfp], (const uint16_t *)d[ie], n,
+                                         (uint8_t *)d[iv], (uint64_t *)d[ip]);
     if (decrypt)
-      if (int rc = ntru_decrypt_batch_dev(eng, N, q, p, (const int8_t *)d[jf], (const uint8_t *)d[jfp], (const uint16_t *)d[ie], n,
-                                          (uint8_t *)d[iv], nullptr, nullptr, nullptr)) return rc;
-    if (packed)
-      return decrypt ? ntru_pack_bytes_batch_dev(eng, pack_max, N, (const uint8_t *)d[iv], n, (uint64_t *)d[ip])
-                     : ntru_pack_batch_dev(eng, pack_max, N, (const uint16_t *)d[ie], n, (uint64_t *)d[ip]);
+      return ntru_decrypt_batch_dev(eng, N, q, p, (const int8_t *)d[jf], (const uint8_t *)d[jfp], (const uint16_t *)d[ie], n,
+                                    (uint8_t *)d[iv], nullptr, nullptr, nullptr);
+    if (packed) return ntru_pack_batch_dev(eng, pack_max, N, (const uint16_t *)d[ie], n, (uint64_t *)d[ip]);
     return NTRU_OK;
   });
 }

@@ -46,6 +46,7 @@ _SIGS["ntru_sample_ternary"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, 
 _SIGS["ntru_sample_ternary_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _ip = C.POINTER(C.c_int)
 _SIGS["ntru_pack_params"] = (C.c_int, [_i, _i, _ip, _ip, _ip, _ip])
+_SIGS["ntru_decrypt_pack_batch_dev"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
 for _sfx in ("", "_dev"):
     _SIGS["ntru_pack_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i64, _vp])
     _SIGS["ntru_unpack_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i, _i64, _vp])
@@ -396,6 +397,12 @@ class Engine:
     def invert_key_batch_dev(self, N, q, p, d_f, B, d_fq, d_fp, d_flags):
         dp = self._dp
         self._chk(self._lib.ntru_invert_key_batch_dev(self._h, N, q, p, dp(d_f), B, dp(d_fq), dp(d_fp), dp(d_flags)))
+
+    def decrypt_pack_batch_dev(self, N, q, p, d_f, d_fp, d_e, B, d_value, d_packed):
+        """decryptBits + packOutput(p - 1, N, value) (one kernel on the matrix path); d_value may be None there."""
+        dp = self._dp
+        self._chk(self._lib.ntru_decrypt_pack_batch_dev(self._h, N, q, p, dp(d_f), dp(d_fp), dp(d_e), B, dp(d_value), dp(d_packed)))
+        self._note(N, B, 2 * N + 32 * max(3, -(-N // 126)) + (N if d_value else 0))      # e in; packed rows (+ the plain values) out
 
     def public_key_batch_dev(self, N, q, p, d_fq, d_g, B, d_h):
         dp = self._dp

@@ -16,6 +16,9 @@ int ntru_launch_encrypt_matrix(ntru_engine *eng, int N, int q, int ld, const uin
   fake_enqueue(eng->stream, [=] { fake_encrypt(N, q, d_h, d_r, d_m, B, d_e, d_quotE); });
   return NTRU_OK;
 }
+int ntru_launch_decrypt_pack_matrix(ntru_engine *, int, int, int, const int8_t *, const uint8_t *, const uint16_t *, int64_t, uint8_t *, uint64_t *, int) {
+  return NTRU_NOT_TAKEN;      // the host pipeline then runs decrypt + pack as two (fake) launches
+}
 int ntru_launch_encrypt_rowimage(ntru_engine *, int, int, int, const uint16_t *, const uint8_t *, const uint8_t *, int64_t, uint16_t *, uint16_t *) {
   return NTRU_NOT_TAKEN;
 }

@@ -1256,3 +1256,36 @@ def test_generic_family_waits_for_the_scratch_buffers_previous_stream(eng):
         assert got[0] == ref
     finally:
         eng.set_stream(None)
+
+
+@pytest.mark.parametrize("N,q", [(821, 4096), (701, 8192), (509, 2048), (252, 256), (253, 256), (378, 512), (1000, 1024), (127, 64)])
+def test_decrypt_with_fused_pack_output_equals_oracle(eng, N, q):
+    """ntru_decrypt_pack_batch_dev: decryptBits + packOutput(p - 1, N, value) (index.js:111-140, :572-596) in ONE kernel where the
+    matrix path applies (k_decrypt_mp: 2-bit image of the second product's values -> packed dwords), with and without the plain
+    values; sizes around the 126-column element boundary, ragged batches; against the oracle's decrypt + pack."""
+    import torch
+    p = 3
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N + q)
+    f = ternary_rows(rng, 1, N, N // 3, N // 3 - 1, two=-1)[0].astype(np.int8)
+    fp = rng.integers(0, p, N).astype(np.uint8)
+    tf, tfp = torch.from_numpy(f).to(dev), torch.from_numpy(fp).to(dev)
+    fused = 0
+    for B in (1, 33, 777, 2 * 32 * 256 + 5):            # the last one: several row blocks per workgroup (image wiped and reused)
+        e = rng.integers(0, q, (B, N)).astype(np.uint16)
+        te = torch.from_numpy(e.view(np.int16)).to(dev)
+        v_o = orc.decrypt_batch(N, q, p, f, fp, e, want_witness=False)[0]
+        want = orc.pack_batch(p - 1, N, v_o.astype(np.uint16)).view(np.uint64)
+        for with_value in (True, False):
+            packed = torch.full(want.shape, -1, dtype=torch.int64, device=dev)
+            val = torch.full((B, N), 9, dtype=torch.uint8, device=dev)
+            eng.decrypt_pack_batch_dev(N, q, p, tf.data_ptr(), tfp.data_ptr(), te.data_ptr(), B, val.data_ptr() if with_value else None,
+                                       packed.data_ptr())
+            torch.cuda.synchronize()
+            fused += eng.last_kernel() == "k_decrypt_mp"
+            assert np.array_equal(packed.cpu().numpy().view(np.uint64), want.reshape(packed.shape)), (B, with_value, eng.last_kernel())
+            if with_value:
+                assert np.array_equal(val.cpu().numpy(), v_o), B
+            elif eng.last_kernel() == "k_decrypt_mp":
+                assert int(val.min()) == 9                  # the plain values were not written
+    assert fused == 8 or N < 256                            # the fused kernel is what ran (tiny N: the image does not fit behind the tables)

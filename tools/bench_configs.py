@@ -217,6 +217,35 @@ def pipeline_dev_config(profile, logB, log_chunk=17):
             "rows_equal_oracle": ok, "rows_checked": 3}
 
 
+def decrypt_pack_config(profile, logB):
+    """decryptBits (value only) followed by packOutput(p - 1, N, value): two kernels with the values through HBM, against the fused
+    k_decrypt_mp that writes only the packed field elements (32 ceil(N / 126) bytes per item instead of N + 32 ceil(N / 126))."""
+    o, _, f_np, fp_np = bench.load_key(profile)
+    N, q, p = o["N"], o["q"], o["p"]
+    B = 1 << logB
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    e = torch.randint(0, q, (B, N), dtype=torch.int32, device=dev, generator=gen).to(torch.int16)
+    f = torch.from_numpy(f_np).to(dev); fp = torch.from_numpy(fp_np).to(dev)
+    os_ = max(3, -(-N // 126))
+    v = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    packed = torch.empty((B, os_, 4), dtype=torch.int64, device=dev); packed2 = torch.empty_like(packed)
+
+    def separate():
+        eng.decrypt_batch_dev(N, q, p, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr())
+        eng.pack_bytes_batch_dev(p - 1, N, v.data_ptr(), B, packed.data_ptr())
+    ms_sep = timed(separate)
+    ms_fused = timed(lambda: eng.decrypt_pack_batch_dev(N, q, p, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, None, packed2.data_ptr()))
+    kern = eng.last_kernel()
+    rows = sample_rows(B)
+    v_o = orc.decrypt_batch(N, q, p, f_np, fp_np, host(e, rows), want_witness=False)[0]
+    want = orc.pack_batch(p - 1, N, v_o.astype(np.uint16)).view(np.uint64)
+    ok = bool(np.array_equal(packed2[rows].cpu().numpy().view(np.uint64), want.reshape(len(rows), os_, 4))) and bool(torch.equal(packed, packed2))
+    return {"config": "N=%d q=%d batch=2^%d decryptBits + packOutput(%d, N, value), 1 GPU" % (N, q, logB, p - 1), "kernel": kern,
+            "ms": ms_fused, "items_per_s": B / (ms_fused * 1e-3), "separate_kernels_ms": ms_sep,
+            "bytes_written_per_item": {"fused": 32 * os_, "separate": N + 32 * os_},
+            "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
+
+
 def add_config(N, q, logB):
     B = 1 << logB
     gen = torch.Generator(device=dev); gen.manual_seed(9)
@@ -254,7 +283,8 @@ def polymul_config(N, q, logB):
 
 if __name__ == "__main__":
     for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
-                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), keygen_config("n821_q4096", 18), polymul_config(821, 4096, 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20)):
+                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), keygen_config("n821_q4096", 18), polymul_config(821, 4096, 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20),
+                decrypt_pack_config("n821_q4096", 20)):
         print(json.dumps(res), flush=True)
     if "--no-pipeline" not in sys.argv:       # (uses its own streams: kept out of the rocprofv3 passes of tools/collect_profiles.sh)
         print(json.dumps(pipeline_dev_config("n821_q4096", 20)), flush=True)
