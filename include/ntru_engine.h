@@ -111,8 +111,8 @@ const char *ntru_last_error(void);
  *   key != NULL: r is sampled (n1 ones, n2 entries p - 1, item b from stream position first_item + b); else r [B][N] is read.
  *   f, fp both NULL: encrypt only.
  *   outputs, each optional (at least one): r_out [B][N] (the sampled r, to replay), e [B][N], value [B][N] (needs f, fp),
- *   packed [B][output_size][4] = packOutput(max, N, .) of the LAST stage's result: value with max = p - 1 when decrypting, else e
- *   with max = q - 1 (sizes from ntru_pack_params). */
+ *   packed [B][output_size][4] = packOutput(max, N, .) of the LAST stage's result: value with max = p - 1 when decrypting (then it
+ *   comes out of the decrypt kernel itself: ntru_decrypt_pack_batch_dev), else e with max = q - 1 (sizes from ntru_pack_params). */
 int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *h, const int8_t *f, const uint8_t *fp,
                         const uint32_t *key, uint64_t first_item, int n1, int n2, const uint8_t *r, const uint8_t *m, int64_t B,
                         uint8_t *r_out, uint16_t *e, uint8_t *value, uint64_t *packed);
