@@ -108,3 +108,12 @@ def test_plain_c_consumer_builds_and_fails_loudly_without_a_gpu(lib, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and "no CPU fallback" in out.stderr, out.stdout + out.stderr
     assert "identical" not in out.stdout
+
+
+def test_the_shipped_library_is_not_a_timing_only_build(lib):
+    """Libraries built with -DNTRU_ABLATE / -DRI_ABL compute wrong values on purpose (timing experiments); they say so through
+    ntru_engine_is_timing_only_build, refuse ntru_engine_create unless NTRU_ALLOW_TIMING_ONLY=1 and tag every kernel name.  What
+    ge.build() produces -- the library everything else loads -- must not be one."""
+    assert lib.ntru_engine_is_timing_only_build() == 0
+    src = open(os.path.join(ROOT, "ntru-circom_amd", "csrc", "abi.hip")).read()
+    assert "NTRU_ALLOW_TIMING_ONLY" in src and "TIMING-ONLY" in src        # the guard is in the engine's life cycle, not in a script
