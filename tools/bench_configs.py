@@ -282,9 +282,18 @@ def polymul_config(N, q, logB):
 
 
 if __name__ == "__main__":
-    for res in (encrypt_config("n509_q2048", 20), encrypt_config("n701_q8192", 20), encrypt_config("n821_q4096", 20),
-                verify_config("n821_q4096", 15), verify_config("n821_q4096", 18), keygen_config("n821_q4096", 18), polymul_config(821, 4096, 18), sampler_config("n821_q4096", 20), add_config(821, 4096, 20),
-                decrypt_pack_config("n821_q4096", 20)):
-        print(json.dumps(res), flush=True)
-    if "--no-pipeline" not in sys.argv:       # (uses its own streams: kept out of the rocprofv3 passes of tools/collect_profiles.sh)
-        print(json.dumps(pipeline_dev_config("n821_q4096", 20)), flush=True)
+    # python tools/bench_configs.py [--only NAME[,NAME...]] [--no-pipeline]     NAME: encrypt509 encrypt701 encrypt821 verify15 verify18
+    #                                                                                keygen polymul sampler add decrypt_pack pipeline
+    configs = [("encrypt509", lambda: encrypt_config("n509_q2048", 20)), ("encrypt701", lambda: encrypt_config("n701_q8192", 20)),
+               ("encrypt821", lambda: encrypt_config("n821_q4096", 20)), ("verify15", lambda: verify_config("n821_q4096", 15)),
+               ("verify18", lambda: verify_config("n821_q4096", 18)), ("keygen", lambda: keygen_config("n821_q4096", 18)),
+               ("polymul", lambda: polymul_config(821, 4096, 18)), ("sampler", lambda: sampler_config("n821_q4096", 20)),
+               ("add", lambda: add_config(821, 4096, 20)), ("decrypt_pack", lambda: decrypt_pack_config("n821_q4096", 20)),
+               ("pipeline", lambda: pipeline_dev_config("n821_q4096", 20))]      # (uses its own streams: kept out of the rocprofv3 passes)
+    only = None
+    if "--only" in sys.argv:
+        only = sys.argv[sys.argv.index("--only") + 1].split(",")
+    for name, fn in configs:
+        if (only is not None and name not in only) or (only is None and name == "pipeline" and "--no-pipeline" in sys.argv):
+            continue
+        print(json.dumps(fn()), flush=True)
