@@ -12,7 +12,7 @@ KERNEL_TUS = ("valu_families", "matrix_encrypt", "matrix_decrypt", "matrix_rowim
               "ntru_generic")
 # the shipped library, and the experiments build (kernel paths 6-10: most 16-byte result stores live there; it is tested for
 # bit-exactness too, so its kernels get the same gates): (ASMDIR, EXTRA, fewest wide stores the scan must see)
-BUILDS = {"default": ("/tmp/ntru_asm", "", 100), "experiments": ("/tmp/ntru_asm_exp", "-DNTRU_EXPERIMENTS", 200)}
+BUILDS = {"default": ("/tmp/ntru_asm", "", 4), "experiments": ("/tmp/ntru_asm_exp", "-DNTRU_EXPERIMENTS", 60)}
 
 
 def _asm_usage(build):
