@@ -233,14 +233,17 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
 #pragma unroll UNR
     for (int w = 0; w < NW; w++) {
       u32 g1 = 0, g2 = 0;
-      for (int b = 0; b < 32; b++) {
-        const int i = 32 * w + b;                         // coefficient i of gg is f[N-1-i]
-        if (i < N && have) {
-          int c = fk[N - 1 - i];
-          c = c < 0 ? c + P : c;
-          c %= P;
-          g1 |= (u32)(c == 1) << b;
-          g2 |= (u32)(c == 2) << b;
+#pragma unroll 1                                           // (fully unrolled, the 32 NW tests `i < N` are hoisted out of the key loop and
+      for (int b0 = 0; b0 < 32; b0 += 8) {                //  spilled as ~1650 scalar registers; eight byte loads in flight at a time)
+#pragma unroll
+        for (int bb = 0; bb < 8; bb++) {
+          const int b = b0 + bb, i = 32 * w + b;          // coefficient i of gg is f[N-1-i]
+          if (i < N) {                                    // (lanes without a key work on key 0's row; nothing of theirs is stored)
+            // residue of the int8 in [0, P) without compares: 129 = 0 mod 3, and the parity of a two's complement byte is its residue mod 2
+            const u32 c = P == 2 ? (u32)fk[N - 1 - i] & 1u : (u32)(fk[N - 1 - i] + 129) % 3u;
+            g1 |= (c & 1u) << b;
+            g2 |= (c >> 1) << b;
+          }
         }
       }
       const u32 top = (32 * w <= N && N < 32 * w + 32) ? 1u << (N & 31) : 0u;   // coefficient N of ff is -1
@@ -254,6 +257,17 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       }
     }
     int delta = 1;
+    auto wave_max_abs_delta = [&]() {
+      const u32 ad = have ? (u32)(delta < 0 ? -delta : delta) : 0u;          // (lanes without a key: gg = 0, delta grows for ever)
+      u32 mx = 0;
+      for (int bit = 16; bit >= 0; bit--) {                 // wave maximum by bisection on ballots: scalar work only
+        const u32 c = mx | (1u << bit);
+        if (__ballot(ad >= c) != 0) mx = c;
+      }
+      return (int)mx;
+    };
+    auto word_of = [&](int deg) { const int t = deg >> 5; return t < NW - 1 ? t : NW - 1; };
+    int fg_top = NW - 1, vw_top = 0;
     // GF(3) helpers on (is-one, is-two) plane pairs
     // GF(3), planes (c == 1, c == 2): r = g + cm f with the per-lane scalar cm given as two lane masks (m2: cm == 2, mnz: cm != 0).
     // Seven three-input functions (v_bitop3_b32 each): t = cm f as u = (f0 ^ f1) & m2, t0 = (f0 ^ u) & mnz, t1 = (f1 ^ u) & mnz (the scalar
@@ -267,6 +281,11 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       r1 = (t0 & g0) | (~t0 & h1);
     };
     for (int step = 0; step < 2 * N - 1; step++) {
+      if ((step & 15) == 0) {                             // (before delta moves on: the bounds are for what this step reads)
+        const int mx = wave_max_abs_delta();
+        fg_top = word_of((2 * N - 1 - step + mx) >> 1);
+        vw_top = word_of((step + mx + 34) >> 1);
+      }
       const u32 f0w0 = at(AF, 0, 0), g0w0 = at(AG, 0, 0);
       const u32 f0w1 = P == 3 ? at(AF, 1, 0) : 0u, g0w1 = P == 3 ? at(AG, 1, 0) : 0u;
       const int fc = (int)(f0w0 & 1u) + 2 * (int)(f0w1 & 1u), gc = (int)(g0w0 & 1u) + 2 * (int)(g0w1 & 1u);   // constant terms
@@ -280,18 +299,20 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       const int cm = P == 3 ? (9 - (swap ? fc : gc) * c1) % 3 : 0;
       u32 m2 = cm == 2 ? ~0u : 0u, mnz = cm != 0 ? ~0u : 0u;
       asm volatile("" : "+v"(m2), "+v"(mnz));            // opaque: `x & mask` must stay a bit operation that fuses, not become a select
-      // v and w have degree <= step before this step (v = 0, w = 1 at the start; a step multiplies v by x and adds a multiple of
-      // it to w), so words above (step + 1) / 32 of both are zero before and after it: their half of the work is skipped.  The
-      // bound is the same in every lane (the step counter is), so the test is a scalar branch per word.
-      const int vw_top = (step + 1) >> 5;
+      // Degrees (by induction over the two kinds of step; delta = 1, deg f = N, deg g < N, v = 0, w = 1 at the start), before step n:
+      //   2 deg f <= 2N - 1 - n + delta,  2 deg g <= 2N - 1 - n - delta        (f and g shrink),
+      //   2 deg v <= n - 1 + delta,       2 deg w <= n + 1 - delta             (v and w grow half as fast as the step counter),
+      // so a step touches about N / 32 + 2 words of the four polynomials together instead of 4 N / 32.  delta is per lane: the
+      // maximum of |delta| over the wave's keys is taken every 16th step (at the top of the step).  For f and g the bound at that step
+      // holds for the 15 that follow (n - |delta| never decreases); for v and w those steps are allowed for (|delta| and n move by at
+      // most one per step, and a step writes the polynomials of step n + 1: + 34 in all).  The tests are scalar branches per word.
       // Words from the TOP down: g / x takes its incoming bit from the word above (already computed: `gup`), x v from the word below
       // (not yet overwritten), so every word is read and rewritten in place within its own iteration -- with register planes nothing
       // has to be copied at the end of a step (going up, the results land one word behind and the loop ended in ~100 moves).
       u32 gup[PL];
 #pragma unroll
       for (int pl = 0; pl < PL; pl++) gup[pl] = 0;
-#pragma unroll UNR
-      for (int w = NW - 1; w >= 0; w--) {
+      auto fg_word = [&](int w) {
         u32 F[PL], G[PL];
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
@@ -308,42 +329,121 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
 #pragma unroll
         for (int pl = 0; pl < PL; pl++) {
           at(AF, pl, w) = F[pl];
-          at(AG, pl, w) = __builtin_amdgcn_alignbit(gup[pl], NG[pl], 1);       // g = g / x
+          at(AG, pl, w) = __builtin_amdgcn_alignbit(gup[pl], NG[pl], 1);       // g = g / x (gup = 0 above the top word: zero there)
           gup[pl] = NG[pl];
         }
-        if (w <= vw_top) {
-          u32 V[PL], W[PL], NWW[PL];
+      };
+      auto vw_word = [&](int w) {
+        u32 V[PL], W[PL], NWW[PL];
 #pragma unroll
-          for (int pl = 0; pl < PL; pl++) {
-            W[pl] = at(AW, pl, w);
-            V[pl] = __builtin_amdgcn_alignbit(at(AV, pl, w), w > 0 ? at(AV, pl, w - 1) : 0u, 31);      // v = x v
-            const u32 v_ = V[pl];
-            V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
-          }
-          if (P == 2) {
-            NWW[0] = W[0] ^ (c2m1 & V[0]);
-          } else {
-            madd3(W[0], W[1], V[0], V[1], m2, mnz, NWW[0], NWW[1]);
-          }
+        for (int pl = 0; pl < PL; pl++) {
+          W[pl] = at(AW, pl, w);
+          V[pl] = __builtin_amdgcn_alignbit(at(AV, pl, w), w > 0 ? at(AV, pl, w - 1) : 0u, 31);        // v = x v
+          const u32 v_ = V[pl];
+          V[pl] = swap ? W[pl] : v_; W[pl] = swap ? v_ : W[pl];
+        }
+        if (P == 2) {
+          NWW[0] = W[0] ^ (c2m1 & V[0]);
+        } else {
+          madd3(W[0], W[1], V[0], V[1], m2, mnz, NWW[0], NWW[1]);
+        }
 #pragma unroll
-          for (int pl = 0; pl < PL; pl++) { at(AV, pl, w) = V[pl]; at(AW, pl, w) = NWW[pl]; }
+        for (int pl = 0; pl < PL; pl++) { at(AV, pl, w) = V[pl]; at(AW, pl, w) = NWW[pl]; }
+      };
+      // One test per GROUP of words (a group is worked on when its lowest word is inside the bound), marked likely: the bodies then
+      // stay in line and a group that is worked on costs a compare and a branch that is not taken.  (Left to itself the compiler
+      // moved every body out of line, two taken branches per word; GF(2) has four instructions per word, so small groups cost it
+      // more in tests than they save.)
+      constexpr int GRP = P == 2 ? 8 : 2;                  // measured at N = 821, 2^18 keys: GF(2) 3.3 / 2.5 / 2.6 / 3.0 ms with 4 / 8 / 16 / all words; GF(3) 6.5 / 6.2 / 6.4 with 1 / 2 / 4
+#pragma unroll UNR
+      for (int gb = (NW - 1) / GRP * GRP; gb >= 0; gb -= GRP) {
+        if (__builtin_expect(gb <= fg_top, 1)) {
+#pragma unroll
+          for (int w = gb + GRP - 1; w >= gb; w--) if (w < NW) fg_word(w);
+        }
+        if (__builtin_expect(gb <= vw_top, 1)) {
+#pragma unroll
+          for (int w = gb + GRP - 1; w >= gb; w--) if (w < NW) vw_word(w);
         }
       }
     }
-    // unit iff the gcd (in ff) is a non-zero constant
+    // unit iff the gcd (in ff) is a non-zero constant.  Words above the final bound were left alone once they had become zero
+    // (they may still hold what they held then), so only the words below it are looked at.
+    fg_top = word_of((wave_max_abs_delta()) >> 1);       // n = 2N - 1
     u32 rest = 0;
 #pragma unroll UNR
     for (int w = 0; w < NW; w++)
+      if (w <= fg_top) {
 #pragma unroll
-      for (int pl = 0; pl < PL; pl++) rest |= at(AF, pl, w) & (w == 0 ? ~1u : ~0u);
+        for (int pl = 0; pl < PL; pl++) rest |= at(AF, pl, w) & (w == 0 ? ~1u : ~0u);
+      }
     const int fc = (int)(at(AF, 0, 0) & 1u) + (P == 3 ? 2 * (int)(at(AF, 1, 0) & 1u) : 0);
     const bool unit = rest == 0 && fc != 0;
-    if (have) {
-      if (!unit) flags[key] = (uint8_t)(flags[key] | flag_bit);
-      // inverse[i] = fc^-1 * vv[N-1-i]; in GF(3) fc^-1 = fc
+    if (have && !unit) flags[key] = (uint8_t)(flags[key] | flag_bit);
+    // inverse[i] = fc^-1 * vv[N-1-i]; in GF(3) fc^-1 = fc (the scalar 2 exchanges the planes); zero for a non-unit
+    const bool whole = k0 + 64 <= B && N >= 32 && ((((unsigned long long)out16 | (unsigned long long)out8) & 15) == 0);
+    if (whole) {
+      // The 64 rows of the block are ONE contiguous run of 64 N results that starts on a 64-element boundary.  A store per
+      // coefficient from every lane's own row (64 lines touched per instruction, 821 of them per block) was a THIRD of the kernel's
+      // time; the finished planes go through LDS as [plane][word][lane] instead, and lane L then writes the 16-element pieces
+      // 16 (L + 64 it) of the run: 16 consecutive coefficients are 16 consecutive plane bits (descending), so a piece is one
+      // bit-field read of the key's words (two when it crosses into the next row), reversed and spread to bytes or u16 pairs.
+      u32 *tr = NWC ? base : base + (size_t)(AV * PL) * NW * 64;
+#pragma unroll UNR
+      for (int w = 0; w < NW; w++) {
+        u32 p0 = at(AV, 0, w), p1 = P == 3 ? at(AV, 1, w) : 0u;
+        if (P == 3 && fc == 2) { const u32 t = p0; p0 = p1; p1 = t; }
+        p0 = unit ? p0 : 0u; p1 = unit ? p1 : 0u;
+        tr[(0 * NW + w) * 64 + lane] = p0;
+        if (P == 3) tr[(1 * NW + w) * 64 + lane] = p1;
+      }
+      wave_lds_fence();
+      const u32 uN = (u32)N, inv = 0xFFFFFFFFu / uN + 1u, total = 64u * uN;       // e / N = umulhi(e, inv): exact while 64 N^2 < 2^32
+      auto seg = [&](const u32 *pw, u32 nf) {               // the (up to) 16 coefficients from N - nf on, coefficient order, of one plane of one key
+        u32 x;
+        if (nf >= 16u) {
+          const u32 lo = nf - 16u, w = lo >> 5;
+          const u32 hi_w = (int)w + 1 < NW ? pw[64 * (w + 1)] : 0u;
+          x = __builtin_amdgcn_alignbit(hi_w, pw[64 * w], lo & 31u) & 0xFFFFu;
+        } else {
+          x = (pw[0] << (16u - nf)) & 0xFFFFu;
+        }
+        return __builtin_bitreverse32(x) >> 16;
+      };
+      auto spread4 = [](u32 nib) { return (nib * 0x00204081u) & 0x01010101u; };       // bit j of a nibble -> byte j
+      for (u32 e = 16u * (u32)lane; e < total; e += 1024u) {
+        const u32 kk = __umulhi(e, inv), i = e - kk * uN, nf = uN - i;
+        u32 f0 = seg(tr + kk, nf), f1 = P == 3 ? seg(tr + (size_t)NW * 64 + kk, nf) : 0u;
+        if (nf < 16u) {                                     // the piece goes on in row kk + 1 (which exists: 64 N is a multiple of 16)
+          f0 |= seg(tr + kk + 1, uN) << nf;
+          if (P == 3) f1 |= seg(tr + (size_t)NW * 64 + kk + 1, uN) << nf;
+          f0 &= 0xFFFFu; f1 &= 0xFFFFu;
+        }
+        const size_t at0 = (size_t)k0 * N + e;
+        if (out8) {
+          u32 o[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) o[c] = spread4((f0 >> (4 * c)) & 15u) + 2u * spread4((f1 >> (4 * c)) & 15u);
+          *(uint4 *)(out8 + at0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (out16) {
+          u32 o[8];
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const u32 s0 = (f0 >> (2 * c)) & 3u, s1 = (f1 >> (2 * c)) & 3u;
+            o[c] = ((s0 & 1u) | (s0 & 2u) << 15) + 2u * ((s1 & 1u) | (s1 & 2u) << 15);
+          }
+          *(uint4 *)(out16 + at0) = make_uint4(o[0], o[1], o[2], o[3]);
+          *(uint4 *)(out16 + at0 + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+      }
+      wave_lds_fence();                                     // (LDS planes: the next block's set-up writes them)
+    } else if (have) {
+      // partial last block, unaligned outputs, tiny N: one store per coefficient from every lane's own row
 #pragma unroll UNR
       for (int w = 0; w < NW; w++) {
         const u32 p0 = at(AV, 0, w), p1 = P == 3 ? at(AV, 1, w) : 0u;
+#pragma unroll 1
         for (int b = 0; b < 32; b++) {
           const int i = N - 1 - (32 * w + b);
           if (i < 0) break;
@@ -501,7 +601,8 @@ static const int64_t INVERT_CHUNK = 1 << 16;   // keys per set of Newton tempora
 template <int P, int NWC>
 static int launch_invert_nw(ntru_engine *eng, int N, const int8_t *d_f, long B, uint16_t *d16, uint8_t *d8, uint8_t *d_flags,
                             unsigned bit) {
-  const size_t lds = NWC ? 0 : (size_t)(P == 2 ? 4 : 8) * ((N + 32) / 32) * 64 * 4;
+  // planes in LDS (NWC = 0), or only the transposition buffer of the results: [plane][word][lane]
+  const size_t lds = NWC ? (size_t)(P == 2 ? 1 : 2) * NWC * 64 * 4 : (size_t)(P == 2 ? 4 : 8) * ((N + 32) / 32) * 64 * 4;
   if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the inversion kernel's LDS planes");
   int per_cu = 0;
   if (int rc = ntru_blocks_per_cu(eng, (const void *)k_invert_key<P, NWC>, 64, lds, &per_cu)) return rc;

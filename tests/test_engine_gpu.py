@@ -584,6 +584,45 @@ def test_key_inversion_captured_cases_and_random_keys(eng):
         assert all(np.array_equal(rem3[i], one) for i in range(B) if ok[i])
 
 
+def test_key_inversion_whole_block_output_equals_the_per_coefficient_path(eng):
+    """k_invert_key writes a whole block of 64 keys through LDS as one contiguous run when the outputs are 16-byte aligned, and one
+    coefficient at a time otherwise (unaligned outputs, the partial last block, N < 32): both on the same keys -- with non-units
+    among them, whose rows are zero -- must agree byte for byte, for register planes (N = 107, 509, 821) and LDS planes (N = 1024)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    for N, q, d in ((107, 64, 35), (509, 2048, 169), (821, 4096, 273), (1024, 2048, 341), (17, 32, 5)):
+        B = 64 * 3 + 5
+        f = ternary_rows(rng, B, N, d, d - 1, two=-1).astype(np.int8)
+        f[3] = 0                                             # not a unit modulo anything
+        f[70] = 0; f[70, 0] = 1; f[70, 1] = 1                # 1 + x: f(1) = 2, not a unit modulo 2
+        f[130] = 0; f[130, 0] = 1; f[130, 1] = 1; f[130, 2] = 1   # 1 + x + x^2: f(1) = 3, not a unit modulo 3
+        fd = torch.from_numpy(f).to(dev)
+        out = {}
+        for shift in (0, 1):                                 # element offset of the outputs: 0 = aligned, 1 = 2 / 1 byte(s) off
+            fq = torch.zeros(B * N + 8, dtype=torch.int16, device=dev); fp = torch.zeros(B * N + 16, dtype=torch.uint8, device=dev)
+            fl = torch.zeros(B, dtype=torch.uint8, device=dev)
+            assert fq.data_ptr() % 16 == 0 and fp.data_ptr() % 16 == 0
+            eng.invert_key_batch_dev(N, q, 3, fd.data_ptr(), B, fq.data_ptr() + 2 * shift, fp.data_ptr() + shift, fl.data_ptr())
+            torch.cuda.synchronize()
+            out[shift] = (fq[shift:shift + B * N].cpu().numpy().reshape(B, N), fp[shift:shift + B * N].cpu().numpy().reshape(B, N),
+                          fl.cpu().numpy())
+            assert int(fq[shift + B * N:].abs().sum()) == 0 and int(fp[shift + B * N:].sum()) == 0     # nothing past the last row
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b), N
+        fq, fp, fl = out[0]
+        assert fl[3] & pkg.engine.FLAG_NOT_UNIT_MOD2 and fl[3] & pkg.engine.FLAG_NOT_UNIT_MODP
+        assert fl[70] & pkg.engine.FLAG_NOT_UNIT_MOD2 and fl[130] & pkg.engine.FLAG_NOT_UNIT_MODP
+        assert not fp[3].any() and not fp[130].any()         # (fq of a mod-2 non-unit is whatever Newton makes of zero: only fp is pinned)
+        ok = fl == 0
+        assert ok.sum() >= 20                                # (x^N - 1 has many factors for some of these N: units are not the rule)
+        one = np.zeros(N, np.int64); one[0] = 1
+        _, rem3 = orc.polymul_split_batch(N, 3, f.astype(np.int64) % 3, fp)
+        assert all(np.array_equal(rem3[i], one) for i in range(B) if not fl[i] & pkg.engine.FLAG_NOT_UNIT_MODP)
+        _, rem = orc.polymul_split_batch(N, q, f.astype(np.int64) % q, fq.astype(np.int64) % q)
+        assert all(np.array_equal(rem[i], one) for i in range(B) if ok[i])
+
+
 def test_load_private_key_equals_reference_on_every_captured_f(eng):
     """loadPrivateKeyF through the host mirror on all 123 captured f (tests/golden/keygen_cases.json): the reference's fq
     and fp where it returns, its message where it throws -- including the non-units its `&&` checks accept, which the
