@@ -479,6 +479,15 @@ __global__ void k_newton_combine_vec(u16x8 *__restrict__ v, const u16x8 *__restr
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x)
     v[i] = ((u16)2 * v[i] - u[i]) & (u16)(q - 1);                        // q | 2^16: wrapped 16-bit arithmetic is exact mod q
 }
+// the same round in its lifted form: v <- (v - 2^k w) mod q, w = e * v, e = (f v - 1) / 2^k
+__global__ void k_newton_lift(u16 *__restrict__ v, const u16 *__restrict__ w, long first, long n, u32 k, u32 q) {
+  for (long i = first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    v[i] = (u16)((v[i] - (w[i] << k)) & (q - 1));
+}
+__global__ void k_newton_lift_vec(u16x8 *__restrict__ v, const u16x8 *__restrict__ w, long nvec, u32 k, u32 q) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x)
+    v[i] = (v[i] - (w[i] << (u16)k)) & (u16)(q - 1);
+}
 
 // ---- BN254 field-element packing (index.js:572-620): elementwise, HBM-bound ---------------------------------------
 // One thread per 64-bit limb of the output: out[b][o] = sum_j data[b][o*per + j] << (j*bits), four LE limbs per element.
@@ -687,30 +696,40 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   if (int rc = launch_invert<2>(eng, N, d_f, (long)B, d_fq, nullptr, d_flags, NTRU_FLAG_NOT_UNIT_MOD2)) return rc;
   if (rounds > 0) {
     struct { void *p; } f16{sc}, t{sc + part}, u{sc + 2 * part}, qs{sc + 3 * part};
+    bool need_f16 = false;                                 // f as u16 residues: only the vector-ALU form of a round reads it
+    for (int r = 0; r < rounds; r++) need_f16 |= !ntru_product_tern_matrix_applies(eng, N, (2 << r) >= k ? q : 1 << (2 << r));
     for (int64_t o = 0; o < B; o += C) {
       const int64_t n = B - o < C ? B - o : C;
       uint16_t *v = d_fq + o * N;
-      hipLaunchKernelGGL(k_signed_to_u16, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, d_f + o * N, (long)(n * N),
-                         (u32)q, (u16 *)f16.p);
+      if (need_f16) hipLaunchKernelGGL(k_signed_to_u16, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, d_f + o * N, (long)(n * N),
+                                       (u32)q, (u16 *)f16.p);
       for (int r = 0; r < rounds; r++) {
         // Hensel lifting: round r only has to be right modulo 2^(2^(r+1)); the early rounds therefore run modulo 4, 16,
         // 256 (single int8 digit planes on the matrix cores), the last one modulo q.  The inverse modulo q is unique.
         const int mr = (2 << r) >= k ? q : 1 << (2 << r);
-        int rc_vv = ntru_launch_polymul_matrix(eng, N, mr, v, v, n, nullptr, (uint16_t *)t.p);       // v * v: only the remainder is used
-        if (rc_vv == NTRU_NOT_TAKEN) rc_vv = ntru_polymul_split_dev(eng, N, mr, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p);
-        if (rc_vv) return rc_vv;
-        if (ntru_product_tern_matrix_applies(eng, N, mr)) {         // f * t with f ternary: per-item product on the matrix cores
-          if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, (const uint16_t *)t.p, d_f + o * N, (long)n, nullptr, (uint16_t *)u.p)) return rc;
-        } else if (int rc = ntru_polymul_split_dev(eng, N, mr, (const uint16_t *)f16.p, (const uint16_t *)t.p, n,
-                                                   (uint16_t *)qs.p, (uint16_t *)u.p)) return rc;
-        {
-          const long tot = (long)(n * N);
-          const long nvec = ((((unsigned long long)v | (unsigned long long)u.p) & 15) == 0) ? tot / 8 : 0;
-          if (nvec) hipLaunchKernelGGL(k_newton_combine_vec, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u16x8 *)v,
-                                       (const u16x8 *)u.p, nvec, (u32)mr);
-          if (nvec * 8 < tot) hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, tot - nvec * 8), dim3(256), 0, eng->stream, (u16 *)v,
-                                                 (const u16 *)u.p, nvec * 8, tot, (u32)mr);
+        const long tot = (long)(n * N);
+        const long nvec = ((((unsigned long long)v | (unsigned long long)u.p) & 15) == 0) ? tot / 8 : 0;
+        if (ntru_product_tern_matrix_applies(eng, N, mr)) {
+          // Per-item products on the matrix cores, the round in its LIFTED form.  v is right modulo 2^kb (kb = 2^r bits), so
+          // f v = 1 + 2^kb e and v (2 - f v) = v - 2^kb (e v) modulo mr = 2^m, m <= 2 kb: only e v modulo 2^(m - kb) is needed, a
+          // product of operands of at most kb bits (ONE int8 digit plane each, also in the last round, whose v * v form takes
+          // two planes and three matrix instructions per step).  The ternary product stores e directly (nshift).
+          const int kb = 1 << r, m = (2 << r) >= k ? k : 2 << r, me = 1 << (m - kb);
+          if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, v, d_f + o * N, (long)n, nullptr, (uint16_t *)t.p, (uint32_t)kb)) return rc;
+          if (int rc = ntru_launch_polymul_matrix(eng, N, me, (const uint16_t *)t.p, v, n, nullptr, (uint16_t *)u.p)) return rc;
+          if (nvec) hipLaunchKernelGGL(k_newton_lift_vec, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u16x8 *)v,
+                                       (const u16x8 *)u.p, nvec, (u32)kb, (u32)mr);
+          if (nvec * 8 < tot) hipLaunchKernelGGL(k_newton_lift, elementwise_grid(eng, tot - nvec * 8), dim3(256), 0, eng->stream, (u16 *)v,
+                                                 (const u16 *)u.p, nvec * 8, tot, (u32)kb, (u32)mr);
+          continue;
         }
+        // vector-ALU families: v <- 2 v - f v^2
+        if (int rc = ntru_polymul_split_dev(eng, N, mr, v, v, n, (uint16_t *)qs.p, (uint16_t *)t.p)) return rc;
+        if (int rc = ntru_polymul_split_dev(eng, N, mr, (const uint16_t *)f16.p, (const uint16_t *)t.p, n, (uint16_t *)qs.p, (uint16_t *)u.p)) return rc;
+        if (nvec) hipLaunchKernelGGL(k_newton_combine_vec, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u16x8 *)v,
+                                     (const u16x8 *)u.p, nvec, (u32)mr);
+        if (nvec * 8 < tot) hipLaunchKernelGGL(k_newton_combine, elementwise_grid(eng, tot - nvec * 8), dim3(256), 0, eng->stream, (u16 *)v,
+                                               (const u16 *)u.p, nvec * 8, tot, (u32)mr);
       }
       HIP_TRY(hipGetLastError());                          // the next chunk reuses the temporaries in stream order
     }

@@ -400,9 +400,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
 
 // One per-item product on the matrix cores: rem (and quot) of ((mul a) mod q) * s split by 1 - x^N, a < 2^16 per item,
 // s ternary per item: generatePublicKeyH (index.js:72-79, mul = p) and the f * t product of polyInv's Newton rounds
-// (index.js:499-506, mul = 1).  Same machinery as k_verify_keys_m.
+// (index.js:499-506, mul = 1; there the remainder leaves as (f v - 1) / 2^nshift, see ntru_invert_key_batch_dev).  Same machinery
+// as k_verify_keys_m.
 __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_product_tern_m(
-    PGeom g, u32 q, u32 mul, const u16 *__restrict__ a, const int8_t *__restrict__ s, long B, u16 *__restrict__ quot,
+    PGeom g, u32 q, u32 mul, u32 nshift, const u16 *__restrict__ a, const int8_t *__restrict__ s, long B, u16 *__restrict__ quot,
     u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
@@ -464,7 +465,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
-        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
+        u32 rv = (u32)(lo + hi) & (q - 1);
+        // nshift = k > 0 (a Newton round of the key inversion, a = v with f v = 1 mod 2^k): what is stored is e = (f v - 1) / 2^k
+        if (nshift) rv = ((rv - (i == 0 && kl == 0 ? 1u : 0u)) & (q - 1)) >> nshift;
+        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
         if (want_q) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);   // (a store through an empty descriptor is dropped, but issued)
       }
     }
@@ -640,12 +644,12 @@ int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t 
 bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q) { return peritem_applies(eng, N, q); }
 
 int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s, long B,
-                                    uint16_t *d_quot, uint16_t *d_rem) {
+                                    uint16_t *d_quot, uint16_t *d_rem, uint32_t nshift) {
   const PGeom pg = make_pgeom(N);
   const size_t lds = PI_WAVES * pi_wave_bytes(pg);
   dim3 grid;
   if (int rc = peritem_grid(eng, k_product_tern_m, lds, B, &grid)) return rc;
-  hipLaunchKernelGGL(k_product_tern_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, (u32)mul, d_a, d_s, B, d_quot, d_rem);
+  hipLaunchKernelGGL(k_product_tern_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, (u32)mul, (u32)nshift, d_a, d_s, B, d_quot, d_rem);
   HIP_TRY(hipGetLastError());
   return NTRU_OK;
 }
