@@ -229,10 +229,66 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
     const long key = k0 + lane;
     const bool have = key < B;
     const int8_t *fk = f + (have ? key : 0) * N;
-    // ff = rev(x^N - 1) = 1 - x^N, gg = rev_{N-1}(f), vv = 0, ww = 1
+    // gg = rev_{N-1}(f) as bit planes: plane bit j of a key is the residue flag of f[N-1-j].  A whole block of 64 keys is ONE contiguous,
+    // 64-byte aligned run of 64 N bytes: lane L loads its 16-byte pieces 16 (L + 64 it), turns the 16 int8 into residue flags on
+    // packed bytes, and ORs the (reversed) bit field into the words of the key(s) the piece belongs to, in LDS as [plane][word][key];
+    // then every lane reads its own key's words.  (A byte load per coefficient from every lane's own row -- 64 lines per
+    // instruction -- was a fifth of the mod-2 inversion.)
+    const bool whole_in = k0 + 64 <= B && N >= 32 && (((unsigned long long)f & 15) == 0);
+    u32 *tin = NWC ? base : base + (size_t)(AG * PL) * NW * 64;
+    if (whole_in) {
+      for (int w = 0; w < PL * NW; w++) tin[w * 64 + lane] = 0;
+      wave_lds_fence();
+      const uint4 *src = (const uint4 *)(f + (size_t)k0 * N);
+      const u32 uN = (u32)N, inv = 0xFFFFFFFFu / uN + 1u, total = 64u * uN;       // e / N = umulhi(e, inv): exact while 64 N^2 < 2^32
+      auto put = [&](u32 *pw, u32 lo, u32 n, u32 x) {       // coefficients c .. c + n - 1 (bit j of x: c + j) = plane bits lo + n - 1 .. lo of one key
+        const u32 rev = __builtin_bitreverse32(x & ((1u << n) - 1u)) >> (32u - n);
+        const u32 w = lo >> 5, sh = lo & 31u;
+        if (rev) {
+          atomicOr(pw + 64 * w, rev << sh);
+          if (sh + n > 32u && (rev >> (32u - sh))) atomicOr(pw + 64 * (w + 1), rev >> (32u - sh));
+        }
+      };
+      for (u32 e = 16u * (u32)lane, it = 0; e < total; e += 1024u, it++) {
+        const uint4 d4 = src[lane + 64 * it];
+        const u32 d[4] = {d4.x, d4.y, d4.z, d4.w};
+        u32 x0 = 0, x1 = 0;                                 // bit j: byte j is 1 / is 2 modulo P
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          u32 r0, r1 = 0;
+          if (P == 2) {
+            r0 = d[c] & 0x01010101u;                        // the parity of a two's complement byte is its residue modulo 2
+          } else {
+            // int8 modulo 3 on four packed bytes: 4 = 1 (mod 3), so a byte is congruent to the sum of its base-4 digits, + 2 if its sign
+            // bit is set (-256 = 2 mod 3); two more digit sums bring that into 0..3, where 3 stands for 0
+            const u32 s1 = (d[c] & 0x33333333u) + ((d[c] >> 2) & 0x33333333u);
+            const u32 s2 = (s1 & 0x0F0F0F0Fu) + ((s1 >> 4) & 0x0F0F0F0Fu) + ((d[c] >> 6) & 0x02020202u);
+            const u32 u = (s2 & 0x03030303u) + ((s2 >> 2) & 0x03030303u);
+            const u32 v = (u & 0x03030303u) + ((u >> 2) & 0x03030303u);
+            r0 = v & ~(v >> 1) & 0x01010101u;
+            r1 = (v >> 1) & ~v & 0x01010101u;
+          }
+          x0 |= (((r0 * 0x00204081u) >> 21) & 15u) << (4 * c);          // bit 0 of byte j -> bit j
+          x1 |= (((r1 * 0x00204081u) >> 21) & 15u) << (4 * c);
+        }
+        const u32 kk = __umulhi(e, inv), i = e - kk * uN, nf = uN - i, na = nf < 16u ? nf : 16u;
+        put(tin + kk, nf - na, na, x0);
+        if (P == 3) put(tin + (size_t)NW * 64 + kk, nf - na, na, x1);
+        if (nf < 16u) {                                     // the piece goes on in row kk + 1 (which exists: 64 N is a multiple of 16)
+          put(tin + kk + 1, uN - (16u - nf), 16u - nf, x0 >> nf);
+          if (P == 3) put(tin + (size_t)NW * 64 + kk + 1, uN - (16u - nf), 16u - nf, x1 >> nf);
+        }
+      }
+      wave_lds_fence();
+    }
+    // ff = rev(x^N - 1) = 1 - x^N, gg, vv = 0, ww = 1
 #pragma unroll UNR
     for (int w = 0; w < NW; w++) {
       u32 g1 = 0, g2 = 0;
+      if (whole_in) {
+        g1 = tin[(0 * NW + w) * 64 + lane];
+        if (P == 3) g2 = tin[(1 * NW + w) * 64 + lane];
+      } else
 #pragma unroll 1                                           // (fully unrolled, the 32 NW tests `i < N` are hoisted out of the key loop and
       for (int b0 = 0; b0 < 32; b0 += 8) {                //  spilled as ~1650 scalar registers; eight byte loads in flight at a time)
 #pragma unroll
@@ -258,7 +314,7 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
     }
     int delta = 1;
     auto wave_max_abs_delta = [&]() {
-      const u32 ad = have ? (u32)(delta < 0 ? -delta : delta) : 0u;          // (lanes without a key: gg = 0, delta grows for ever)
+      const u32 ad = have ? (u32)(delta < 0 ? -delta : delta) : 0u;          // (lanes without a key work on key 0's row)
       u32 mx = 0;
       for (int bit = 16; bit >= 0; bit--) {                 // wave maximum by bisection on ballots: scalar work only
         const u32 c = mx | (1u << bit);
