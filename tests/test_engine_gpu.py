@@ -587,11 +587,12 @@ def test_key_inversion_captured_cases_and_random_keys(eng):
 def test_key_inversion_whole_block_output_equals_the_per_coefficient_path(eng):
     """k_invert_key writes a whole block of 64 keys through LDS as one contiguous run when the outputs are 16-byte aligned, and one
     coefficient at a time otherwise (unaligned outputs, the partial last block, N < 32): both on the same keys -- with non-units
-    among them, whose rows are zero -- must agree byte for byte, for register planes (N = 107, 509, 821) and LDS planes (N = 1024)."""
+    among them, whose rows are zero -- must agree byte for byte, for register planes (N = 107, 509, 821; N = 1000: GF(2) only) and LDS
+    planes (N = 1024, 1919)."""
     import torch
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(77)
-    for N, q, d in ((107, 64, 35), (509, 2048, 169), (821, 4096, 273), (1024, 2048, 341), (17, 32, 5)):
+    for N, q, d in ((107, 64, 35), (509, 2048, 169), (821, 4096, 273), (1000, 2048, 333), (1024, 2048, 341), (1919, 2048, 600), (17, 32, 5)):
         B = 64 * 3 + 5
         f = ternary_rows(rng, B, N, d, d - 1, two=-1).astype(np.int8)
         f[3] = 0                                             # not a unit modulo anything
