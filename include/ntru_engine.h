@@ -112,7 +112,8 @@ const char *ntru_last_error(void);
  *   f, fp both NULL: encrypt only.
  *   outputs, each optional (at least one): r_out [B][N] (the sampled r, to replay), e [B][N], value [B][N] (needs f, fp),
  *   packed [B][output_size][4] = packOutput(max, N, .) of the LAST stage's result: value with max = p - 1 when decrypting (then it
- *   comes out of the decrypt kernel itself: ntru_decrypt_pack_batch_dev), else e with max = q - 1 (sizes from ntru_pack_params). */
+ *   comes out of the decrypt kernel itself: ntru_decrypt_pack_batch_dev), else e with max = q - 1 (out of the encrypt kernel itself when
+ *   e is not asked for as well: ntru_encrypt_pack_batch_dev; sizes from ntru_pack_params). */
 int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, const uint16_t *h, const int8_t *f, const uint8_t *fp,
                         const uint32_t *key, uint64_t first_item, int n1, int n2, const uint8_t *r, const uint8_t *m, int64_t B,
                         uint8_t *r_out, uint16_t *e, uint8_t *value, uint64_t *packed);
@@ -308,6 +309,13 @@ int ntru_pack_bytes_batch_dev(ntru_engine_t *eng, int max_val, int data_len, con
  * epilogue and d_value may be NULL (nothing but the packed rows is written); elsewhere it is decrypt + pack and d_value is needed. */
 int ntru_decrypt_pack_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp,
                                 const uint16_t *d_e, int64_t B, uint8_t *d_value, uint64_t *d_packed);
+/* encryptBits (index.js:87-110) + packOutput(q - 1, N, e) (index.js:572-596) of its result, device pointers: d_packed
+ * [B][output_size][4] (sizes from ntru_pack_params(q - 1, N, ...)).  With d_e == NULL and where the row-image matrix kernel applies
+ * (shared key, q in {2048, 4096, 8192}, N <= 1024, d_packed 16-byte aligned) this is ONE kernel that writes nothing but the packed
+ * rows (32 output_size bytes per ciphertext instead of 2 N + 32 output_size); with d_e != NULL, or elsewhere, it is encrypt (e only)
+ * + pack, and d_e is needed. */
+int ntru_encrypt_pack_batch_dev(ntru_engine_t *eng, int N, int q, const uint16_t *d_h, const uint8_t *d_r, const uint8_t *d_m,
+                                int64_t B, uint16_t *d_e, uint64_t *d_packed);
 int ntru_unpack_batch(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *in, int packed_size, int64_t B,
                       uint16_t *out);
 int ntru_unpack_batch_dev(ntru_engine_t *eng, int max_val, int packed_bits, const uint64_t *d_in, int packed_size,

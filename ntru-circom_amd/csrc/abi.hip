@@ -281,6 +281,26 @@ extern "C" int ntru_decrypt_pack_batch_dev(ntru_engine_t *eng, int N, int q, int
   return ntru_pack_bytes_batch_dev(eng, p - 1, N, d_value, B, d_packed);
 }
 
+// encryptBits (index.js:87-110) followed by packOutput(q - 1, N, e) (index.js:572-596): ONE kernel where the row-image matrix kernel
+// applies and the caller does not ask for e itself (d_e == NULL: nothing but the packed rows is written), else encrypt + pack as two
+// launches (then d_e is the intermediate: NTRU_ERR_ARG without it).
+extern "C" int ntru_encrypt_pack_batch_dev(ntru_engine_t *eng, int N, int q, const uint16_t *d_h, const uint8_t *d_r, const uint8_t *d_m,
+                                           int64_t B, uint16_t *d_e, uint64_t *d_packed) {
+  if (int rc = ntru_check_common(eng, N, q, B)) return rc;
+  int bits, per, al, os;
+  if (int rc = ntru_pack_params(q - 1, N, &bits, &per, &al, &os)) return rc;
+  if (B == 0) return NTRU_OK;
+  if (!d_h || !d_r || !d_m || !d_packed) return fail(NTRU_ERR_ARG, "ntru_encrypt_pack_batch: NULL buffer");
+  HIP_TRY(hipSetDevice(eng->device));
+  if (!d_e && (eng->path == 0 || eng->path >= 4)) {
+    const int rc = ntru_launch_encrypt_pack_rowimage(eng, N, q, d_h, d_r, d_m, B, d_packed, os);
+    if (rc != NTRU_NOT_TAKEN) return rc;
+  }
+  if (!d_e) return fail(NTRU_ERR_ARG, "ntru_encrypt_pack_batch: outside the fused kernel's range d_e is needed as the intermediate");
+  if (int rc = ntru_encrypt_batch_dev(eng, N, q, d_h, d_r, d_m, B, d_e, nullptr)) return rc;
+  return ntru_pack_batch_dev(eng, q - 1, N, d_e, B, d_packed);
+}
+
 extern "C" int ntru_polymul_split_dev(ntru_engine_t *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b,
                                       int64_t B, uint16_t *d_quot, uint16_t *d_rem) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");

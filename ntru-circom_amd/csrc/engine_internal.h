@@ -135,6 +135,8 @@ NTRU_HIDDEN int ntru_launch_decrypt_pack_matrix(ntru_engine *eng, int N, int q, 
 // the row-image variants (matrix_rowimage.hip): dense rows, one eight-wave workgroup per CU, results leave through LDS images
 NTRU_HIDDEN int ntru_launch_encrypt_rowimage(ntru_engine *eng, int N, int q, int ld, const uint16_t *d_h, const uint8_t *d_r,
                                              const uint8_t *d_m, int64_t B, uint16_t *d_e, uint16_t *d_quotE);
+NTRU_HIDDEN int ntru_launch_encrypt_pack_rowimage(ntru_engine *eng, int N, int q, const uint16_t *d_h, const uint8_t *d_r, const uint8_t *d_m,
+                                                  int64_t B, uint64_t *d_packed, int os);
 // the same on the vector-ALU families (dense rows); never NTRU_NOT_TAKEN
 NTRU_HIDDEN int ntru_launch_encrypt_valu(ntru_engine *eng, int N, int q, const uint16_t *d_h, const uint8_t *d_r, const uint8_t *d_m,
                                          int64_t B, uint16_t *d_e, uint16_t *d_quotE);

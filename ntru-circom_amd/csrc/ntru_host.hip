@@ -419,6 +419,15 @@ extern "C" int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, cons
   const int ip = packed ? P.out(packed, (size_t)os * 32) : -1;
   return P.run(B, chunk_items(B), [&](int64_t o, int64_t n, void **d) {
     if (key) if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, p - 1, key, first_item + (uint64_t)o, n, (uint8_t *)d[ir])) return rc;
+    if (!decrypt && packed) {   // packOutput of e: out of the encrypt kernel itself when e is not an output too and the row-image kernel applies
+      if (!e) {
+        const int rc = ntru_encrypt_pack_batch_dev(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
+                                                   nullptr, (uint64_t *)d[ip]);
+        if (rc != NTRU_ERR_ARG) return rc;                 // (NTRU_ERR_ARG: outside the fused kernel's range -- e as the intermediate, below)
+      }
+      return ntru_encrypt_pack_batch_dev(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
+                                         (uint16_t *)d[ie], (uint64_t *)d[ip]);
+    }
     if (int rc = ntru_encrypt_batch_dev(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
                                         (uint16_t *)d[ie], nullptr)) return rc;
     if (decrypt && packed)      // packOutput fused into the decrypt kernel's second epilogue where the matrix path applies (no k_pack launch)
@@ -427,7 +436,6 @@ extern "C" int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, cons
     if (decrypt)
       return ntru_decrypt_batch_dev(eng, N, q, p, (const int8_t *)d[jf], (const uint8_t *)d[jfp], (const uint16_t *)d[ie], n,
                                     (uint8_t *)d[iv], nullptr, nullptr, nullptr);
-    if (packed) return ntru_pack_batch_dev(eng, pack_max, N, (const uint16_t *)d[ie], n, (uint64_t *)d[ip]);
     return NTRU_OK;
   });
 }

@@ -47,6 +47,7 @@ _SIGS["ntru_sample_ternary_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint
 _ip = C.POINTER(C.c_int)
 _SIGS["ntru_pack_params"] = (C.c_int, [_i, _i, _ip, _ip, _ip, _ip])
 _SIGS["ntru_decrypt_pack_batch_dev"] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
+_SIGS["ntru_encrypt_pack_batch_dev"] = (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp])
 for _sfx in ("", "_dev"):
     _SIGS["ntru_pack_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i64, _vp])
     _SIGS["ntru_unpack_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _vp, _i, _i64, _vp])
@@ -403,6 +404,13 @@ class Engine:
         dp = self._dp
         self._chk(self._lib.ntru_decrypt_pack_batch_dev(self._h, N, q, p, dp(d_f), dp(d_fp), dp(d_e), B, dp(d_value), dp(d_packed)))
         self._note(N, B, 2 * N + 32 * max(3, -(-N // 126)) + (N if d_value else 0))      # e in; packed rows (+ the plain values) out
+
+    def encrypt_pack_batch_dev(self, N, q, d_h, d_r, d_m, B, d_e, d_packed):
+        """encryptBits + packOutput(q - 1, N, e) (one kernel with d_e None where the row-image matrix kernel applies)."""
+        dp = self._dp
+        self._chk(self._lib.ntru_encrypt_pack_batch_dev(self._h, N, q, dp(d_h), dp(d_r), dp(d_m), B, dp(d_e), dp(d_packed)))
+        bits = max(1, (q - 1).bit_length())
+        self._note(N, B, 2 * N + 32 * max(3, -(-N // (252 // bits))) + (2 * N if d_e else 0))   # r, m in; packed rows (+ e) out
 
     def public_key_batch_dev(self, N, q, p, d_fq, d_g, B, d_h):
         dp = self._dp

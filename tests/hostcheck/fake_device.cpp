@@ -22,6 +22,9 @@ int ntru_launch_decrypt_pack_matrix(ntru_engine *, int, int, int, const int8_t *
 int ntru_launch_encrypt_rowimage(ntru_engine *, int, int, int, const uint16_t *, const uint8_t *, const uint8_t *, int64_t, uint16_t *, uint16_t *) {
   return NTRU_NOT_TAKEN;
 }
+int ntru_launch_encrypt_pack_rowimage(ntru_engine *, int, int, const uint16_t *, const uint8_t *, const uint8_t *, int64_t, uint64_t *, int) {
+  return NTRU_NOT_TAKEN;      // the host pipeline then runs encrypt + pack as two (fake) launches
+}
 int ntru_launch_encrypt_valu(ntru_engine *, int, int, const uint16_t *, const uint8_t *, const uint8_t *, int64_t, uint16_t *, uint16_t *) {
   return ntru_fail(NTRU_ERR_UNSUPPORTED, "fake device: matrix launcher only");
 }

@@ -38,7 +38,7 @@ def test_no_kernel_spills_to_scratch(build):
     # their loops: measured slower than the int8 kernels anyway, profiles/r04_fp4_product2.txt -- not worth a register diet)
     bad = [(n, s) for n, s in zip(names, scratch) if s and not (build == "experiments" and ("k_decrypt_mq" in n or "k_decrypt_m8q" in n) and s <= 96)]
     assert not bad, bad
-    for must in ("k_encrypt_t", "k_decrypt_s", "k_encrypt", "k_decrypt", "k_verify_keys", "k_polymul_split"):
+    for must in ("k_encrypt_t", "k_decrypt_s", "k_encrypt", "k_decrypt", "k_verify_keys", "k_polymul_split", "k_encrypt_wp", "k_decrypt_mp"):
         assert any(must in n for n in names), must
     if build == "experiments":
         for must in ("k_encrypt_m2", "k_encrypt_mc", "k_encrypt_m8", "k_decrypt_m8d", "k_encrypt_w", "k_decrypt_m8q"):

@@ -1309,6 +1309,46 @@ def test_generic_family_waits_for_the_scratch_buffers_previous_stream(eng):
         eng.set_stream(None)
 
 
+@pytest.mark.parametrize("N,q", [(821, 4096), (701, 8192), (509, 2048), (1021, 4096), (64, 2048), (821, 1024), (1100, 4096)])
+def test_encrypt_with_fused_pack_output_equals_oracle(eng, N, q):
+    """ntru_encrypt_pack_batch_dev: encryptBits + packOutput(q - 1, N, e) (index.js:87-110, :572-596) in ONE kernel (k_encrypt_wp: the
+    row block's raw image drained as field elements) when e itself is not asked for and q is 2048 / 4096 / 8192; the two-launch form
+    with e as the intermediate otherwise; 11-, 12- and 13-bit fields, a row's last element of 1 .. per fields, ragged batches, several
+    row blocks per workgroup; against the oracle's encrypt + pack.  Outside the fused range without e: NTRU_ERR_ARG."""
+    import torch
+    p = 3
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N * 7 + q)
+    h = rng.integers(0, q, N).astype(np.uint16)
+    th = torch.from_numpy(h.view(np.int16)).to(dev)
+    can_fuse = q in (2048, 4096, 8192) and N <= 1024         # ... and the row block's image fits the LDS (N <= ~890)
+    must_fuse = can_fuse and N <= 850
+    fused = refused = 0
+    for B in (1, 33, 777, 2 * 32 * 256 + 5):
+        r = ternary_rows(rng, B, N, N // 3, N // 3, two=p - 1).astype(np.uint8)
+        m = rng.integers(0, 2, (B, N)).astype(np.uint8)
+        tr, tm = torch.from_numpy(r).to(dev), torch.from_numpy(m).to(dev)
+        e_o = orc.encrypt_batch(N, q, h, r, m, want_quot=False)[0]
+        want = orc.pack_batch(q - 1, N, e_o).view(np.uint64)
+        for with_e in (True, False):
+            packed = torch.full(want.shape, -1, dtype=torch.int64, device=dev)
+            te = torch.full((B, N), 9, dtype=torch.int16, device=dev)
+            try:
+                eng.encrypt_pack_batch_dev(N, q, th.data_ptr(), tr.data_ptr(), tm.data_ptr(), B, te.data_ptr() if with_e else None, packed.data_ptr())
+            except pkg.engine.EngineError:
+                assert not with_e and not must_fuse         # outside the fused kernel's range e is needed as the intermediate
+                refused += 1
+                continue
+            torch.cuda.synchronize()
+            fused += eng.last_kernel() == "k_encrypt_wp"
+            assert np.array_equal(packed.cpu().numpy().view(np.uint64), want.reshape(packed.shape)), (B, with_e, eng.last_kernel())
+            if with_e:
+                assert np.array_equal(te.cpu().numpy().view(np.uint16), e_o), B
+            else:
+                assert int(te.min()) == 9 and int(te.max()) == 9      # e was not written
+    assert fused + refused == 4 and (fused == 4 if must_fuse else True) and (fused == 0 if not can_fuse else True)
+
+
 @pytest.mark.parametrize("N,q", [(821, 4096), (701, 8192), (509, 2048), (252, 256), (253, 256), (378, 512), (1000, 1024), (127, 64)])
 def test_decrypt_with_fused_pack_output_equals_oracle(eng, N, q):
     """ntru_decrypt_pack_batch_dev: decryptBits + packOutput(p - 1, N, value) (index.js:111-140, :572-596) in ONE kernel where the

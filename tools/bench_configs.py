@@ -246,6 +246,35 @@ def decrypt_pack_config(profile, logB):
             "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
 
 
+def encrypt_pack_config(profile, logB):
+    """encryptBits (e only) followed by packOutput(q - 1, N, e): two kernels with e through HBM, against the fused k_encrypt_wp that
+    writes only the packed field elements (32 ceil(N / per) bytes per item instead of 2 N + 32 ceil(N / per))."""
+    o, h_np, _, _ = bench.load_key(profile)
+    N, q, p, d = o["N"], o["q"], o["p"], o["dr"]
+    B = 1 << logB
+    gen = torch.Generator(device=dev); gen.manual_seed(12)
+    key = (np.arange(8, dtype=np.uint32) * 0x9E3779B1 + 3).astype(np.uint32)
+    r = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    eng.sample_ternary_dev(N, d, d, p - 1, key, 0, B, r.data_ptr())
+    m = torch.randint(0, 2, (B, N), dtype=torch.uint8, device=dev, generator=gen)
+    h = torch.from_numpy(h_np.view(np.int16)).to(dev)
+    bits = (q - 1).bit_length(); per = 252 // bits
+    os_ = max(3, -(-N // per))
+    e = torch.empty((B, N), dtype=torch.int16, device=dev)
+    packed = torch.empty((B, os_, 4), dtype=torch.int64, device=dev); packed2 = torch.empty_like(packed)
+    ms_sep = timed(lambda: eng.encrypt_pack_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e.data_ptr(), packed.data_ptr()))
+    ms_fused = timed(lambda: eng.encrypt_pack_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, None, packed2.data_ptr()))
+    kern = eng.last_kernel()
+    rows = sample_rows(B)
+    e_o = orc.encrypt_batch(N, q, h_np, host(r, rows), host(m, rows), want_quot=False)[0]
+    want = orc.pack_batch(q - 1, N, e_o).view(np.uint64)
+    ok = bool(np.array_equal(packed2[rows].cpu().numpy().view(np.uint64), want.reshape(len(rows), os_, 4))) and bool(torch.equal(packed, packed2))
+    return {"config": "N=%d q=%d batch=2^%d encryptBits + packOutput(%d, N, e), 1 GPU" % (N, q, logB, q - 1), "kernel": kern,
+            "ms": ms_fused, "items_per_s": B / (ms_fused * 1e-3), "separate_kernels_ms": ms_sep,
+            "bytes_written_per_item": {"fused": 32 * os_, "separate": 2 * N + 32 * os_},
+            "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
+
+
 def add_config(N, q, logB):
     B = 1 << logB
     gen = torch.Generator(device=dev); gen.manual_seed(9)
@@ -283,12 +312,13 @@ def polymul_config(N, q, logB):
 
 if __name__ == "__main__":
     # python tools/bench_configs.py [--only NAME[,NAME...]] [--no-pipeline]     NAME: encrypt509 encrypt701 encrypt821 verify15 verify18
-    #                                                                                keygen polymul sampler add decrypt_pack pipeline
+    #                                                                                keygen polymul sampler add decrypt_pack encrypt_pack pipeline
     configs = [("encrypt509", lambda: encrypt_config("n509_q2048", 20)), ("encrypt701", lambda: encrypt_config("n701_q8192", 20)),
                ("encrypt821", lambda: encrypt_config("n821_q4096", 20)), ("verify15", lambda: verify_config("n821_q4096", 15)),
                ("verify18", lambda: verify_config("n821_q4096", 18)), ("keygen", lambda: keygen_config("n821_q4096", 18)),
                ("polymul", lambda: polymul_config(821, 4096, 18)), ("sampler", lambda: sampler_config("n821_q4096", 20)),
                ("add", lambda: add_config(821, 4096, 20)), ("decrypt_pack", lambda: decrypt_pack_config("n821_q4096", 20)),
+               ("encrypt_pack", lambda: encrypt_pack_config("n821_q4096", 20)),
                ("pipeline", lambda: pipeline_dev_config("n821_q4096", 20))]      # (uses its own streams: kept out of the rocprofv3 passes)
     only = None
     if "--only" in sys.argv:
