@@ -1221,6 +1221,7 @@ def test_pipeline_batch_equals_oracle_stage_by_stage(eng, N, q, d, B):
     assert list(lean) == ["value"] and np.array_equal(lean["value"], v_o)
     enc = eng.pipeline_batch(N, q, p, h, m, r=r_o, want_packed=True)                       # encrypt only, r given, packed ciphertext
     assert list(enc) == ["packed"] and np.array_equal(enc["packed"], orc.pack_batch(q - 1, N, e_o))
+    assert (eng.last_kernel() == "k_encrypt_wp") == (q in (2048, 4096, 8192))               # fused where the row-image kernel applies
     for bad in (dict(key=key, r=r_o, want_e=True), dict(want_e=True), dict(key=key, want_value=True), dict(key=key)):
         with pytest.raises(pkg.EngineError):
             eng.pipeline_batch(N, q, p, h, m, n1=d, n2=d, **bad)
