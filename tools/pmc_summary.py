@@ -41,6 +41,8 @@ def short(name):
     fam = m.group(1)
     if m.group(2) is None:
         return fam
+    if fam == "k_encrypt_wp":                                      # k_encrypt_wp<BITS>: the engine reports the family name alone
+        return fam
     args = [x.strip() for x in m.group(2).split(",")]
     if fam == "k_decrypt_s" and args[-1] in ("true", "false"):     # k_decrypt_s<K, ME, D8>: the engine reports "k_decrypt_s+dot8<K,ME>"
         fam += "+dot8" if args.pop() == "true" else ""
