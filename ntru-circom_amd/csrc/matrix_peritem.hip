@@ -487,7 +487,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes2(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
+  // (q <= 256: one digit plane per operand, the second reversed array does not exist -- 12.5 instead of 19.3 KB of LDS per wave, twelve
+  // instead of eight waves per CU: the launcher sizes the workgroup's LDS the same way)
+  unsigned char *fa0 = lds + (size_t)wave * (q <= 256 ? pi_wave_bytes(g) : pi_wave_bytes2(g)), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
   u32 *T0 = (u32 *)(fa1 + pi_fa_bytes(g)), *T1 = T0 + 4 * g.tpitch;
   const int N = g.N, NT = g.NT;
   for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
@@ -632,7 +634,7 @@ int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t 
                                uint16_t *d_rem) {
   if (!peritem_applies(eng, N, mod)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
-  const size_t lds = PI_WAVES * pi_wave_bytes2(pg);
+  const size_t lds = PI_WAVES * (mod <= 256 ? pi_wave_bytes(pg) : pi_wave_bytes2(pg));
   dim3 grid;
   if (int rc = peritem_grid(eng, k_polymul_m, lds, (long)B, &grid)) return rc;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
