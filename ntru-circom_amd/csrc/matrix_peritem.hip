@@ -19,6 +19,10 @@ static __host__ __device__ inline size_t pi_nat_bytes(const PGeom &g) { return (
 // per wave: the two chunk matrices, then the reversed array.  The three natural-order periods the array is built from
 // are staged OVER the chunk matrices (2 fa >= nat for every N <= 1024) and wiped again before the digits go in.
 static __host__ __device__ inline size_t pi_wave_bytes(const PGeom &g) { return 2 * pi_fa_bytes(g) + (size_t)16 * g.tpitch; }
+// single digit plane (q <= 256): ONE chunk matrix (with room for the natural-order staging that lies over it) and the reversed array
+static __host__ __device__ inline size_t pi_one_bytes(const PGeom &g) {
+  return (pi_fa_bytes(g) > pi_nat_bytes(g) ? pi_fa_bytes(g) : pi_nat_bytes(g)) + (size_t)16 * g.tpitch;
+}
 
 // Reversed cyclic array (4 byte-shifted copies) of the 16 bytes per lane in sv (coefficients 16 lane .. 16 lane + 15 of a
 // ternary operand, zero at and beyond N): three periods in natural order (period k starts at byte k N, any alignment:
@@ -402,15 +406,19 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
 // s ternary per item: generatePublicKeyH (index.js:72-79, mul = p) and the f * t product of polyInv's Newton rounds
 // (index.js:499-506, mul = 1; there the remainder leaves as (f v - 1) / 2^nshift, see ntru_invert_key_batch_dev).  Same machinery
 // as k_verify_keys_m.
-__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_product_tern_m(
+// ONE: a single int8 digit plane (q <= 256: the early Newton rounds): half the accumulators, no second chunk matrix -- 128 registers and
+// 9.7 KB of LDS per wave, i.e. FOUR waves per SIMD instead of three.
+template <bool ONE>
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(ONE ? 4 : 3, 4))) void k_product_tern_m(
     PGeom g, u32 q, u32 mul, u32 nshift, const u16 *__restrict__ a, const int8_t *__restrict__ s, long B, u16 *__restrict__ quot,
     u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
-  u32 *T = (u32 *)(fa1 + pi_fa_bytes(g));
+  const size_t fa_region = ONE ? pi_one_bytes(g) - (size_t)16 * g.tpitch : 2 * pi_fa_bytes(g);
+  unsigned char *fa0 = lds + (size_t)wave * (ONE ? pi_one_bytes(g) : pi_wave_bytes(g)), *fa1 = ONE ? fa0 : fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T = (u32 *)(fa0 + fa_region);
   const int N = g.N, NT = g.NT;
-  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  for (size_t i = 16 * lane; i < fa_region; i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
   const int y0 = 32 * NT - 1 - r + 16 * hh;
   const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
   const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
@@ -450,13 +458,12 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
         v4i o0, o1;
         pi_digits(xa, q, mul, 16 * lane, N, o0, o1);
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
-        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
+        if (!ONE) *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
       }
       wave_lds_fence();
     }
     v16i L0, L1, H0, H1;
-    if (q <= 256) pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);   // one digit plane (early Newton rounds, small q)
-    else pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
+    pi_product<!ONE>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);       // ONE: one digit plane (early Newton rounds, small q)
     {
       const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
@@ -482,24 +489,27 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
 // accumulator groups, two reversed arrays (the digit planes of b) per item.
 static __host__ __device__ inline size_t pi_wave_bytes2(const PGeom &g) { return pi_wave_bytes(g) + (size_t)16 * g.tpitch; }
 
-__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_polymul_m(
+// ONE (q <= 256: one digit plane per operand -- every Newton round of the key inversion in its lifted form): no second chunk matrix,
+// no second reversed array, half the accumulators: 9.7 instead of 19.3 KB of LDS per wave and 128 registers, i.e. sixteen instead of
+// eight waves per CU.
+template <bool ONE>
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(ONE ? 4 : 3, 4))) void k_polymul_m(
     PGeom g, u32 q, const u16 *__restrict__ a, const u16 *__restrict__ b, long B, u16 *__restrict__ quot,
     u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  // (q <= 256: one digit plane per operand, the second reversed array does not exist -- 12.5 instead of 19.3 KB of LDS per wave, twelve
-  // instead of eight waves per CU: the launcher sizes the workgroup's LDS the same way)
-  unsigned char *fa0 = lds + (size_t)wave * (q <= 256 ? pi_wave_bytes(g) : pi_wave_bytes2(g)), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
-  u32 *T0 = (u32 *)(fa1 + pi_fa_bytes(g)), *T1 = T0 + 4 * g.tpitch;
+  const size_t fa_region = ONE ? pi_one_bytes(g) - (size_t)16 * g.tpitch : 2 * pi_fa_bytes(g);
+  unsigned char *fa0 = lds + (size_t)wave * (ONE ? pi_one_bytes(g) : pi_wave_bytes2(g)), *fa1 = ONE ? fa0 : fa0 + pi_fa_bytes(g), *nat = fa0;
+  u32 *T0 = (u32 *)(fa0 + fa_region), *T1 = T0 + 4 * g.tpitch;
   const int N = g.N, NT = g.NT;
-  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  for (size_t i = 16 * lane; i < fa_region; i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
   const int y0 = 32 * NT - 1 - r + 16 * hh;
   const u32 *tb0 = T0 + (y0 & 3) * g.tpitch + (y0 >> 2), *tb1 = tb0 + 4 * g.tpitch;
   const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
   u32 mlow[4];
   diag_low_mask(lane, mlow);
   const bool stager = 16 * lane < 32 * NT;
-  const bool one = q <= 256;                               // single int8 plane per operand (pi_digits)
+  constexpr bool one = ONE;                                // single int8 plane per operand (pi_digits)
   const bool want_q = quot != nullptr;                     // the Newton rounds of the key inversion only need the remainder
   wave_lds_fence();
   const long item_step = (long)gridDim.x * PI_WAVES;         // the NEXT item's operands are requested early: see k_product_tern_m
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       STAMP(3);                                            // reversed arrays
       if (stager) {
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = a0;
-        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
+        if (!one) *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
       }
       wave_lds_fence();
     }
@@ -546,8 +556,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
     // The loop lives on its LDS reads (phase stamps, profiles/r03_phase_stamps_peritem.txt: ~250 clocks per step = what 12 waves x 4 KB
     // cost the CU's LDS), so the single-plane form (q <= 256: the early Newton rounds) must not read the second plane's operands.
-    auto loops = [&](auto one_c) {
-      constexpr bool ONE = decltype(one_c)::value;
+    auto loops = [&]() {
       auto ld = [&](int d, v4i &x0, v4i &x1, v4i &w0, v4i &w1) {
         const u32 *p0 = tb0 - 8 * d;
         w0 = (v4i){(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3]};
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
         x0 = n0; x1 = n1; w0 = m0; w1 = m1;
       }
     };
-    if (one) loops(std::true_type{}); else loops(std::false_type{});
+    loops();
     STAMP(5);                                              // matrix loops
     {
       const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
@@ -634,13 +643,15 @@ int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t 
                                uint16_t *d_rem) {
   if (!peritem_applies(eng, N, mod)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
-  const size_t lds = PI_WAVES * (mod <= 256 ? pi_wave_bytes(pg) : pi_wave_bytes2(pg));
   dim3 grid;
-  if (int rc = peritem_grid(eng, k_polymul_m, lds, (long)B, &grid)) return rc;
-  snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
-  hipLaunchKernelGGL(k_polymul_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b, (long)B, d_quot, d_rem);
-  HIP_TRY(hipGetLastError());
-  return NTRU_OK;
+  auto go = [&](auto kern, size_t lds) -> int {
+    if (int rc = peritem_grid(eng, kern, lds, (long)B, &grid)) return rc;
+    snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
+    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b, (long)B, d_quot, d_rem);
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  };
+  return mod <= 256 ? go(k_polymul_m<true>, PI_WAVES * pi_one_bytes(pg)) : go(k_polymul_m<false>, PI_WAVES * pi_wave_bytes2(pg));
 }
 
 bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q) { return peritem_applies(eng, N, q); }
@@ -648,12 +659,14 @@ bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q) { re
 int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s, long B,
                                     uint16_t *d_quot, uint16_t *d_rem, uint32_t nshift) {
   const PGeom pg = make_pgeom(N);
-  const size_t lds = PI_WAVES * pi_wave_bytes(pg);
   dim3 grid;
-  if (int rc = peritem_grid(eng, k_product_tern_m, lds, B, &grid)) return rc;
-  hipLaunchKernelGGL(k_product_tern_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, (u32)mul, (u32)nshift, d_a, d_s, B, d_quot, d_rem);
-  HIP_TRY(hipGetLastError());
-  return NTRU_OK;
+  auto go = [&](auto kern, size_t lds) -> int {
+    if (int rc = peritem_grid(eng, kern, lds, B, &grid)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, (u32)mul, (u32)nshift, d_a, d_s, B, d_quot, d_rem);
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  };
+  return q <= 256 ? go(k_product_tern_m<true>, PI_WAVES * pi_one_bytes(pg)) : go(k_product_tern_m<false>, PI_WAVES * pi_wave_bytes(pg));
 }
 
 int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const int8_t *d_g, const uint16_t *d_fq,
