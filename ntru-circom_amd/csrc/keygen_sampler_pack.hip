@@ -713,6 +713,11 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   while ((1 << k) < q) k++;
   int rounds = 0;
   while ((1 << rounds) < k) rounds++;
+  // precision schedule, halved backwards from log2 q (12: 1, 2, 3, 6, 12; 13: 1, 2, 4, 7, 13): as many rounds as doubling from 1 takes, but
+  // the v a round starts from has at most 7 bits whenever log2 q <= 14, i.e. ONE non-negative int8 digit plane in every product
+  int bits_of[18];
+  bits_of[rounds] = k;
+  for (int r = rounds; r > 0; r--) bits_of[r - 1] = (bits_of[r] + 1) / 2;
   const int64_t C = B < INVERT_CHUNK ? B : INVERT_CHUNK;     // Newton temporaries for C keys at a time
   const size_t row = (size_t)N * 2, part = rounds > 0 ? ((size_t)C * row + 255) & ~(size_t)255 : 0;
   const size_t fl_bytes = d_fp ? ((size_t)B + 255) & ~(size_t)255 : 0;
@@ -753,25 +758,25 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   if (rounds > 0) {
     struct { void *p; } f16{sc}, t{sc + part}, u{sc + 2 * part}, qs{sc + 3 * part};
     bool need_f16 = false;                                 // f as u16 residues: only the vector-ALU form of a round reads it
-    for (int r = 0; r < rounds; r++) need_f16 |= !ntru_product_tern_matrix_applies(eng, N, (2 << r) >= k ? q : 1 << (2 << r));
+    for (int r = 0; r < rounds; r++) need_f16 |= !ntru_product_tern_matrix_applies(eng, N, 1 << bits_of[r + 1]);
     for (int64_t o = 0; o < B; o += C) {
       const int64_t n = B - o < C ? B - o : C;
       uint16_t *v = d_fq + o * N;
       if (need_f16) hipLaunchKernelGGL(k_signed_to_u16, elementwise_grid(eng, n * N), dim3(256), 0, eng->stream, d_f + o * N, (long)(n * N),
                                        (u32)q, (u16 *)f16.p);
       for (int r = 0; r < rounds; r++) {
-        // Hensel lifting: round r only has to be right modulo 2^(2^(r+1)); the early rounds therefore run modulo 4, 16,
-        // 256 (single int8 digit planes on the matrix cores), the last one modulo q.  The inverse modulo q is unique.
-        const int mr = (2 << r) >= k ? q : 1 << (2 << r);
+        // Hensel lifting: round r takes v from kb = bits_of[r] to m = bits_of[r + 1] <= 2 kb bits, i.e. runs modulo mr = 2^m (the last
+        // one modulo q).  The inverse modulo q is unique.
+        const int kb = bits_of[r], m = bits_of[r + 1], mr = 1 << m;
         const long tot = (long)(n * N);
         const long nvec = ((((unsigned long long)v | (unsigned long long)u.p) & 15) == 0) ? tot / 8 : 0;
         if (ntru_product_tern_matrix_applies(eng, N, mr)) {
-          // Per-item products on the matrix cores, the round in its LIFTED form.  v is right modulo 2^kb (kb = 2^r bits), so
+          // Per-item products on the matrix cores, the round in its LIFTED form.  v is right modulo 2^kb, so
           // f v = 1 + 2^kb e and v (2 - f v) = v - 2^kb (e v) modulo mr = 2^m, m <= 2 kb: only e v modulo 2^(m - kb) is needed, a
           // product of operands of at most kb bits (ONE int8 digit plane each, also in the last round, whose v * v form takes
           // two planes and three matrix instructions per step).  The ternary product stores e directly (nshift).
-          const int kb = 1 << r, m = (2 << r) >= k ? k : 2 << r, me = 1 << (m - kb);
-          if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, v, d_f + o * N, (long)n, nullptr, (uint16_t *)t.p, (uint32_t)kb)) return rc;
+          const int me = 1 << (m - kb);
+          if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, v, d_f + o * N, (long)n, nullptr, (uint16_t *)t.p, (uint32_t)kb, kb)) return rc;
           if (int rc = ntru_launch_polymul_matrix(eng, N, me, (const uint16_t *)t.p, v, n, nullptr, (uint16_t *)u.p)) return rc;
           if (nvec) hipLaunchKernelGGL(k_newton_lift_vec, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u16x8 *)v,
                                        (const u16x8 *)u.p, nvec, (u32)kb, (u32)mr);

@@ -456,7 +456,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
       pi_build_array(nat, T, g, lane, u.v);
       if (stager) {
         v4i o0, o1;
-        pi_digits(xa, q, mul, 16 * lane, N, o0, o1);
+        // (ONE with q > 256: the caller vouches for a < 128 -- a Newton round whose v has at most 7 bits -- and such an a is its own
+        // centred representative modulo 256; the result is still reduced modulo q)
+        pi_digits(xa, ONE && q > 256 ? 256u : q, mul, 16 * lane, N, o0, o1);
         *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
         if (!ONE) *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
       }
@@ -657,7 +659,7 @@ int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t 
 bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q) { return peritem_applies(eng, N, q); }
 
 int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s, long B,
-                                    uint16_t *d_quot, uint16_t *d_rem, uint32_t nshift) {
+                                    uint16_t *d_quot, uint16_t *d_rem, uint32_t nshift, int abits) {
   const PGeom pg = make_pgeom(N);
   dim3 grid;
   auto go = [&](auto kern, size_t lds) -> int {
@@ -666,7 +668,9 @@ int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul
     HIP_TRY(hipGetLastError());
     return NTRU_OK;
   };
-  return q <= 256 ? go(k_product_tern_m<true>, PI_WAVES * pi_one_bytes(pg)) : go(k_product_tern_m<false>, PI_WAVES * pi_wave_bytes(pg));
+  // one digit plane: q <= 256, or every a[i] below 2^abits <= 128 (then mul must be 1)
+  return q <= 256 || (abits <= 7 && mul == 1u) ? go(k_product_tern_m<true>, PI_WAVES * pi_one_bytes(pg))
+                                               : go(k_product_tern_m<false>, PI_WAVES * pi_wave_bytes(pg));
 }
 
 int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const int8_t *d_g, const uint16_t *d_fq,
