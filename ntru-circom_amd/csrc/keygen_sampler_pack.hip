@@ -535,15 +535,6 @@ __global__ void k_newton_combine_vec(u16x8 *__restrict__ v, const u16x8 *__restr
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x)
     v[i] = ((u16)2 * v[i] - u[i]) & (u16)(q - 1);                        // q | 2^16: wrapped 16-bit arithmetic is exact mod q
 }
-// the same round in its lifted form: v <- (v - 2^k w) mod q, w = e * v, e = (f v - 1) / 2^k
-__global__ void k_newton_lift(u16 *__restrict__ v, const u16 *__restrict__ w, long first, long n, u32 k, u32 q) {
-  for (long i = first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    v[i] = (u16)((v[i] - (w[i] << k)) & (q - 1));
-}
-__global__ void k_newton_lift_vec(u16x8 *__restrict__ v, const u16x8 *__restrict__ w, long nvec, u32 k, u32 q) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x)
-    v[i] = (v[i] - (w[i] << (u16)k)) & (u16)(q - 1);
-}
 
 // ---- BN254 field-element packing (index.js:572-620): elementwise, HBM-bound ---------------------------------------
 // One thread per 64-bit limb of the output: out[b][o] = sum_j data[b][o*per + j] << (j*bits), four LE limbs per element.
@@ -777,11 +768,8 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
           // two planes and three matrix instructions per step).  The ternary product stores e directly (nshift).
           const int me = 1 << (m - kb);
           if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, v, d_f + o * N, (long)n, nullptr, (uint16_t *)t.p, (uint32_t)kb, kb)) return rc;
-          if (int rc = ntru_launch_polymul_matrix(eng, N, me, (const uint16_t *)t.p, v, n, nullptr, (uint16_t *)u.p)) return rc;
-          if (nvec) hipLaunchKernelGGL(k_newton_lift_vec, elementwise_grid(eng, nvec, true), dim3(256), 0, eng->stream, (u16x8 *)v,
-                                       (const u16x8 *)u.p, nvec, (u32)kb, (u32)mr);
-          if (nvec * 8 < tot) hipLaunchKernelGGL(k_newton_lift, elementwise_grid(eng, tot - nvec * 8), dim3(256), 0, eng->stream, (u16 *)v,
-                                                 (const u16 *)u.p, nvec * 8, tot, (u32)kb, (u32)mr);
+          // ... and the generic product lifts v in place: v <- (v - 2^kb w) mod mr comes out of its epilogue
+          if (int rc = ntru_launch_polymul_matrix(eng, N, me, (const uint16_t *)t.p, v, n, nullptr, nullptr, v, kb, mr)) return rc;
           continue;
         }
         // vector-ALU families: v <- 2 v - f v^2

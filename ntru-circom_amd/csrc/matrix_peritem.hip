@@ -496,8 +496,8 @@ static __host__ __device__ inline size_t pi_wave_bytes2(const PGeom &g) { return
 // eight waves per CU.
 template <bool ONE>
 __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(ONE ? 4 : 3, 4))) void k_polymul_m(
-    PGeom g, u32 q, const u16 *__restrict__ a, const u16 *__restrict__ b, long B, u16 *__restrict__ quot,
-    u16 *__restrict__ rem) {
+    PGeom g, u32 q, const u16 *__restrict__ a, const u16 *b, long B, u16 *__restrict__ quot,
+    u16 *__restrict__ rem, u16 *lift_v, u32 lift_k, u32 lift_q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
   const size_t fa_region = ONE ? pi_one_bytes(g) - (size_t)16 * g.tpitch : 2 * pi_fa_bytes(g);
@@ -601,10 +601,27 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
         x0 = n0; x1 = n1; w0 = m0; w1 = m1;
       }
     };
+    // lift_v (a Newton round of the key inversion in its lifted form, ntru_invert_key_batch_dev): what leaves is not the product w but
+    // v <- (v - 2^lift_k w) mod lift_q on the item's row of lift_v, read here in the accumulator layout (it is the b row this item
+    // staged a moment ago: an L2 hit) -- the round's third kernel and its two passes over HBM are gone.
+    const int kl = 128 * hh + r;                                         // see k_verify_keys_m: indices >= N are dropped
+    u16 vold[16];
+    if (lift_v) {
+      const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(lift_v + row, 2L * N);
+#pragma unroll
+      for (int i = 0; i < 16; i++) vold[i] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_v, 2 * kl, 2 * 32 * ((i & 3) + 8 * (i >> 2)), 0);
+    }
     loops();
     STAMP(5);                                              // matrix loops
-    {
-      const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
+    if (lift_v) {
+      const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(lift_v + row, 2L * N);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
+        const u32 w = ((u32)L0[i] + 128u * (u32)L1[i] + (u32)H0[i] + 128u * (u32)H1[i]) & (q - 1);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)(((u32)vold[i] - (w << lift_k)) & (lift_q - 1)), rs_v, 2 * kl, 2 * ko, 0);
+      }
+    } else {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
       const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quot + row : nullptr, want_q ? 2L * N : 0L);
 #pragma unroll
@@ -642,14 +659,15 @@ static int peritem_grid(ntru_engine *eng, Kern kern, size_t lds, long B, dim3 *g
 }
 
 int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B, uint16_t *d_quot,
-                               uint16_t *d_rem) {
+                               uint16_t *d_rem, uint16_t *d_lift_v, int lift_k, int lift_q) {
   if (!peritem_applies(eng, N, mod)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
   dim3 grid;
   auto go = [&](auto kern, size_t lds) -> int {
     if (int rc = peritem_grid(eng, kern, lds, (long)B, &grid)) return rc;
     snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
-    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b, (long)B, d_quot, d_rem);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b, (long)B, d_quot, d_rem, (u16 *)d_lift_v,
+                       (u32)lift_k, (u32)lift_q);
     HIP_TRY(hipGetLastError());
     return NTRU_OK;
   };

@@ -39,7 +39,7 @@ int ntru_launch_decrypt_valu(ntru_engine *, int, int, int, const int8_t *, const
   return ntru_fail(NTRU_ERR_UNSUPPORTED, "fake device: matrix launcher only");
 }
 int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B, uint16_t *d_quot,
-                               uint16_t *d_rem) {
+                               uint16_t *d_rem, uint16_t *, int, int) {
   fake_enqueue(eng->stream, [=] { fake_polymul(N, mod, d_a, d_b, B, d_quot, d_rem); });
   return NTRU_OK;
 }
