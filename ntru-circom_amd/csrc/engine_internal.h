@@ -144,6 +144,7 @@ NTRU_HIDDEN int ntru_launch_decrypt_valu(ntru_engine *eng, int N, int q, int p, 
                                          const uint16_t *d_e, int64_t B, uint8_t *d_value, uint16_t *d_quot1, uint16_t *d_rem1,
                                          uint8_t *d_quot2);
 // per-item products
+NTRU_HIDDEN int ntru_launch_newton_round_matrix(ntru_engine *eng, int N, int kb, int m, const int8_t *d_f, uint16_t *d_v, long B);
 NTRU_HIDDEN int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B,
                                            uint16_t *d_quot, uint16_t *d_rem, uint16_t *d_lift_v = nullptr, int lift_k = 0, int lift_q = 0);
 NTRU_HIDDEN int ntru_launch_polymul_valu(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B,

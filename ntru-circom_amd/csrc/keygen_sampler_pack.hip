@@ -766,6 +766,11 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
           // f v = 1 + 2^kb e and v (2 - f v) = v - 2^kb (e v) modulo mr = 2^m, m <= 2 kb: only e v modulo 2^(m - kb) is needed, a
           // product of operands of at most kb bits (ONE int8 digit plane each, also in the last round, whose v * v form takes
           // two planes and three matrix instructions per step).  The ternary product stores e directly (nshift).
+          {                                                   // ... as ONE kernel while v has at most 7 bits (log2 q <= 14)
+            const int rc = ntru_launch_newton_round_matrix(eng, N, kb, m, d_f + o * N, v, (long)n);
+            if (rc == NTRU_OK) continue;
+            if (rc != NTRU_NOT_TAKEN) return rc;
+          }
           const int me = 1 << (m - kb);
           if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, v, d_f + o * N, (long)n, nullptr, (uint16_t *)t.p, (uint32_t)kb, kb)) return rc;
           // ... and the generic product lifts v in place: v <- (v - 2^kb w) mod mr comes out of its epilogue

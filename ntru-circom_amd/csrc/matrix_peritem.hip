@@ -485,6 +485,102 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
   }
 }
 
+// One Newton round of the key inversion (polyInv, index.js:499-506) per item in ONE kernel, in its lifted form: v is right modulo
+// 2^kb (kb <= 7 bits, the schedule of ntru_invert_key_batch_dev), f v = 1 + 2^kb e, and v <- v - 2^kb (e v mod 2^(m - kb)) is right
+// modulo 2^m, m <= 2 kb.  Both products run on one int8 digit plane: f (x) v with f's reversed array and v (< 128) as the chunk matrix;
+// then e -- at most kb bits per coefficient -- goes from the accumulator layout STRAIGHT into the chunk matrix as bytes (no
+// natural-order pass: the chunk matrix IS natural order), v's residues modulo 2^(m - kb) become the reversed array in f's place, and
+// the second product's epilogue lifts v on the item's own row.  Against the two kernels it replaces: v and f are fetched once, e never
+// leaves the CU, one launch, one set of per-item waits.
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_newton_round_m(
+    PGeom g, u32 kb, u32 m, const int8_t *__restrict__ f, u16 *v, long B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+  const size_t fa_region = pi_one_bytes(g) - (size_t)16 * g.tpitch;
+  unsigned char *fa0 = lds + (size_t)wave * pi_one_bytes(g), *nat = fa0;
+  u32 *T = (u32 *)(fa0 + fa_region);
+  const int N = g.N, NT = g.NT;
+  const u32 mr = 1u << m, me = 1u << (m - kb);
+  for (size_t i = 16 * lane; i < fa_region; i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
+  const int y0 = 32 * NT - 1 - r + 16 * hh;
+  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
+  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh;
+  u32 mlow[4];
+  diag_low_mask(lane, mlow);
+  const bool stager = 16 * lane < 32 * NT;
+  const int kl = 128 * hh + r;                             // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + kl
+  wave_lds_fence();
+  const long item_step = (long)gridDim.x * PI_WAVES;
+  RawChunks<2> rv;
+  RawChunks<1> rf;
+  auto request = [&](long it) {
+    const long rw = it * N, lf = (B - it) * N;
+    const AlignedSrc sv = aligned_src(v + rw, 2 * lf), sf = aligned_src(f + rw, lf);
+    rv = load_raw<2>(sv, sv.a0 + 32 * lane, 0);
+    rf = load_raw<1>(sf, sf.a0 + 16 * lane, 0);
+  };
+  if ((long)blockIdx.x * PI_WAVES + wave < B) request((long)blockIdx.x * PI_WAVES + wave);
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
+    const long row = item * N;
+    v4i b0;                                                // v modulo 2^(m - kb), centred: the second product's Toeplitz operand
+    int ln = lane;                                         // (opaque per item: the column masks of pi_digits are otherwise hoisted out of the
+    asm volatile("" : "+v"(ln));                           //  item loop -- 24 registers live for ever, spilled at 128 per wave)
+    {
+      v4i va[2], vf[1];
+      shift_raw<2>(rv, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(v + row) & 15)), va);
+      shift_raw<1>(rf, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(f + row) & 15)), vf);
+      u32 xv[8];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { xv[c] = (u32)va[0][c]; xv[4 + c] = (u32)va[1][c]; }
+      {
+        v4i b1;
+        pi_digits(xv, me, 1u, 16 * ln, N, b0, b1);
+      }
+      union { v4i v; signed char c[16]; } u; u.v = vf[0] & col_mask16(16 * ln, N);        // any negative byte is -1 (ValTernary)
+#pragma unroll
+      for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
+      pi_build_array(nat, T, g, lane, u.v);
+      if (stager) {
+        v4i o0, o1;
+        pi_digits(xv, 256u, 1u, 16 * ln, N, o0, o1);     // v < 2^kb <= 128: its own centred representative modulo 256
+        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
+      }
+      wave_lds_fence();
+    }
+    v16i L0, L1, H0, H1;
+    pi_product<false>(pa0, pa0, tb, NT, mlow, L0, L1, H0, H1);           // f v
+    if (item + item_step < B) request(item + item_step);   // the next item's rows (nobody lifts them before this wave does): a product ahead
+    u32 e[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 fv = (u32)(L0[i] + H0[i]) & (mr - 1);
+      e[i] = ((fv - (i == 0 && kl == 0 ? 1u : 0u)) & (mr - 1)) >> kb;   // e = (f v - 1) / 2^kb, below 2^(m - kb) <= 128
+    }
+    {
+      pi_build_array(nat, T, g, lane, b0);                 // (over f's array; it leaves the chunk matrix region zero)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int k = 32 * ((i & 3) + 8 * (i >> 2)) + kl;
+        if (k < N) fa0[32 * PI_PAD + k] = (unsigned char)e[i];
+      }
+      wave_lds_fence();
+    }
+    // v in the accumulator layout, for the lift (the row this item staged a moment ago: an L2 hit), in flight during the second product
+    const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(v + row, 2L * N);
+    u16 vold[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) vold[i] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_v, 2 * kl, 2 * 32 * ((i & 3) + 8 * (i >> 2)), 0);
+    pi_product<false>(pa0, pa0, tb, NT, mlow, L0, L1, H0, H1);           // e v
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int ko = 32 * ((i & 3) + 8 * (i >> 2));
+      const u32 w = (u32)(L0[i] + H0[i]) & (me - 1);
+      __builtin_amdgcn_raw_buffer_store_b16((u16)(((u32)vold[i] - (w << kb)) & (mr - 1)), rs_v, 2 * kl, 2 * ko, 0);
+    }
+    wave_lds_fence();
+  }
+}
+
 // Generic per-item product on the matrix cores: both operands < q <= 8192 (multiplyPolynomials + dividePolynomials by I,
 // index.js:319-401, with q a power of two; the v * v product of polyInv's Newton rounds).  With a = a0 + 128 a1 and
 // b = b0 + 128 b1 the product is a0 b0 + 128 (a0 b1 + a1 b0) + 16384 a1 b1, and 16384 = 0 mod q: three plane products, two
@@ -702,6 +798,19 @@ int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const 
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_verify_keys_m");
   hipLaunchKernelGGL(k_verify_keys_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, d_f, d_g, d_fq, d_fp, d_h, (long)B,
                      d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h, d_flags);
+  HIP_TRY(hipGetLastError());
+  return NTRU_OK;
+}
+
+
+// One Newton round (v from kb to m bits) of the key inversion as ONE kernel: kb <= 7 (v below 128: one digit plane), per-item matrix path.
+int ntru_launch_newton_round_matrix(ntru_engine *eng, int N, int kb, int m, const int8_t *d_f, uint16_t *d_v, long B) {
+  if (kb > 7 || m > 2 * kb || m <= kb || !peritem_applies(eng, N, 1 << m)) return NTRU_NOT_TAKEN;
+  const PGeom pg = make_pgeom(N);
+  const size_t lds = PI_WAVES * pi_one_bytes(pg);
+  dim3 grid;
+  if (int rc = peritem_grid(eng, k_newton_round_m, lds, B, &grid)) return rc;
+  hipLaunchKernelGGL(k_newton_round_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)kb, (u32)m, d_f, d_v, B);
   HIP_TRY(hipGetLastError());
   return NTRU_OK;
 }

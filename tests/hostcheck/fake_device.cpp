@@ -38,6 +38,7 @@ int ntru_launch_decrypt_valu(ntru_engine *, int, int, int, const int8_t *, const
                              uint16_t *, uint8_t *) {
   return ntru_fail(NTRU_ERR_UNSUPPORTED, "fake device: matrix launcher only");
 }
+int ntru_launch_newton_round_matrix(ntru_engine *, int, int, int, const int8_t *, uint16_t *, long) { return NTRU_NOT_TAKEN; }
 int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B, uint16_t *d_quot,
                                uint16_t *d_rem, uint16_t *, int, int) {
   fake_enqueue(eng->stream, [=] { fake_polymul(N, mod, d_a, d_b, B, d_quot, d_rem); });
