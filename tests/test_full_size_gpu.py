@@ -235,3 +235,41 @@ def test_config4_encrypt_2e20(ctx):
     rows = _sample_rows(torch, dev, B)
     e_o, qe_o = orc.encrypt_batch(n, q, h.cpu().numpy().view(np.uint16), _host(r, rows), _host(m1, rows))
     assert np.array_equal(_host(e1, rows), e_o) and np.array_equal(_host(qe1, rows), qe_o)
+
+
+@pytest.mark.parametrize("n,q,logb", [(821, 4096, 20), (701, 8192, 20)])
+def test_fused_pack_kernels_full_batch(ctx, n, q, logb):
+    """encryptBits + packOutput(q - 1, N, e) and decryptBits + packOutput(p - 1, N, value) at BASELINE batch sizes (2^20 per GPU): the
+    fused kernels (k_encrypt_wp, k_decrypt_mp: every workgroup loops over many row blocks, the image is reused) against the two-launch
+    forms on the WHOLE batch, and a strided sample of rows against the CPU oracle."""
+    torch, eng, dev = ctx
+    B = 1 << logb
+    gen = torch.Generator(device=dev); gen.manual_seed(57 + n)
+    d = n // 3
+    r = (_ternary(torch, dev, gen, B, n, d, d).to(torch.int16) % 3).to(torch.uint8)       # d ones, d twos
+    m = torch.randint(0, 2, (B, n), device=dev, generator=gen, dtype=torch.uint8)
+    h = _u16(torch, gen, dev, 1, n, q)[0]
+    f = _ternary(torch, dev, gen, 1, n, d, d - 1)[0]
+    fp = torch.randint(0, 3, (n,), device=dev, generator=gen, dtype=torch.uint8)
+    bits = (q - 1).bit_length()
+    os_e, os_v = max(3, -(-n // (252 // bits))), max(3, -(-n // 126))
+    e = torch.empty((B, n), dtype=torch.int16, device=dev)
+    pe1, pe2 = (torch.empty((B, os_e, 4), dtype=torch.int64, device=dev) for _ in range(2))
+    eng.encrypt_pack_batch_dev(n, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e.data_ptr(), pe1.data_ptr())       # two launches
+    eng.encrypt_pack_batch_dev(n, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, None, pe2.data_ptr())
+    torch.cuda.synchronize()
+    assert eng.last_kernel() == "k_encrypt_wp" and torch.equal(pe1, pe2)
+    v = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    pv1, pv2 = (torch.empty((B, os_v, 4), dtype=torch.int64, device=dev) for _ in range(2))
+    eng.decrypt_batch_dev(n, q, P, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr())
+    eng.pack_bytes_batch_dev(P - 1, n, v.data_ptr(), B, pv1.data_ptr())
+    eng.decrypt_pack_batch_dev(n, q, P, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, None, pv2.data_ptr())
+    torch.cuda.synchronize()
+    assert eng.last_kernel() == "k_decrypt_mp" and torch.equal(pv1, pv2)
+    rows = _sample_rows(torch, dev, B, 1024)
+    e_o = orc.encrypt_batch(n, q, _host(h, slice(None)), _host(r, rows), _host(m, rows), want_quot=False)[0]
+    assert np.array_equal(_host(e, rows), e_o)
+    assert np.array_equal(pe2[rows].cpu().numpy().view(np.uint64), orc.pack_batch(q - 1, n, e_o).view(np.uint64).reshape(len(rows), os_e, 4))
+    v_o = orc.decrypt_batch(n, q, P, f.cpu().numpy(), fp.cpu().numpy(), e_o, want_witness=False)[0]
+    assert np.array_equal(pv2[rows].cpu().numpy().view(np.uint64),
+                          orc.pack_batch(P - 1, n, v_o.astype(np.uint16)).view(np.uint64).reshape(len(rows), os_v, 4))
