@@ -206,7 +206,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample_ternary(int N, int n1, in
 // what 64 keys in lock-step need; the reference's Euclidean algorithm returns the same polynomial because the inverse is
 // unique.  f is not a unit iff the gcd left in `ff` is not a constant: reported in `flags` (the reference's own `&&`
 // checks accept some non-units and return garbage for them: tests/golden/keygen_cases.json).  Polynomials are bit
-// planes in LDS, [array][word][lane]; GF(3) uses two planes per polynomial (plane 0: coefficient == 1, plane 1: == 2).
+// planes in LDS, [array][word][lane]; GF(3) uses two planes per polynomial: plane 0 = coefficient is non-zero, plane 1 = its sign (set: the
+// coefficient is 2 = -1; whatever it holds where plane 0 is clear is never looked at).
 
 // NWC > 0: the planes are NWC words per polynomial held in REGISTERS (every word loop is unrolled, so all indices are
 // compile-time): no LDS traffic and 8 waves per CU instead of 3; NWC = 0: any N, planes in LDS.
@@ -306,9 +307,9 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       if (P == 2) {
         at(AF, 0, w) = (w == 0 ? 1u : 0u) | top; at(AG, 0, w) = g1;
         at(AV, 0, w) = 0; at(AW, 0, w) = w == 0 ? 1u : 0u;
-      } else {
-        at(AF, 0, w) = w == 0 ? 1u : 0u; at(AF, 1, w) = top;
-        at(AG, 0, w) = g1; at(AG, 1, w) = g2;
+      } else {                                            // (non-zero, sign): 1 - x^N = (1, +), (x^N, -); g1 / g2 = residue is 1 / is 2
+        at(AF, 0, w) = (w == 0 ? 1u : 0u) | top; at(AF, 1, w) = top;
+        at(AG, 0, w) = g1 | g2; at(AG, 1, w) = g2;
         at(AV, 0, w) = 0; at(AV, 1, w) = 0; at(AW, 0, w) = w == 0 ? 1u : 0u; at(AW, 1, w) = 0;
       }
     }
@@ -324,17 +325,18 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
     };
     auto word_of = [&](int deg) { const int t = deg >> 5; return t < NW - 1 ? t : NW - 1; };
     int fg_top = NW - 1, vw_top = 0;
-    // GF(3) helpers on (is-one, is-two) plane pairs
-    // GF(3), planes (c == 1, c == 2): r = g + cm f with the per-lane scalar cm given as two lane masks (m2: cm == 2, mnz: cm != 0).
-    // Seven three-input functions (v_bitop3_b32 each): t = cm f as u = (f0 ^ f1) & m2, t0 = (f0 ^ u) & mnz, t1 = (f1 ^ u) & mnz (the scalar
-    // 2 exchanges the planes); then r == 1 iff t == 2 ? g == 2 : (t == 0 ? g == 1 : g == 0), and the mirror image for r == 2.
+    // GF(3) on (non-zero, sign) plane pairs: r = g + cm f with the per-lane scalar cm given as two lane masks (m2: cm == 2, mnz: cm != 0).
+    // Six three-input functions (v_bitop3_b32 / v_bfi_b32 each; eight with planes "is 1" / "is 2"): t = cm f is (f_n & mnz, f_s ^ m2)
+    // -- the scalar 2 flips the sign --; the sum is non-zero iff exactly one term is, or both are and their signs agree (1 + 1 = 2:
+    // then the sign flips); its sign is g's (flipped if t is non-zero too) where g is non-zero, t's otherwise.  Sign bits under a clear
+    // non-zero bit are garbage and never reach a result that is used (tests/test_divstep_bounds_cpu.py checks the formulas exhaustively).
     auto madd3 = [](u32 g0, u32 g1, u32 f0, u32 f1, u32 m2, u32 mnz, u32 &r0, u32 &r1) {
-      const u32 u = (f0 ^ f1) & m2;
-      const u32 t0 = (f0 ^ u) & mnz, t1 = (f1 ^ u) & mnz;
-      const u32 h0 = (g0 & ~t0) | (~(g0 | g1) & t0);
-      const u32 h1 = (g1 & ~t1) | (~(g0 | g1) & t1);
-      r0 = (t1 & g1) | (~t1 & h0);
-      r1 = (t0 & g0) | (~t0 & h1);
+      // (v_bitop3_b32 by hand -- truth table = the expression on a = 0xf0, b = 0xcc, c = 0xaa: left to itself the compiler splits r0 in two)
+      const u32 tn = f0 & mnz, ts = f1 ^ m2;
+      const u32 x = __builtin_amdgcn_bitop3_b32(g1, f1, m2, 0x96);          // g1 ^ ts
+      r0 = __builtin_amdgcn_bitop3_b32(g0, tn, x, 0x7c);                   // (g0 ^ tn) | (g0 & tn & ~x)
+      const u32 p = g1 ^ tn;
+      r1 = __builtin_amdgcn_bitop3_b32(g0, p, ts, 0xca);                   // g0 ? p : ts
     };
     for (int step = 0; step < 2 * N - 1; step++) {
       if ((step & 15) == 0) {                             // (before delta moves on: the bounds are for what this step reads)
@@ -344,7 +346,9 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       }
       const u32 f0w0 = at(AF, 0, 0), g0w0 = at(AG, 0, 0);
       const u32 f0w1 = P == 3 ? at(AF, 1, 0) : 0u, g0w1 = P == 3 ? at(AG, 1, 0) : 0u;
-      const int fc = (int)(f0w0 & 1u) + 2 * (int)(f0w1 & 1u), gc = (int)(g0w0 & 1u) + 2 * (int)(g0w1 & 1u);   // constant terms
+      // constant terms (GF(3): non-zero ? 1 + sign : 0)
+      const int fc = P == 3 ? ((f0w0 & 1u) ? 1 + (int)(f0w1 & 1u) : 0) : (int)(f0w0 & 1u);
+      const int gc = P == 3 ? ((g0w0 & 1u) ? 1 + (int)(g0w1 & 1u) : 0) : (int)(g0w0 & 1u);
       const bool swap = delta > 0 && gc != 0;
       delta = (swap ? -delta : delta) + 1;
       const int c1 = swap ? gc : fc;                      // new f(0): multiplies g and w
@@ -429,14 +433,11 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
     u32 rest = 0;
 #pragma unroll UNR
     for (int w = 0; w < NW; w++)
-      if (w <= fg_top) {
-#pragma unroll
-        for (int pl = 0; pl < PL; pl++) rest |= at(AF, pl, w) & (w == 0 ? ~1u : ~0u);
-      }
-    const int fc = (int)(at(AF, 0, 0) & 1u) + (P == 3 ? 2 * (int)(at(AF, 1, 0) & 1u) : 0);
+      if (w <= fg_top) rest |= at(AF, 0, w) & (w == 0 ? ~1u : ~0u);            // (plane 0 says "non-zero" for both fields)
+    const int fc = (at(AF, 0, 0) & 1u) ? 1 + (P == 3 ? (int)(at(AF, 1, 0) & 1u) : 0) : 0;
     const bool unit = rest == 0 && fc != 0;
     if (have && !unit) flags[key] = (uint8_t)(flags[key] | flag_bit);
-    // inverse[i] = fc^-1 * vv[N-1-i]; in GF(3) fc^-1 = fc (the scalar 2 exchanges the planes); zero for a non-unit
+    // inverse[i] = fc^-1 * vv[N-1-i]; in GF(3) fc^-1 = fc (the scalar 2 flips the signs); zero for a non-unit
     const bool whole = k0 + 64 <= B && N >= 32 && ((((unsigned long long)out16 | (unsigned long long)out8) & 15) == 0);
     if (whole) {
       // The 64 rows of the block are ONE contiguous run of 64 N results that starts on a 64-element boundary.  A store per
@@ -447,8 +448,11 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
       u32 *tr = NWC ? base : base + (size_t)(AV * PL) * NW * 64;
 #pragma unroll UNR
       for (int w = 0; w < NW; w++) {
-        u32 p0 = at(AV, 0, w), p1 = P == 3 ? at(AV, 1, w) : 0u;
-        if (P == 3 && fc == 2) { const u32 t = p0; p0 = p1; p1 = t; }
+        u32 p0 = at(AV, 0, w), p1 = 0;                      // -> planes "is 1" / "is 2" of fc^-1 vv
+        if (P == 3) {
+          const u32 nz = p0, sg = fc == 2 ? ~at(AV, 1, w) : at(AV, 1, w);
+          p0 = nz & ~sg; p1 = nz & sg;
+        }
         p0 = unit ? p0 : 0u; p1 = unit ? p1 : 0u;
         tr[(0 * NW + w) * 64 + lane] = p0;
         if (P == 3) tr[(1 * NW + w) * 64 + lane] = p1;
@@ -503,7 +507,8 @@ __global__ __launch_bounds__(64) void k_invert_key(int N, const int8_t *__restri
         for (int b = 0; b < 32; b++) {
           const int i = N - 1 - (32 * w + b);
           if (i < 0) break;
-          int c = (int)((p0 >> b) & 1u) + 2 * (int)((p1 >> b) & 1u);
+          int c = (int)((p0 >> b) & 1u);
+          if (P == 3) c = c ? 1 + (int)((p1 >> b) & 1u) : 0;
           if (P == 3 && fc == 2) c = (2 * c) % 3;
           c = unit ? c : 0;
           if (out16) out16[key * N + i] = (u16)c;

@@ -79,3 +79,20 @@ def test_degree_bounds_hold_at_every_step_and_the_inverse_comes_out(N, P):
             assert np.array_equal(inv, want), (N, P, fpoly.tolist())
             units += 1
     assert units >= 2
+
+
+def test_gf3_multiply_add_on_nonzero_and_sign_planes():
+    """k_invert_key<3>'s r = g + cm f on (non-zero, sign) bit planes, bit for bit as the kernel computes it (madd3), for every
+    g, f, cm in GF(3) and every value of the sign bits that lie under a clear non-zero bit (garbage by design)."""
+    import itertools
+    for g, f, cm in itertools.product(range(3), repeat=3):
+        for junk_g, junk_f in itertools.product((0, 1), repeat=2):
+            g0, g1 = int(g != 0), (int(g == 2) if g else junk_g)
+            f0, f1 = int(f != 0), (int(f == 2) if f else junk_f)
+            mnz, m2 = int(cm != 0), int(cm == 2)
+            tn, ts = f0 & mnz, f1 ^ m2
+            x = g1 ^ ts
+            r0 = (g0 ^ tn) | (g0 & tn & (1 - x))
+            p = g1 ^ tn
+            r1 = (g0 & p) | ((1 - g0) & ts)
+            assert ((1 + r1) if r0 else 0) == (g + cm * f) % 3, (g, f, cm, junk_g, junk_f)
