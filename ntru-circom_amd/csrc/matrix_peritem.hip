@@ -185,98 +185,206 @@ static __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-#if NTRU_ABLATE & 4                                                       // timing only: operands made up in registers
-#define PI_LOAD(NCH, src, pos) fake_raw<NCH>((int)(pos))
-#else
-#define PI_LOAD(NCH, src, pos) load_raw<NCH>(src, pos, 0)
-#endif
+// ---- chunk rows in REGISTERS (k_verify_keys_m) -----------------------------------------------------------------------------------
+// The A operand of tile distance d is the chunk matrix moved down by d rows: lane (r, hh) holds bytes 16 hh .. 16 hh + 15 of chunk
+// r - d.  Going from d to d + 1 (d >= 0) every lane takes its lower neighbour's 16 bytes and nothing enters at row 0; going from d to
+// d - 1 (d <= 0) every lane takes its upper neighbour's and nothing enters at row 31 (chunks >= NT are zero).  So the low part walks
+// d = 1, 2, ... and the high part d = -1, -2, ..., each from the unshifted rows, with ONE v_and_b32_dpp per dword and step (wave_shr /
+// wave_shl by one lane; the AND cuts the seam between the two half-waves: lane 32 would take lane 31's row, lane 31 lane 32's) and
+// no LDS read for the rows at all.  [Round 3 had tried the shift the other way round -- the high part walking d upwards, a new row
+// entering at lane 0 every step through a small LDS read and v_cndmask_b32_dpp: slower than reading the rows.]  The loops' LDS
+// traffic is the fragment reads alone, shared by every plane that multiplies the same Toeplitz operand: 1 KB per step for the three
+// planes of products 1 and 2 (fq lo / hi and fp against f) where the LDS-row form read 5 KB.  bench_micro/peritem_step.hip is the probe.
+// A fresh copy of a lane-dependent value that the compiler cannot trace back: everything derived from it is computed where it is used,
+// instead of being hoisted out of the item loop (per-lane addresses and masks of every phase: dozens of registers live for ever, i.e.
+// spilled at three waves per SIMD).
+static __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+static __device__ __forceinline__ v4i rows_up(v4i a, int seam) {          // lane l <- lane l - 1 (lane 0 <- 0)
+  v4i o;
+#pragma unroll
+  for (int c = 0; c < 4; c++) o[c] = __builtin_amdgcn_update_dpp(0, a[c], 0x138, 0xf, 0xf, true) & seam;
+  return o;
+}
+static __device__ __forceinline__ v4i rows_down(v4i a, int seam) {        // lane l <- lane l + 1 (lane 63 <- 0)
+  v4i o;
+#pragma unroll
+  for (int c = 0; c < 4; c++) o[c] = __builtin_amdgcn_update_dpp(0, a[c], 0x130, 0xf, 0xf, true) & seam;
+  return o;
+}
+
+// NPL planes F[p] (unshifted chunk rows of this lane, zero at and beyond N) against the Toeplitz fragments of T: L[p] / H[p] = low /
+// high half of plane p's product.  Low and high parts advance together (two independent fragment reads and 2 NPL matrix
+// instructions per trip, fragments requested one trip ahead, unrolled by two so that the two fragment sets rotate without moves).
+template <int NPL>
+static __device__ __forceinline__ void pi_product_reg(const v4i (&F)[NPL], const u32 *T, const PGeom &g, int lane_, v16i (&L)[NPL], v16i (&H)[NPL]) {
+  const int lane = opaque(lane_), NT = g.NT;
+  const int y0 = 32 * NT - 1 - (lane & 31) + 16 * (lane >> 5);
+  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);     // this lane's fragment of distance 0; distance d lies 8 d dwords below
+  int seam_up = lane == 32 ? 0 : -1, seam_dn = lane == 31 ? 0 : -1;
+  asm volatile("" : "+v"(seam_up), "+v"(seam_dn));         // (opaque: as a known 0 / -1 the AND becomes a select that cannot carry the DPP shift)
+  auto frag = [&](int d) {                                 // |d| <= NT - 1; requests past the last step read the last fragment again
+    d = d > NT - 1 ? NT - 1 : (d < 1 - NT ? 1 - NT : d);
+    const u32 *p = tb - 8 * d;
+    return (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+  };
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  v4i AL[NPL], AH[NPL];
+  const v4i w0 = frag(0);
+  v4i wl_a = frag(1), wh_a = frag(-1), wl_b, wh_b;
+  {                                                        // d = 0: split by the diagonal mask; the first term of every accumulator
+    u32 mlow[4];
+    diag_low_mask(lane, mlow);
+    const v4i wl = and4(w0, mlow);
+    const v4i wh = {(int)((u32)w0[0] & ~mlow[0]), (int)((u32)w0[1] & ~mlow[1]), (int)((u32)w0[2] & ~mlow[2]), (int)((u32)w0[3] & ~mlow[3])};
+#pragma unroll
+    for (int p = 0; p < NPL; p++) {
+      L[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[p], wl, zero, 0, 0, 0);
+      H[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[p], wh, zero, 0, 0, 0);
+      AL[p] = F[p]; AH[p] = F[p];
+    }
+  }
+  auto trip = [&](const v4i &wl, const v4i &wh) {
+#pragma unroll
+    for (int p = 0; p < NPL; p++) {
+      AL[p] = rows_up(AL[p], seam_up);
+      L[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AL[p], wl, L[p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                   // the next plane's shifts issue under this matrix instruction
+    }
+#pragma unroll
+    for (int p = 0; p < NPL; p++) {
+      AH[p] = rows_down(AH[p], seam_dn);
+      H[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AH[p], wh, H[p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int j = 1;
+  for (; j + 1 < NT; j += 2) {
+    wl_b = frag(j + 1); wh_b = frag(-(j + 1));
+    trip(wl_a, wh_a);
+    wl_a = frag(j + 2); wh_a = frag(-(j + 2));
+    trip(wl_b, wh_b);
+  }
+  if (j < NT) trip(wl_a, wh_a);
+}
+
+// Per wave: three natural-order periods of the ternary operand (the source of its reversed array; later the remainder of product 3
+// for the comparison with h), then the reversed array.  No chunk matrix: the rows live in registers.
+static __host__ __device__ inline size_t pi_reg_wave_bytes(const PGeom &g) { return pi_nat_bytes(g) + (size_t)16 * g.tpitch; }
+
+// pi_build_array for a lane that holds chunk ch (any assignment of chunks to lanes); sv zero at and beyond N.  The last chunk of a
+// period is stored whole: its zero tail lands on the next period's first bytes, which the NEXT store instruction writes (the LDS
+// executes one wave's instructions in order).  nat is not wiped afterwards.
+static __device__ __forceinline__ void pi_build_array_ch(unsigned char *nat, u32 *T, const PGeom &g, int lane_, int ch, v4i sv) {
+  const int N = g.N, Y0 = 32 * g.NT - 1, lane = opaque(lane_);
+  const bool holds = 16 * ch < N;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    if (holds) *(v4i *)(nat + k * N + 16 * ch) = sv;
+  if (ch < 4) *(v4i *)(nat + 3 * N + 16 * ch) = sv;        // N >= 64
+  wave_lds_fence();
+  const u32 *D = (const u32 *)nat;
+  const int e = __builtin_amdgcn_readfirstlane((Y0 + 2 * N - 3) & 3);
+  u32 sel[4]; int dk[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int al = c <= e ? e - c : e - c + 4;
+    dk[c] = c <= e ? 0 : -1;
+    sel[c] = 0x00010203u + 0x01010101u * (u32)al;
+  }
+  for (int w = lane; w < g.tpitch; w += 64) {
+    int K = (Y0 + 2 * N - 3 - 4 * w) >> 2;
+    K = K < 1 ? 1 : K;
+    const u32 dm = D[K - 1], d0 = D[K], dp = D[K + 1];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      T[c * g.tpitch + w] = dk[c] == 0 ? __builtin_amdgcn_perm(dp, d0, sel[c]) : __builtin_amdgcn_perm(d0, dm, sel[c]);
+  }
+  wave_lds_fence();
+}
+
+// verifyKeysInputs (index.js:141-197) for one key pair per wave.  Lane (r, hh) = 32 hh + r holds chunk ch = 2 r + hh (16 coefficients)
+// of every operand row -- the layout the matrix instruction wants its A operand in -- so the rows go from HBM to the matrix cores
+// through registers only; the LDS holds the reversed array of the ternary operand (f for products 1 and 2, which share every
+// fragment read: three planes, six matrix instructions per trip; then g for product 3).
 __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_verify_keys_m(
     PGeom g, u32 q, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
     const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
     u16 *__restrict__ rem_fq, uint8_t *__restrict__ quot_fp, uint8_t *__restrict__ rem_fp, u16 *__restrict__ quot_h,
     u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  unsigned char *fa0 = lds + (size_t)wave * pi_wave_bytes(g), *fa1 = fa0 + pi_fa_bytes(g), *nat = fa0;
-  u32 *T = (u32 *)(fa1 + pi_fa_bytes(g));
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char *nat = lds + (size_t)wave * pi_reg_wave_bytes(g);
+  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
   const int N = g.N, NT = g.NT;
-  for (size_t i = 16 * lane; i < 2 * pi_fa_bytes(g); i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
-  const int y0 = 32 * NT - 1 - r + 16 * hh;
-  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
-  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
-  u32 mlow[4];
-  diag_low_mask(lane, mlow);
-  const bool stager = 16 * lane < 32 * NT;                                 // lanes that hold a 16-coefficient chunk of a row
-  const v4i cmask = col_mask16(16 * lane, N);                              // bytes of this lane's chunk that are below N
-  const int kl = 128 * hh + r;                                             // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + kl
-  wave_lds_fence();
+  auto chunk_of = [](int ln) { return 2 * (ln & 31) + (ln >> 5); };      // this lane's chunk of every operand row
+  auto index_of = [](int ln) { return 128 * (ln >> 5) + (ln & 31); };    // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + this
   const long item_step = (long)gridDim.x * PI_WAVES;
-  // The first operand rows of an item (fq, f: product 1) are requested at the end of the PREVIOUS item's last epilogue: a timing-only build
-  // with made-up operands was 14 % faster (profiles/r03_ablation_verify_keys.txt), i.e. that much of an item was the wave waiting
-  // for its first round trip to HBM.  They stay in these registers across the loop back-edge.
+  // The first operand rows of an item (fq, f, fp: products 1 and 2) are requested at the end of the PREVIOUS item's last epilogue
+  // (a wave that fetched them where it needs them sat idle for a round trip to HBM per item) and stay in these registers across
+  // the loop back-edge.
   RawChunks<2> r_fq;
-  RawChunks<1> r_f;
-  {
-    const long item0 = (long)blockIdx.x * PI_WAVES + wave;
-    if (item0 < B) {
-      const long row = item0 * N, left = (B - item0) * N;
-      const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left);
-      r_fq = PI_LOAD(2, s_fq, s_fq.a0 + 32 * lane); r_f = PI_LOAD(1, s_f, s_f.a0 + 16 * lane);
-    }
-  }
+  RawChunks<1> r_f, r_fp;
+  auto request_first = [&](long it) {
+    const long row = it * N, left = (B - it) * N;
+    const int ch = chunk_of(opaque(lane));
+    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_fp = aligned_src(fp + row, left);
+    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * ch, 0); r_f = load_raw<1>(s_f, s_f.a0 + 16 * ch, 0); r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * ch, 0);
+  };
+  if ((long)blockIdx.x * PI_WAVES + wave < B) request_first((long)blockIdx.x * PI_WAVES + wave);
   [[maybe_unused]] int stamp_iter = -1;                    // -DNTRU_STAMPS: phase stamps of the first items (tools/phase_stamps_peritem.py)
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
     const long row = item * N, left = (B - item) * N;
     u32 fl = 0;
     stamp_iter++;
     STAMP(0);
-    // Every operand row is requested ahead of its use (rows at any alignment: aligned chunks + a wave-uniform byte shift at
-    // use): fq, f and fp during the previous item, g and fq again (an L2 hit) before product 2, h before product 3.  A fetch
-    // right where each product needs it left the wave idle for a round trip to HBM three times per item.
-    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_g = aligned_src(gg + row, left),
-                     s_fp = aligned_src(fp + row, left);
-    auto bytes_of = [&](const RawChunks<1> &rw, const AlignedSrc &sr) {
+    auto bytes_of = [&](const RawChunks<1> &rw, const void *p) {
       v4i v[1];
-      shift_raw<1>(rw, __builtin_amdgcn_readfirstlane(sr.a0), v);
+      shift_raw<1>(rw, __builtin_amdgcn_readfirstlane((int)((unsigned long long)p & 15)), v);
       return v[0];
     };
-    auto fq_pairs = [&](u32 (&x)[8]) {                                    // 16 coefficients per lane as u16 pairs
+    auto fq_pairs = [&](u32 (&x)[8]) {                     // 16 coefficients per lane as u16 pairs
       v4i v[2];
-      shift_raw<2>(r_fq, __builtin_amdgcn_readfirstlane(s_fq.a0), v);
+      shift_raw<2>(r_fq, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(fq + row) & 15)), v);
 #pragma unroll
       for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
     };
     // ternary operands: any negative byte is -1 (ValTernary), bytes at and beyond N are zero -- four bytes at a time
-    auto ternary = [&](v4i v) {
+    auto ternary = [&](v4i v, const v4i &cmask) {
       v4i o;
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const u32 w = (u32)(v[c] & cmask[c]);
-        u32 neg = (w >> 7) & 0x01010101u;                                  // 1 in every negative byte ...
-        neg |= neg << 1; neg |= neg << 2; neg |= neg << 4;                 // ... spread to 0xFF
+        u32 neg = (w >> 7) & 0x01010101u;                  // 1 in every negative byte ...
+        neg |= neg << 1; neg |= neg << 2; neg |= neg << 4; // ... spread to 0xFF
         o[c] = (int)(w | neg);
       }
       return o;
     };
-    // ---- product 1: fq * f mod q (index.js:158-160)
+    // ---- products 1 and 2: fq * f mod q and fp * f mod p (index.js:158-163): the reversed array of f, planes fq lo / fq hi / fp mod 3
+    v4i F[3];
     {
+      const int ch = chunk_of(opaque(lane));
+      const v4i cmask = col_mask16(16 * ch, N);            // bytes of this lane's chunk that are below N
+      pi_build_array_ch(nat, T, g, lane, ch, ternary(bytes_of(r_f, f + row), cmask));
       u32 xq[8];
       fq_pairs(xq);
-      const v4i tf = ternary(bytes_of(r_f, s_f));
-      pi_build_array(nat, T, g, lane, tf);
-      if (stager) {
-        v4i o0, o1;
-        pi_digits(xq, q, 1u, 16 * lane, N, o0, o1);
-        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
-        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
-      }
-      wave_lds_fence();
+      pi_digits(xq, q, 1u, 16 * ch, N, F[0], F[1]);
+      union { v4i v; unsigned char c[16]; } u; u.v = bytes_of(r_fp, fp + row) & cmask;
+#pragma unroll
+      for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
+      F[2] = u.v;
     }
-    STAMP(1);                                                             // product 1: operands in LDS (array of f, digit planes of fq)
-    v16i L0, L1, H0, H1;
-    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
-    STAMP(2);                                                             // ... its matrix loops
-    const RawChunks<1> r_fp = PI_LOAD(1, s_fp, s_fp.a0 + 16 * lane);     // product 2's operand: it has product 1's epilogue to arrive
+    STAMP(1);                                              // operands of products 1 and 2 in place
+    v16i L[3], H[3];
+    pi_product_reg<3>(F, T, g, lane, L, H);
+    STAMP(2);                                              // ... their matrix loops
+    // product 3's rows (g; fq again: an L2 hit) have the two epilogues to arrive
+    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_g = aligned_src(gg + row, left);
+    const int ch3 = chunk_of(opaque(lane));
+    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * ch3, 0);
+    const RawChunks<1> r_g = load_raw<1>(s_g, s_g.a0 + 16 * ch3, 0);
+    const int kl = index_of(opaque(lane));
     {
       // stores through one-row descriptors: index k = 32 kb + r is a per-lane offset (128 hh + r) plus a compile-time
       // one per register, indices >= N fall outside the descriptor and are dropped -- no address arithmetic per store
@@ -285,33 +393,16 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
-        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        const int lo = L[0][i] + 128 * L[1][i], hi = H[0][i] + 128 * H[1][i];
         const u32 rv = (u32)(lo + hi) & (q - 1);
-        if (1 ABL_STORE(lo)) {
-          __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
-          __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
         nz_hi |= k >= 1 && k < N && rv != 0;
         first_not_one |= k == 0 && rv != 1;
       }
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
     }
-    wave_lds_fence();
-    STAMP(3);                                                             // ... its epilogue
-    // ---- product 2: fp * f mod p (index.js:161-163): the array of f serves again, one plane of fp mod 3
-    {
-      const v4i vfp = bytes_of(r_fp, s_fp);
-      union { v4i v; unsigned char c[16]; } u; u.v = vfp & cmask;
-#pragma unroll
-      for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
-      if (stager) *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = u.v;
-    }
-    wave_lds_fence();
-    r_fq = PI_LOAD(2, s_fq, s_fq.a0 + 32 * lane);                           // for product 3, in flight during product 2
-    const RawChunks<1> r_g = PI_LOAD(1, s_g, s_g.a0 + 16 * lane);
-    STAMP(4);                                                             // product 2: operand in LDS
-    pi_product<false>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
-    STAMP(5);
+    STAMP(3);                                              // product 1's epilogue
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
       bool nz_hi = false, first_not_one = false;
@@ -319,67 +410,55 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
         // |L + H|, |H| <= 127 N (f is an int8, fp < 3): a multiple of 3 above that keeps the dividend non-negative
-        const u32 x = (u32)(L0[i] + H0[i] + 3 * 131072), y = (u32)(3 * 131072 - H0[i]);
+        const u32 x = (u32)(L[2][i] + H[2][i] + 3 * 131072), y = (u32)(3 * 131072 - H[2][i]);
         const u32 rv = x % 3u, qv = y % 3u;
-        if (1 ABL_STORE(L0[i])) {
-          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
-          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
         nz_hi |= k >= 1 && k < N && rv != 0;
         first_not_one |= k == 0 && rv != 1;
       }
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
     }
-    wave_lds_fence();
-    STAMP(6);
+    STAMP(4);                                              // product 2's epilogue
     // ---- product 3: ((p fq) mod q) * g mod q, compared with h below its trimmed length (index.js:155,164-166)
+    v4i G[2];
     {
+      const int ch = chunk_of(opaque(lane));
+      pi_build_array_ch(nat, T, g, lane, ch, ternary(bytes_of(r_g, gg + row), col_mask16(16 * ch, N)));
       u32 xq[8];
       fq_pairs(xq);
-      const v4i tg = ternary(bytes_of(r_g, s_g));
-      pi_build_array(nat, T, g, lane, tg);
-      if (stager) {
-        v4i o0, o1;
-        pi_digits(xq, q, 3u, 16 * lane, N, o0, o1);
-        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
-        *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
-      }
-      wave_lds_fence();
+      pi_digits(xq, q, 3u, 16 * ch, N, G[0], G[1]);
     }
-    // h is requested before the product whose remainder it is compared with, as a row chunk (16 coefficients per lane);
+    // h is requested before the product whose remainder it is compared with, as a natural-order row chunk (16 coefficients per lane);
     // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
     const AlignedSrc s_h = aligned_src(h + row, 2 * left);
-    STAMP(7);                                                             // product 3: operands in LDS (array of g, digit planes of p fq)
-    pi_product<true>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);
-    STAMP(8);
-    const RawChunks<2> r_h = PI_LOAD(2, s_h, s_h.a0 + 32 * lane);          // (after the loop: its 9 registers are the loop's operand sets)
+    const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * opaque(lane), 0);
+    STAMP(5);                                              // product 3: operands in place
+    v16i L3[2], H3[2];
+    pi_product_reg<2>(G, T, g, lane, L3, H3);
+    STAMP(6);
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
       u16 *remx = (u16 *)nat;
+      const int kl = index_of(opaque(lane));
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
-        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
+        const int lo = L3[0][i] + 128 * L3[1][i], hi = H3[0][i] + 128 * H3[1][i];
         const u32 rv = (u32)(lo + hi) & (q - 1);
-        if (1 ABL_STORE(lo)) {
-          __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
-          __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
-        }
-        remx[ko + kl] = (u16)rv;                                          // ko + kl < 32 NT <= (3 N + 64) / 2
+        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        remx[ko + kl] = (u16)rv;                           // ko + kl < 32 NT <= (3 N + 64) / 2
       }
-      if (item + item_step < B) {                         // the next item's first rows (product 1's operands): in flight from here on --
-        const long nrow = (item + item_step) * N, nleft = (B - item - item_step) * N;     // the accumulators are dead, the registers free
-        const AlignedSrc n_fq = aligned_src(fq + nrow, 2 * nleft), n_f = aligned_src(f + nrow, nleft);
-        r_fq = PI_LOAD(2, n_fq, n_fq.a0 + 32 * lane); r_f = PI_LOAD(1, n_f, n_f.a0 + 16 * lane);
-      }
+      if (item + item_step < B) request_first(item + item_step);   // the next item's first rows: in flight from here on (the accumulators are dead)
       wave_lds_fence();
       // index.js:165: h[k] must equal the remainder for every k below h's trimmed length
       v4i hc[2];
       shift_raw<2>(r_h, __builtin_amdgcn_readfirstlane(s_h.a0), hc);
-      const int i0 = 16 * lane;
-      u32 nz = 0, df = 0;                                                 // bit j: h[i0 + j] != 0 / != remainder[i0 + j]
-      if (stager) {
-        const v4i rc0 = *(const v4i *)(nat + 32 * lane), rc1 = *(const v4i *)(nat + 32 * lane + 16);
+      const int i0 = 16 * opaque(lane);
+      u32 nz = 0, df = 0;                                  // bit j: h[i0 + j] != 0 / != remainder[i0 + j]
+      if (i0 < 32 * NT) {
+        const v4i rc0 = *(const v4i *)(nat + 2 * i0), rc1 = *(const v4i *)(nat + 2 * i0 + 16);
 #pragma unroll
         for (int c = 0; c < 8; c++) {
           const int lf = N - (i0 + 2 * c);
@@ -392,13 +471,13 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
       const int top = nz ? i0 + 31 - __builtin_clz(nz) : -1;
       const int wtop = wave_max(top);
-      const int hl = wtop >= 0 ? wtop + 1 : 1;                          // trimmed length of h (1 for the zero polynomial)
+      const int hl = wtop >= 0 ? wtop + 1 : 1;             // trimmed length of h (1 for the zero polynomial)
       const int nv = hl - i0 < 0 ? 0 : (hl - i0 > 16 ? 16 : hl - i0);   // this lane's indices below hl
       if (__ballot((df & ((1u << nv) - 1u)) != 0) != 0) fl |= NTRU_FLAG_INVALID_H;
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
     wave_lds_fence();
-    STAMP(9);                                                             // product 3's epilogue and the comparison with h
+    STAMP(7);                                              // product 3's epilogue and the comparison with h
   }
 }
 
@@ -792,7 +871,7 @@ int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const 
                                    uint8_t *d_quot_fp, uint8_t *d_rem_fp, uint16_t *d_quot_h, uint16_t *d_rem_h, uint8_t *d_flags) {
   if (p != 3 || !peritem_applies(eng, N, q)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
-  const size_t lds = PI_WAVES * pi_wave_bytes(pg);
+  const size_t lds = PI_WAVES * pi_reg_wave_bytes(pg);
   dim3 grid;
   if (int rc = peritem_grid(eng, k_verify_keys_m, lds, (long)B, &grid)) return rc;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_verify_keys_m");
