@@ -144,15 +144,17 @@ NTRU_HIDDEN int ntru_launch_decrypt_valu(ntru_engine *eng, int N, int q, int p, 
                                          const uint16_t *d_e, int64_t B, uint8_t *d_value, uint16_t *d_quot1, uint16_t *d_rem1,
                                          uint8_t *d_quot2);
 // per-item products
+// one Newton round of the key inversion (v from kb to m bits) as one kernel; _applies: kb <= 7, kb < m <= 2 kb, per-item matrix range
+NTRU_HIDDEN bool ntru_newton_round_matrix_applies(const ntru_engine *eng, int N, int kb, int m);
 NTRU_HIDDEN int ntru_launch_newton_round_matrix(ntru_engine *eng, int N, int kb, int m, const int8_t *d_f, uint16_t *d_v, long B);
 NTRU_HIDDEN int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B,
-                                           uint16_t *d_quot, uint16_t *d_rem, uint16_t *d_lift_v = nullptr, int lift_k = 0, int lift_q = 0);
+                                           uint16_t *d_quot, uint16_t *d_rem);
 NTRU_HIDDEN int ntru_launch_polymul_valu(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B,
                                          uint16_t *d_quot, uint16_t *d_rem);
 NTRU_HIDDEN bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q);
 // ((mul * a) mod q) * s with s ternary per item; d_quot may be NULL
 NTRU_HIDDEN int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s,
-                                                long B, uint16_t *d_quot, uint16_t *d_rem, uint32_t nshift = 0, int abits = 16);
+                                                long B, uint16_t *d_quot, uint16_t *d_rem);
 NTRU_HIDDEN int ntru_launch_public_key_valu(ntru_engine *eng, int N, int q, int p, const uint16_t *d_fq, const int8_t *d_g, int64_t B,
                                             uint16_t *d_h);
 NTRU_HIDDEN int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const int8_t *d_g,

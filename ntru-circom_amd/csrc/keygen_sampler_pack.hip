@@ -754,7 +754,7 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   if (rounds > 0) {
     struct { void *p; } f16{sc}, t{sc + part}, u{sc + 2 * part}, qs{sc + 3 * part};
     bool need_f16 = false;                                 // f as u16 residues: only the vector-ALU form of a round reads it
-    for (int r = 0; r < rounds; r++) need_f16 |= !ntru_product_tern_matrix_applies(eng, N, 1 << bits_of[r + 1]);
+    for (int r = 0; r < rounds; r++) need_f16 |= !ntru_newton_round_matrix_applies(eng, N, bits_of[r], bits_of[r + 1]);
     for (int64_t o = 0; o < B; o += C) {
       const int64_t n = B - o < C ? B - o : C;
       uint16_t *v = d_fq + o * N;
@@ -766,20 +766,12 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
         const int kb = bits_of[r], m = bits_of[r + 1], mr = 1 << m;
         const long tot = (long)(n * N);
         const long nvec = ((((unsigned long long)v | (unsigned long long)u.p) & 15) == 0) ? tot / 8 : 0;
-        if (ntru_product_tern_matrix_applies(eng, N, mr)) {
-          // Per-item products on the matrix cores, the round in its LIFTED form.  v is right modulo 2^kb, so
+        if (ntru_newton_round_matrix_applies(eng, N, kb, m)) {
+          // Per-item products on the matrix cores, the round in its LIFTED form, ONE kernel.  v is right modulo 2^kb, so
           // f v = 1 + 2^kb e and v (2 - f v) = v - 2^kb (e v) modulo mr = 2^m, m <= 2 kb: only e v modulo 2^(m - kb) is needed, a
-          // product of operands of at most kb bits (ONE int8 digit plane each, also in the last round, whose v * v form takes
-          // two planes and three matrix instructions per step).  The ternary product stores e directly (nshift).
-          {                                                   // ... as ONE kernel while v has at most 7 bits (log2 q <= 14)
-            const int rc = ntru_launch_newton_round_matrix(eng, N, kb, m, d_f + o * N, v, (long)n);
-            if (rc == NTRU_OK) continue;
-            if (rc != NTRU_NOT_TAKEN) return rc;
-          }
-          const int me = 1 << (m - kb);
-          if (int rc = ntru_launch_product_tern_matrix(eng, N, mr, 1u, v, d_f + o * N, (long)n, nullptr, (uint16_t *)t.p, (uint32_t)kb, kb)) return rc;
-          // ... and the generic product lifts v in place: v <- (v - 2^kb w) mod mr comes out of its epilogue
-          if (int rc = ntru_launch_polymul_matrix(eng, N, me, (const uint16_t *)t.p, v, n, nullptr, nullptr, v, kb, mr)) return rc;
+          // product of operands of at most kb <= 7 bits (ONE int8 digit plane each: the schedule above guarantees it for log2 q <= 14).
+          if (int rc = ntru_launch_newton_round_matrix(eng, N, kb, m, d_f + o * N, v, (long)n))
+            return rc == NTRU_NOT_TAKEN ? fail(NTRU_ERR_UNSUPPORTED, "ntru_invert_key_batch: Newton round outside the matrix kernel's range") : rc;
           continue;
         }
         // vector-ALU families: v <- 2 v - f v^2

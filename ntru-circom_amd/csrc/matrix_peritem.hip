@@ -6,62 +6,19 @@
 // ---- family 4 for PER-ITEM operands: verifyKeysInputs (index.js:141-197) on the matrix cores ---------------------
 // No matrix is shared by the batch, but one product c = a * s is itself a 32-row matrix product per tile distance
 // d = kb - ib (tools/peritem_mfma_model.py): C[kb][k'] += sum_i' F[kb - d][i'] G_d[i'][k'] with F the 32-coefficient chunks
-// of a (rows = output tiles, read as aligned 16-byte pieces of a zero-padded natural-order byte array) and G_d the
-// Toeplitz tile of s (fragments of the reversed cyclic array, as above).  One accumulator pair (low / high) holds the whole
-// product of an item; a 13-bit operand contributes two digit planes with SEPARATE accumulators (value = acc0 + 128 acc1),
-// so nothing is scaled.  2 NT - 1 (+1 for the split diagonal) matrix instructions per plane.  One item per wave, all LDS
-// regions private to the wave, no workgroup barrier.
-constexpr int PI_PAD = 32;          // zero chunks on either side of the chunk matrix: rows 0..31, distances +-(NT-1)
-constexpr int PI_WAVES = 2;         // waves per workgroup (LDS, not registers, bounds the residency: ~15 KB per wave); 4 measured the same
+// of a (rows = output tiles) and G_d the Toeplitz tile of s (fragments of the reversed cyclic array the wave builds per item in
+// its own LDS, as in the shared-key kernels).  One accumulator pair (low / high) holds the whole product of an item; a 13-bit
+// operand contributes two digit planes with SEPARATE accumulators (value = acc0 + 128 acc1), so nothing is scaled.
+// 2 NT - 1 (+1 for the split diagonal) matrix instructions per plane.  One item per wave, all LDS regions private to the wave,
+// no workgroup barrier.  The chunk rows never touch the LDS: see "chunk rows in REGISTERS" below.
+constexpr int PI_WAVES = 2;         // waves per workgroup (registers bound the residency); 4 measured the same
 struct PGeom { int N, NT, tpitch; };
-static __host__ __device__ inline size_t pi_fa_bytes(const PGeom &g) { return (size_t)32 * (g.NT + 2 * PI_PAD); }
-static __host__ __device__ inline size_t pi_nat_bytes(const PGeom &g) { return ((size_t)3 * g.N + 64 + 15) & ~(size_t)15; }
-// per wave: the two chunk matrices, then the reversed array.  The three natural-order periods the array is built from
-// are staged OVER the chunk matrices (2 fa >= nat for every N <= 1024) and wiped again before the digits go in.
-static __host__ __device__ inline size_t pi_wave_bytes(const PGeom &g) { return 2 * pi_fa_bytes(g) + (size_t)16 * g.tpitch; }
-// single digit plane (q <= 256): ONE chunk matrix (with room for the natural-order staging that lies over it) and the reversed array
-static __host__ __device__ inline size_t pi_one_bytes(const PGeom &g) {
-  return (pi_fa_bytes(g) > pi_nat_bytes(g) ? pi_fa_bytes(g) : pi_nat_bytes(g)) + (size_t)16 * g.tpitch;
-}
-
-// Reversed cyclic array (4 byte-shifted copies) of the 16 bytes per lane in sv (coefficients 16 lane .. 16 lane + 15 of a
-// ternary operand, zero at and beyond N): three periods in natural order (period k starts at byte k N, any alignment:
-// unaligned LDS stores), then T[c][w] = bytes rev[4w + c + j], rev[y] = s[(Y0 - y) mod N], as byte-swapped unaligned reads.
-static __device__ __forceinline__ void pi_build_array(unsigned char *nat, u32 *T, const PGeom &g, int lane, v4i sv) {
-  const int N = g.N, Y0 = 32 * g.NT - 1;
-  if (16 * lane < N) {
-    union { v4i v; unsigned char c[16]; } u; u.v = sv;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      if (16 * lane + 16 <= N) *(v4i *)(nat + k * N + 16 * lane) = sv;
-      else for (int j = 0; j < 16; j++) if (16 * lane + j < N) nat[k * N + 16 * lane + j] = u.c[j];
-    }
-    if (lane < 4) *(v4i *)(nat + 3 * N + 16 * lane) = sv;                 // N >= 64
-  }
-  wave_lds_fence();
-  // Word w of copy c holds bytes nat[A .. A+3] reversed, A = E - c, E = Y0 + 2N - 3 - 4w.  E & 3 is the same for every
-  // lane, so the four copies of a word come from three ALIGNED dwords around E >> 2 with one byte permute each
-  // (an unaligned LDS dword read costs several aligned ones: the build was 28 % of a product in the probe).
-  const u32 *D = (const u32 *)nat;
-  const int e = __builtin_amdgcn_readfirstlane((Y0 + 2 * N - 3) & 3);
-  u32 sel[4]; int dk[4];
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const int al = c <= e ? e - c : e - c + 4;                            // byte offset of A inside its dword
-    dk[c] = c <= e ? 0 : -1;                                              // ... which is dword K or K - 1
-    sel[c] = 0x00010203u + 0x01010101u * (u32)al;                         // bytes al+3, al+2, al+1, al of the pair (reversed)
-  }
-  for (int w = lane; w < g.tpitch; w += 64) {
-    int K = (Y0 + 2 * N - 3 - 4 * w) >> 2;
-    K = K < 1 ? 1 : K;                                                    // pad words of a copy are never read
-    const u32 dm = D[K - 1], d0 = D[K], dp = D[K + 1];
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-      T[c * g.tpitch + w] = dk[c] == 0 ? __builtin_amdgcn_perm(dp, d0, sel[c]) : __builtin_amdgcn_perm(d0, dm, sel[c]);
-  }
-  wave_lds_fence();
-  for (int i = 16 * lane; i < (int)pi_nat_bytes(g); i += 16 * 64) *(v4i *)(nat + i) = (v4i){0, 0, 0, 0};   // nat lies over the
-  wave_lds_fence();                                                       // chunk matrices: their pads are zero again
+// Natural-order area of a wave: three periods + 64 bytes of the ternary / Toeplitz operand while its reversed array is built; later a
+// product's results as a natural-order image written from the accumulator layout, where register i of lane (r, hh) holds index
+// 32 ((i&3) + 8 (i>>2)) + 128 hh + r <= 1151 WHATEVER N is (tiles at and beyond NT hold junk that nobody reads): 2304 bytes of u16.
+static __host__ __device__ inline size_t pi_nat_bytes(const PGeom &g) {
+  const size_t periods = ((size_t)3 * g.N + 64 + 15) & ~(size_t)15;
+  return periods > 2304 ? periods : 2304;
 }
 
 // Digit planes of 16 values (u16 pairs in x[8], element i0 + j; zero at and beyond N) -> natural-order int8 bytes, on
@@ -94,81 +51,6 @@ static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 m
       o0[c] = (int)__builtin_amdgcn_perm(b & 0x007F007Fu, a & 0x007F007Fu, 0x06040200u);
       o1[c] = (int)__builtin_amdgcn_perm((b >> 7) & 0x007F007Fu, (a >> 7) & 0x007F007Fu, 0x06040200u);
     }
-  }
-}
-
-// One plane-pair product: acc{L,H}{0,1} += chunk matrices fa0 / fa1 (x) Toeplitz fragments of T.  TWO = false: one plane.
-// A step (tile distance d) is one or two matrix instructions on operands that are used once, so the loop lives on its
-// LDS reads: they are requested TWO steps ahead into three rotating register sets (unrolled by three, no register moves;
-// one step ahead left the wave waiting on LDS latency at the top of every iteration: 64 matrix clocks per step against
-// ~130 of latency).  The first instruction of every accumulator takes C = 0.
-template <bool TWO>
-static __device__ __forceinline__ void pi_product(const unsigned char *pa0, const unsigned char *pa1, const u32 *tb, int NT,
-                                                  const u32 (&mlow)[4], v16i &L0, v16i &L1, v16i &H0, v16i &H1) {
-  struct Ops { v4i a0, a1, w; };
-  auto ld = [&](int d, Ops &o) {                          // distance d: fragment 8 d dwords below the lane's base, rows shifted by d
-    d = d < NT ? d : NT;                                  // requests past the last step read pad bytes (never used)
-    const u32 *p = tb - 8 * d;
-    o.w = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
-    o.a0 = *(const v4i *)(pa0 - 32 * d);
-    if (TWO) o.a1 = *(const v4i *)(pa1 - 32 * d);
-  };
-  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  auto step = [&](int d, const Ops &o) {                  // d < 0: high, d > 0: low, d == 0: split by the diagonal mask
-    if (d < 0) {
-      H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, o.w, H0, 0, 0, 0);
-      if (TWO) H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, o.w, H1, 0, 0, 0);
-    } else if (d > 0) {
-      L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, o.w, L0, 0, 0, 0);
-      if (TWO) L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, o.w, L1, 0, 0, 0);
-    } else {
-      const v4i wl = and4(o.w, mlow);
-      const v4i wh = {(int)((u32)o.w[0] & ~mlow[0]), (int)((u32)o.w[1] & ~mlow[1]), (int)((u32)o.w[2] & ~mlow[2]), (int)((u32)o.w[3] & ~mlow[3])};
-      L0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, wl, zero, 0, 0, 0);          // the first term of `low`
-      H0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a0, wh, H0, 0, 0, 0);
-      if (TWO) {
-        L1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, wl, zero, 0, 0, 0);
-        H1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.a1, wh, H1, 0, 0, 0);
-      }
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < 16; i++) { H0[i] = 0; H1[i] = 0; }   // NT = 1 has no d < 0 step; otherwise folded into the first step below
-#if NTRU_ABLATE & 2                                                       // timing only: no matrix loops
-  NT = 1;
-#pragma unroll
-  for (int i = 0; i < 16; i++) { L1[i] = 0; }
-#endif
-  Ops A, Bq, C;
-  int d = -(NT - 1);
-  ld(d, A); ld(d + 1, Bq);
-  // high part: steps d = -(NT-1) .. -1, three per trip
-  for (; d + 2 < 0; d += 3) {
-    ld(d + 2, C); step(-1, A);
-    ld(d + 3, A); step(-1, Bq);
-    ld(d + 4, Bq); step(-1, C);
-  }
-  // 0, 1 or 2 steps of the high part are left; then the diagonal; then the low part.  The rotation continues with moves
-  // for these few steps (at most two high steps + the diagonal), after which the low part runs three per trip again.
-  for (; d < 0; d++) {
-    ld(d + 2, C); step(-1, A);
-    A = Bq; Bq = C;
-  }
-  ld(2, C); step(0, A);                                   // d == 0
-  A = Bq; Bq = C;
-  d = 1;
-  for (; d + 2 < NT; d += 3) {
-    ld(d + 2, C); step(1, A);
-    ld(d + 3, A); step(1, Bq);
-    ld(d + 4, Bq); step(1, C);
-  }
-  for (; d < NT; d++) {
-    ld(d + 2, C); step(1, A);
-    A = Bq; Bq = C;
-  }
-  if (!TWO) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) { L1[i] = 0; H1[i] = 0; }
   }
 }
 
@@ -272,9 +154,11 @@ static __device__ __forceinline__ void pi_product_reg(const v4i (&F)[NPL], const
 // for the comparison with h), then the reversed array.  No chunk matrix: the rows live in registers.
 static __host__ __device__ inline size_t pi_reg_wave_bytes(const PGeom &g) { return pi_nat_bytes(g) + (size_t)16 * g.tpitch; }
 
-// pi_build_array for a lane that holds chunk ch (any assignment of chunks to lanes); sv zero at and beyond N.  The last chunk of a
-// period is stored whole: its zero tail lands on the next period's first bytes, which the NEXT store instruction writes (the LDS
-// executes one wave's instructions in order).  nat is not wiped afterwards.
+// Reversed cyclic array (4 byte-shifted copies) of a ternary / int8 operand of which this lane holds chunk ch (the 16 bytes sv:
+// coefficients 16 ch .. 16 ch + 15, zero at and beyond N; any assignment of chunks to lanes): three periods in natural order (period
+// k starts at byte k N, any alignment: unaligned LDS stores), then T[c][w] = bytes rev[4w + c + j], rev[y] = s[(Y0 - y) mod N], as
+// byte-swapped reads.  The last chunk of a period is stored whole: its zero tail lands on the next period's first bytes, which the
+// NEXT store instruction writes (the LDS executes one wave's instructions in order).
 static __device__ __forceinline__ void pi_build_array_ch(unsigned char *nat, u32 *T, const PGeom &g, int lane_, int ch, v4i sv) {
   const int N = g.N, Y0 = 32 * g.NT - 1, lane = opaque(lane_);
   const bool holds = 16 * ch < N;
@@ -283,18 +167,21 @@ static __device__ __forceinline__ void pi_build_array_ch(unsigned char *nat, u32
     if (holds) *(v4i *)(nat + k * N + 16 * ch) = sv;
   if (ch < 4) *(v4i *)(nat + 3 * N + 16 * ch) = sv;        // N >= 64
   wave_lds_fence();
+  // Word w of copy c holds bytes nat[A .. A+3] reversed, A = E - c, E = Y0 + 2N - 3 - 4w.  E & 3 is the same for every
+  // lane, so the four copies of a word come from three ALIGNED dwords around E >> 2 with one byte permute each
+  // (an unaligned LDS dword read costs several aligned ones).
   const u32 *D = (const u32 *)nat;
   const int e = __builtin_amdgcn_readfirstlane((Y0 + 2 * N - 3) & 3);
   u32 sel[4]; int dk[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    const int al = c <= e ? e - c : e - c + 4;
-    dk[c] = c <= e ? 0 : -1;
-    sel[c] = 0x00010203u + 0x01010101u * (u32)al;
+    const int al = c <= e ? e - c : e - c + 4;                            // byte offset of A inside its dword
+    dk[c] = c <= e ? 0 : -1;                                              // ... which is dword K or K - 1
+    sel[c] = 0x00010203u + 0x01010101u * (u32)al;                         // bytes al+3, al+2, al+1, al of the pair (reversed)
   }
   for (int w = lane; w < g.tpitch; w += 64) {
     int K = (Y0 + 2 * N - 3 - 4 * w) >> 2;
-    K = K < 1 ? 1 : K;
+    K = K < 1 ? 1 : K;                                                    // pad words of a copy are never read
     const u32 dm = D[K - 1], d0 = D[K], dp = D[K + 1];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -367,6 +254,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       const int ch = chunk_of(opaque(lane));
       const v4i cmask = col_mask16(16 * ch, N);            // bytes of this lane's chunk that are below N
       pi_build_array_ch(nat, T, g, lane, ch, ternary(bytes_of(r_f, f + row), cmask));
+      STAMP(1);                                            // the reversed array of f
       u32 xq[8];
       fq_pairs(xq);
       pi_digits(xq, q, 1u, 16 * ch, N, F[0], F[1]);
@@ -375,10 +263,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
       F[2] = u.v;
     }
-    STAMP(1);                                              // operands of products 1 and 2 in place
+    STAMP(2);                                              // the three planes in registers
     v16i L[3], H[3];
     pi_product_reg<3>(F, T, g, lane, L, H);
-    STAMP(2);                                              // ... their matrix loops
+    STAMP(3);                                              // the matrix loops of products 1 and 2
     // product 3's rows (g; fq again: an L2 hit) have the two epilogues to arrive
     const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_g = aligned_src(gg + row, left);
     const int ch3 = chunk_of(opaque(lane));
@@ -402,7 +290,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
     }
-    STAMP(3);                                              // product 1's epilogue
+    STAMP(4);                                              // product 1's epilogue
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
       bool nz_hi = false, first_not_one = false;
@@ -419,12 +307,13 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
     }
-    STAMP(4);                                              // product 2's epilogue
+    STAMP(5);                                              // product 2's epilogue
     // ---- product 3: ((p fq) mod q) * g mod q, compared with h below its trimmed length (index.js:155,164-166)
     v4i G[2];
     {
       const int ch = chunk_of(opaque(lane));
       pi_build_array_ch(nat, T, g, lane, ch, ternary(bytes_of(r_g, gg + row), col_mask16(16 * ch, N)));
+      STAMP(6);                                            // the reversed array of g
       u32 xq[8];
       fq_pairs(xq);
       pi_digits(xq, q, 3u, 16 * ch, N, G[0], G[1]);
@@ -433,10 +322,10 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
     const AlignedSrc s_h = aligned_src(h + row, 2 * left);
     const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * opaque(lane), 0);
-    STAMP(5);                                              // product 3: operands in place
+    STAMP(7);                                              // product 3: planes in registers
     v16i L3[2], H3[2];
     pi_product_reg<2>(G, T, g, lane, L3, H3);
-    STAMP(6);
+    STAMP(8);
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
       u16 *remx = (u16 *)nat;
@@ -448,10 +337,11 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
         const u32 rv = (u32)(lo + hi) & (q - 1);
         __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
         __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
-        remx[ko + kl] = (u16)rv;                           // ko + kl < 32 NT <= (3 N + 64) / 2
+        remx[ko + kl] = (u16)rv;                           // ko + kl <= 1151: inside the area for every N (pi_nat_bytes)
       }
       if (item + item_step < B) request_first(item + item_step);   // the next item's first rows: in flight from here on (the accumulators are dead)
       wave_lds_fence();
+      STAMP(9);                                            // product 3's result stores issued
       // index.js:165: h[k] must equal the remainder for every k below h's trimmed length
       v4i hc[2];
       shift_raw<2>(r_h, __builtin_amdgcn_readfirstlane(s_h.a0), hc);
@@ -477,51 +367,43 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
     wave_lds_fence();
-    STAMP(7);                                              // product 3's epilogue and the comparison with h
+    STAMP(10);                                             // the comparison with h
   }
 }
 
 // One per-item product on the matrix cores: rem (and quot) of ((mul a) mod q) * s split by 1 - x^N, a < 2^16 per item,
-// s ternary per item: generatePublicKeyH (index.js:72-79, mul = p) and the f * t product of polyInv's Newton rounds
-// (index.js:499-506, mul = 1; there the remainder leaves as (f v - 1) / 2^nshift, see ntru_invert_key_batch_dev).  Same machinery
-// as k_verify_keys_m.
-// ONE: a single int8 digit plane (q <= 256: the early Newton rounds): half the accumulators, no second chunk matrix -- 128 registers and
-// 9.7 KB of LDS per wave, i.e. FOUR waves per SIMD instead of three.
+// s ternary per item: generatePublicKeyH (index.js:72-79, mul = p).  Same machinery as product 3 of k_verify_keys_m.
+// ONE: a single int8 digit plane (q <= 256): half the accumulators.
 template <bool ONE>
 __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(ONE ? 4 : 3, 4))) void k_product_tern_m(
-    PGeom g, u32 q, u32 mul, u32 nshift, const u16 *__restrict__ a, const int8_t *__restrict__ s, long B, u16 *__restrict__ quot,
+    PGeom g, u32 q, u32 mul, const u16 *__restrict__ a, const int8_t *__restrict__ s, long B, u16 *__restrict__ quot,
     u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  const size_t fa_region = ONE ? pi_one_bytes(g) - (size_t)16 * g.tpitch : 2 * pi_fa_bytes(g);
-  unsigned char *fa0 = lds + (size_t)wave * (ONE ? pi_one_bytes(g) : pi_wave_bytes(g)), *fa1 = ONE ? fa0 : fa0 + pi_fa_bytes(g), *nat = fa0;
-  u32 *T = (u32 *)(fa0 + fa_region);
-  const int N = g.N, NT = g.NT;
-  for (size_t i = 16 * lane; i < fa_region; i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
-  const int y0 = 32 * NT - 1 - r + 16 * hh;
-  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
-  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
-  u32 mlow[4];
-  diag_low_mask(lane, mlow);
-  const bool stager = 16 * lane < 32 * NT;
-  const v4i cmask = col_mask16(16 * lane, N);
+  constexpr int NPL = ONE ? 1 : 2;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char *nat = lds + (size_t)wave * pi_reg_wave_bytes(g);
+  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
+  const int N = g.N;
   const bool want_q = quot != nullptr;
-  wave_lds_fence();
-  // The operands of the NEXT item are requested as soon as this item's are in LDS (the round trip to HBM runs under the matrix
+  auto chunk_of = [](int ln) { return 2 * (ln & 31) + (ln >> 5); };
+  // The operands of the NEXT item are requested as soon as this item's are in registers (the round trip to HBM runs under the matrix
   // loops and the result stores instead of in front of every item).
   const long item_step = (long)gridDim.x * PI_WAVES;
   RawChunks<2> ra;
   RawChunks<1> rs;
   auto request = [&](long it) {
     const long rw = it * N, lf = (B - it) * N;
+    const int ch = chunk_of(opaque(lane));
     const AlignedSrc sa = aligned_src(a + rw, 2 * lf), ss = aligned_src(s + rw, lf);
-    ra = load_raw<2>(sa, sa.a0 + 32 * lane, 0);
-    rs = load_raw<1>(ss, ss.a0 + 16 * lane, 0);
+    ra = load_raw<2>(sa, sa.a0 + 32 * ch, 0);
+    rs = load_raw<1>(ss, ss.a0 + 16 * ch, 0);
   };
   if ((long)blockIdx.x * PI_WAVES + wave < B) request((long)blockIdx.x * PI_WAVES + wave);
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
     const long row = item * N;
+    v4i F[NPL];
     {
+      const int ch = chunk_of(opaque(lane));
       v4i va[2], vs[1];
       shift_raw<2>(ra, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(a + row) & 15)), va);
       shift_raw<1>(rs, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(s + row) & 15)), vs);
@@ -529,35 +411,27 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
       u32 xa[8];
 #pragma unroll
       for (int c = 0; c < 4; c++) { xa[c] = (u32)va[0][c]; xa[4 + c] = (u32)va[1][c]; }
-      union { v4i v; signed char c[16]; } u; u.v = vs[0] & cmask;        // any negative byte is -1 (ValTernary)
+      union { v4i v; signed char c[16]; } u; u.v = vs[0] & col_mask16(16 * ch, N);      // any negative byte is -1 (ValTernary)
 #pragma unroll
       for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
-      pi_build_array(nat, T, g, lane, u.v);
-      if (stager) {
-        v4i o0, o1;
-        // (ONE with q > 256: the caller vouches for a < 128 -- a Newton round whose v has at most 7 bits -- and such an a is its own
-        // centred representative modulo 256; the result is still reduced modulo q)
-        pi_digits(xa, ONE && q > 256 ? 256u : q, mul, 16 * lane, N, o0, o1);
-        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
-        if (!ONE) *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = o1;
-      }
-      wave_lds_fence();
+      pi_build_array_ch(nat, T, g, lane, ch, u.v);
+      v4i o0, o1;
+      pi_digits(xa, q, mul, 16 * ch, N, o0, o1);
+      F[0] = o0;
+      if (!ONE) F[NPL - 1] = o1;
     }
-    v16i L0, L1, H0, H1;
-    pi_product<!ONE>(pa0, pa1, tb, NT, mlow, L0, L1, H0, H1);       // ONE: one digit plane (early Newton rounds, small q)
+    v16i L[NPL], H[NPL];
+    pi_product_reg<NPL>(F, T, g, lane, L, H);
     {
-      const int kl = 128 * hh + r;                                       // see k_verify_keys_m: indices >= N are dropped
+      const int ln = opaque(lane), kl = 128 * (ln >> 5) + (ln & 31);     // see k_verify_keys_m: indices >= N are dropped
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
       const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quot + row : nullptr, want_q ? 2L * N : 0L);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
-        const int lo = L0[i] + 128 * L1[i], hi = H0[i] + 128 * H1[i];
-        u32 rv = (u32)(lo + hi) & (q - 1);
-        // nshift = k > 0 (a Newton round of the key inversion, a = v with f v = 1 mod 2^k): what is stored is e = (f v - 1) / 2^k
-        if (nshift) rv = ((rv - (i == 0 && kl == 0 ? 1u : 0u)) & (q - 1)) >> nshift;
-        __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
-        if (want_q) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);   // (a store through an empty descriptor is dropped, but issued)
+        const int lo = L[0][i] + (ONE ? 0 : 128 * L[NPL - 1][i]), hi = H[0][i] + (ONE ? 0 : 128 * H[NPL - 1][i]);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
+        if (want_q) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
       }
     }
     wave_lds_fence();
@@ -566,136 +440,109 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
 
 // One Newton round of the key inversion (polyInv, index.js:499-506) per item in ONE kernel, in its lifted form: v is right modulo
 // 2^kb (kb <= 7 bits, the schedule of ntru_invert_key_batch_dev), f v = 1 + 2^kb e, and v <- v - 2^kb (e v mod 2^(m - kb)) is right
-// modulo 2^m, m <= 2 kb.  Both products run on one int8 digit plane: f (x) v with f's reversed array and v (< 128) as the chunk matrix;
-// then e -- at most kb bits per coefficient -- goes from the accumulator layout STRAIGHT into the chunk matrix as bytes (no
-// natural-order pass: the chunk matrix IS natural order), v's residues modulo 2^(m - kb) become the reversed array in f's place, and
-// the second product's epilogue lifts v on the item's own row.  Against the two kernels it replaces: v and f are fetched once, e never
-// leaves the CU, one launch, one set of per-item waits.
+// modulo 2^m, m <= 2 kb.  Both products run on one int8 digit plane with the chunk rows in registers: f (x) v with f's reversed
+// array and v (< 128) as the rows; then e -- at most kb bits per coefficient -- goes from the accumulator layout through a
+// natural-order byte image in the LDS into the row layout (ONE read per lane), v's residues modulo 2^(m - kb) become the reversed
+// array in f's place, and the second product's epilogue lifts v on the item's own row.
 __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_newton_round_m(
     PGeom g, u32 kb, u32 m, const int8_t *__restrict__ f, u16 *v, long B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  const size_t fa_region = pi_one_bytes(g) - (size_t)16 * g.tpitch;
-  unsigned char *fa0 = lds + (size_t)wave * pi_one_bytes(g), *nat = fa0;
-  u32 *T = (u32 *)(fa0 + fa_region);
-  const int N = g.N, NT = g.NT;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char *nat = lds + (size_t)wave * pi_reg_wave_bytes(g);
+  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
+  const int N = g.N;
   const u32 mr = 1u << m, me = 1u << (m - kb);
-  for (size_t i = 16 * lane; i < fa_region; i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
-  const int y0 = 32 * NT - 1 - r + 16 * hh;
-  const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);
-  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh;
-  u32 mlow[4];
-  diag_low_mask(lane, mlow);
-  const bool stager = 16 * lane < 32 * NT;
-  const int kl = 128 * hh + r;                             // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + kl
-  wave_lds_fence();
+  auto chunk_of = [](int ln) { return 2 * (ln & 31) + (ln >> 5); };
   const long item_step = (long)gridDim.x * PI_WAVES;
   RawChunks<2> rv;
   RawChunks<1> rf;
   auto request = [&](long it) {
     const long rw = it * N, lf = (B - it) * N;
+    const int ch = chunk_of(opaque(lane));
     const AlignedSrc sv = aligned_src(v + rw, 2 * lf), sf = aligned_src(f + rw, lf);
-    rv = load_raw<2>(sv, sv.a0 + 32 * lane, 0);
-    rf = load_raw<1>(sf, sf.a0 + 16 * lane, 0);
+    rv = load_raw<2>(sv, sv.a0 + 32 * ch, 0);
+    rf = load_raw<1>(sf, sf.a0 + 16 * ch, 0);
   };
   if ((long)blockIdx.x * PI_WAVES + wave < B) request((long)blockIdx.x * PI_WAVES + wave);
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
     const long row = item * N;
     v4i b0;                                                // v modulo 2^(m - kb), centred: the second product's Toeplitz operand
-    int ln = lane;                                         // (opaque per item: the column masks of pi_digits are otherwise hoisted out of the
-    asm volatile("" : "+v"(ln));                           //  item loop -- 24 registers live for ever, spilled at 128 per wave)
+    v4i F[1];
     {
+      const int ch = chunk_of(opaque(lane));
       v4i va[2], vf[1];
       shift_raw<2>(rv, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(v + row) & 15)), va);
       shift_raw<1>(rf, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(f + row) & 15)), vf);
       u32 xv[8];
 #pragma unroll
       for (int c = 0; c < 4; c++) { xv[c] = (u32)va[0][c]; xv[4 + c] = (u32)va[1][c]; }
-      {
-        v4i b1;
-        pi_digits(xv, me, 1u, 16 * ln, N, b0, b1);
-      }
-      union { v4i v; signed char c[16]; } u; u.v = vf[0] & col_mask16(16 * ln, N);        // any negative byte is -1 (ValTernary)
+      v4i o1;
+      pi_digits(xv, me, 1u, 16 * ch, N, b0, o1);
+      pi_digits(xv, 256u, 1u, 16 * ch, N, F[0], o1);      // v < 2^kb <= 128: its own centred representative modulo 256
+      union { v4i v; signed char c[16]; } u; u.v = vf[0] & col_mask16(16 * ch, N);        // any negative byte is -1 (ValTernary)
 #pragma unroll
       for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
-      pi_build_array(nat, T, g, lane, u.v);
-      if (stager) {
-        v4i o0, o1;
-        pi_digits(xv, 256u, 1u, 16 * ln, N, o0, o1);     // v < 2^kb <= 128: its own centred representative modulo 256
-        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = o0;
-      }
-      wave_lds_fence();
+      pi_build_array_ch(nat, T, g, lane, ch, u.v);
     }
-    v16i L0, L1, H0, H1;
-    pi_product<false>(pa0, pa0, tb, NT, mlow, L0, L1, H0, H1);           // f v
+    v16i L[1], H[1];
+    pi_product_reg<1>(F, T, g, lane, L, H);                // f v
     if (item + item_step < B) request(item + item_step);   // the next item's rows (nobody lifts them before this wave does): a product ahead
-    u32 e[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 fv = (u32)(L0[i] + H0[i]) & (mr - 1);
-      e[i] = ((fv - (i == 0 && kl == 0 ? 1u : 0u)) & (mr - 1)) >> kb;   // e = (f v - 1) / 2^kb, below 2^(m - kb) <= 128
-    }
     {
-      pi_build_array(nat, T, g, lane, b0);                 // (over f's array; it leaves the chunk matrix region zero)
+      const int ln = opaque(lane), kl = 128 * (ln >> 5) + (ln & 31), ch = chunk_of(ln);
+      u32 e[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int k = 32 * ((i & 3) + 8 * (i >> 2)) + kl;
-        if (k < N) fa0[32 * PI_PAD + k] = (unsigned char)e[i];
+        const u32 fv = (u32)(L[0][i] + H[0][i]) & (mr - 1);
+        e[i] = ((fv - (i == 0 && kl == 0 ? 1u : 0u)) & (mr - 1)) >> kb;   // e = (f v - 1) / 2^kb, below 2^(m - kb) <= 128
       }
+      pi_build_array_ch(nat, T, g, lane, ch, b0);          // (over f's array; its last fence orders the reads of nat before the writes below)
+#pragma unroll
+      for (int i = 0; i < 16; i++) nat[32 * ((i & 3) + 8 * (i >> 2)) + kl] = (unsigned char)e[i];     // index <= 1151 (pi_nat_bytes)
       wave_lds_fence();
+      F[0] = *(const v4i *)(nat + 16 * ch) & col_mask16(16 * ch, N);       // (bytes at and beyond N: whatever the product left there)
     }
     // v in the accumulator layout, for the lift (the row this item staged a moment ago: an L2 hit), in flight during the second product
     const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(v + row, 2L * N);
+    const int kl2 = 128 * (opaque(lane) >> 5) + (opaque(lane) & 31);
     u16 vold[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) vold[i] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_v, 2 * kl, 2 * 32 * ((i & 3) + 8 * (i >> 2)), 0);
-    pi_product<false>(pa0, pa0, tb, NT, mlow, L0, L1, H0, H1);           // e v
+    for (int i = 0; i < 16; i++) vold[i] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_v, 2 * kl2, 2 * 32 * ((i & 3) + 8 * (i >> 2)), 0);
+    pi_product_reg<1>(F, T, g, lane, L, H);                // e v
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int ko = 32 * ((i & 3) + 8 * (i >> 2));
-      const u32 w = (u32)(L0[i] + H0[i]) & (me - 1);
-      __builtin_amdgcn_raw_buffer_store_b16((u16)(((u32)vold[i] - (w << kb)) & (mr - 1)), rs_v, 2 * kl, 2 * ko, 0);
+      const u32 w = (u32)(L[0][i] + H[0][i]) & (me - 1);
+      __builtin_amdgcn_raw_buffer_store_b16((u16)(((u32)vold[i] - (w << kb)) & (mr - 1)), rs_v, 2 * kl2, 2 * ko, 0);
     }
     wave_lds_fence();
   }
 }
 
 // Generic per-item product on the matrix cores: both operands < q <= 8192 (multiplyPolynomials + dividePolynomials by I,
-// index.js:319-401, with q a power of two; the v * v product of polyInv's Newton rounds).  With a = a0 + 128 a1 and
-// b = b0 + 128 b1 the product is a0 b0 + 128 (a0 b1 + a1 b0) + 16384 a1 b1, and 16384 = 0 mod q: three plane products, two
-// accumulator groups, two reversed arrays (the digit planes of b) per item.
-static __host__ __device__ inline size_t pi_wave_bytes2(const PGeom &g) { return pi_wave_bytes(g) + (size_t)16 * g.tpitch; }
+// index.js:319-401, with q a power of two).  With a = a0 + 128 a1 and b = b0 + 128 b1 the product is
+// a0 b0 + 128 (a0 b1 + a1 b0) + 16384 a1 b1, and 16384 = 0 mod q: three plane products, two accumulator groups, two reversed arrays
+// (the digit planes of b) per item, the rows of a0 and a1 in registers.
+// ONE (q <= 256): one digit plane per operand.
+static __host__ __device__ inline size_t pi_reg_wave_bytes2(const PGeom &g) { return pi_reg_wave_bytes(g) + (size_t)16 * g.tpitch; }
 
-// ONE (q <= 256: one digit plane per operand -- every Newton round of the key inversion in its lifted form): no second chunk matrix,
-// no second reversed array, half the accumulators: 9.7 instead of 19.3 KB of LDS per wave and 128 registers, i.e. sixteen instead of
-// eight waves per CU.
 template <bool ONE>
 __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(ONE ? 4 : 3, 4))) void k_polymul_m(
-    PGeom g, u32 q, const u16 *__restrict__ a, const u16 *b, long B, u16 *__restrict__ quot,
-    u16 *__restrict__ rem, u16 *lift_v, u32 lift_k, u32 lift_q) {
+    PGeom g, u32 q, const u16 *__restrict__ a, const u16 *__restrict__ b, long B, u16 *__restrict__ quot, u16 *__restrict__ rem) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-  const size_t fa_region = ONE ? pi_one_bytes(g) - (size_t)16 * g.tpitch : 2 * pi_fa_bytes(g);
-  unsigned char *fa0 = lds + (size_t)wave * (ONE ? pi_one_bytes(g) : pi_wave_bytes2(g)), *fa1 = ONE ? fa0 : fa0 + pi_fa_bytes(g), *nat = fa0;
-  u32 *T0 = (u32 *)(fa0 + fa_region), *T1 = T0 + 4 * g.tpitch;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char *nat = lds + (size_t)wave * (ONE ? pi_reg_wave_bytes(g) : pi_reg_wave_bytes2(g));
+  u32 *T0 = (u32 *)(nat + pi_nat_bytes(g)), *T1 = T0 + 4 * g.tpitch;
   const int N = g.N, NT = g.NT;
-  for (size_t i = 16 * lane; i < fa_region; i += 16 * 64) *(v4i *)(fa0 + i) = (v4i){0, 0, 0, 0};   // the pads stay zero
-  const int y0 = 32 * NT - 1 - r + 16 * hh;
-  const u32 *tb0 = T0 + (y0 & 3) * g.tpitch + (y0 >> 2), *tb1 = tb0 + 4 * g.tpitch;
-  const unsigned char *pa0 = fa0 + 32 * PI_PAD + 32 * r + 16 * hh, *pa1 = fa1 + 32 * PI_PAD + 32 * r + 16 * hh;
-  u32 mlow[4];
-  diag_low_mask(lane, mlow);
-  const bool stager = 16 * lane < 32 * NT;
-  constexpr bool one = ONE;                                // single int8 plane per operand (pi_digits)
-  const bool want_q = quot != nullptr;                     // the Newton rounds of the key inversion only need the remainder
-  wave_lds_fence();
+  const bool want_q = quot != nullptr;
+  auto chunk_of = [](int ln) { return 2 * (ln & 31) + (ln >> 5); };
   const long item_step = (long)gridDim.x * PI_WAVES;         // the NEXT item's operands are requested early: see k_product_tern_m
   RawChunks<2> rwa, rwb;
   auto request = [&](long it) {
     const long rw = it * N, lf = (B - it) * N;
+    const int ch = chunk_of(opaque(lane));
     const AlignedSrc sa = aligned_src(a + rw, 2 * lf), sb = aligned_src(b + rw, 2 * lf);
-    rwa = load_raw<2>(sa, sa.a0 + 32 * lane, 0);
-    rwb = load_raw<2>(sb, sb.a0 + 32 * lane, 0);
+    rwa = load_raw<2>(sa, sa.a0 + 32 * ch, 0);
+    rwb = load_raw<2>(sb, sb.a0 + 32 * ch, 0);
   };
   if ((long)blockIdx.x * PI_WAVES + wave < B) request((long)blockIdx.x * PI_WAVES + wave);
   [[maybe_unused]] int stamp_iter = -1;                    // -DNTRU_STAMPS: phase stamps of the first items (tools/phase_stamps_peritem.py)
@@ -703,7 +550,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
     const long row = item * N;
     stamp_iter++;
     STAMP(0);
+    v4i a0, a1;
     {
+      const int ch = chunk_of(opaque(lane));
       u32 xa[8], xb[8];
       {
         v4i va[2], vb[2];
@@ -714,101 +563,95 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
       }
       STAMP(1);                                            // operands arrived
       if (item + item_step < B) request(item + item_step);
-      v4i a0, a1, b0, b1;
-      pi_digits(xa, q, 1u, 16 * lane, N, a0, a1);
-      pi_digits(xb, q, 1u, 16 * lane, N, b0, b1);
+      v4i b0, b1;
+      pi_digits(xa, q, 1u, 16 * ch, N, a0, a1);
+      pi_digits(xb, q, 1u, 16 * ch, N, b0, b1);
       STAMP(2);                                            // digits
-      pi_build_array(nat, T0, g, lane, b0);
-      if (!one) pi_build_array(nat, T1, g, lane, b1);
+      pi_build_array_ch(nat, T0, g, lane, ch, b0);
+      if (!ONE) pi_build_array_ch(nat, T1, g, lane, ch, b1);
       STAMP(3);                                            // reversed arrays
-      if (stager) {
-        *(v4i *)(fa0 + 32 * PI_PAD + 16 * lane) = a0;
-        if (!one) *(v4i *)(fa1 + 32 * PI_PAD + 16 * lane) = a1;
-      }
-      wave_lds_fence();
     }
-    STAMP(4);                                              // chunk matrices
-    v16i L0, L1, H0, H1;                                   // group 0: a0 b0; group 1: a0 b1 + a1 b0
+    v16i XL[2], XH[2];                                     // group 0: a0 b0; group 1: a0 b1 + a1 b0
+    if (ONE) {
+      v4i F[1] = {a0};
+      v16i L[1], H[1];
+      pi_product_reg<1>(F, T0, g, lane, L, H);
+      XL[0] = L[0]; XH[0] = H[0];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { L0[i] = 0; L1[i] = 0; H0[i] = 0; H1[i] = 0; }
-    // The loop lives on its LDS reads (phase stamps, profiles/r03_phase_stamps_peritem.txt: ~250 clocks per step = what 12 waves x 4 KB
-    // cost the CU's LDS), so the single-plane form (q <= 256: the early Newton rounds) must not read the second plane's operands.
-    auto loops = [&]() {
-      auto ld = [&](int d, v4i &x0, v4i &x1, v4i &w0, v4i &w1) {
-        const u32 *p0 = tb0 - 8 * d;
-        w0 = (v4i){(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3]};
-        x0 = *(const v4i *)(pa0 - 32 * d);
-        if (!ONE) {
-          const u32 *p1 = tb1 - 8 * d;
-          w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
-          x1 = *(const v4i *)(pa1 - 32 * d);
-        }
+      for (int i = 0; i < 16; i++) { XL[1][i] = 0; XH[1][i] = 0; }
+    } else {
+      // as pi_product_reg, with two fragment streams (the planes of b) and three matrix instructions per half trip
+      const int ln = opaque(lane);
+      const int y0 = 32 * NT - 1 - (ln & 31) + 16 * (ln >> 5);
+      const u32 *tb = T0 + (y0 & 3) * g.tpitch + (y0 >> 2);
+      const int tstep = 4 * g.tpitch;                      // dwords from a fragment of b0 to the same fragment of b1
+      int seam_up = ln == 32 ? 0 : -1, seam_dn = ln == 31 ? 0 : -1;
+      asm volatile("" : "+v"(seam_up), "+v"(seam_dn));
+      struct Fr { v4i w0, w1; };
+      auto frag = [&](int d) {
+        d = d > NT - 1 ? NT - 1 : (d < 1 - NT ? 1 - NT : d);
+        const u32 *p = tb - 8 * d, *p1 = p + tstep;
+        Fr fr;
+        fr.w0 = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+        fr.w1 = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+        return fr;
       };
-      auto mm3 = [&](v16i &X0, v16i &X1, v4i x0, v4i x1, v4i w0, v4i w1) {
-        X0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w0, X0, 0, 0, 0);
-        if (!ONE) {                                        // q <= 256: both operands are single planes
-          X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x0, w1, X1, 0, 0, 0);
-          X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(x1, w0, X1, 0, 0, 0);
-        }
-      };
-      v4i x0, x1 = {0, 0, 0, 0}, w0, w1 = {0, 0, 0, 0};
-      ld(-(NT - 1), x0, x1, w0, w1);
-      for (int d = -(NT - 1); d < 0; d++) {
-        v4i n0, n1 = {0, 0, 0, 0}, m0, m1 = {0, 0, 0, 0};
-        ld(d + 1, n0, n1, m0, m1);
-        mm3(H0, H1, x0, x1, w0, w1);
-        x0 = n0; x1 = n1; w0 = m0; w1 = m1;
-      }
+      const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const Fr f0 = frag(0);
+      Fr la = frag(1), ha = frag(-1), lb, hb;
       {
-        v4i n0, n1 = {0, 0, 0, 0}, m0, m1 = {0, 0, 0, 0};
-        ld(1, n0, n1, m0, m1);
-        u32 mhigh[4];
+        u32 mlow[4], mhigh[4];
+        diag_low_mask(ln, mlow);
 #pragma unroll
         for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
-        mm3(L0, L1, x0, x1, and4(w0, mlow), and4(w1, mlow));
-        mm3(H0, H1, x0, x1, and4(w0, mhigh), and4(w1, mhigh));
-        x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+        XL[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, and4(f0.w0, mlow), zero, 0, 0, 0);
+        XL[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, and4(f0.w1, mlow), zero, 0, 0, 0);
+        XL[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, and4(f0.w0, mlow), XL[1], 0, 0, 0);
+        XH[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, and4(f0.w0, mhigh), zero, 0, 0, 0);
+        XH[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, and4(f0.w1, mhigh), zero, 0, 0, 0);
+        XH[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, and4(f0.w0, mhigh), XH[1], 0, 0, 0);
       }
-      for (int d = 1; d < NT; d++) {
-        v4i n0, n1 = {0, 0, 0, 0}, m0, m1 = {0, 0, 0, 0};
-        ld(d + 1, n0, n1, m0, m1);
-        mm3(L0, L1, x0, x1, w0, w1);
-        x0 = n0; x1 = n1; w0 = m0; w1 = m1;
+      v4i AL0 = a0, AL1 = a1, AH0 = a0, AH1 = a1;
+      auto trip = [&](const Fr &wl, const Fr &wh) {
+        AL0 = rows_up(AL0, seam_up);
+        XL[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AL0, wl.w0, XL[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AL1 = rows_up(AL1, seam_up);
+        XL[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AL0, wl.w1, XL[1], 0, 0, 0);
+        XL[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AL1, wl.w0, XL[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AH0 = rows_down(AH0, seam_dn);
+        XH[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AH0, wh.w0, XH[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        AH1 = rows_down(AH1, seam_dn);
+        XH[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AH0, wh.w1, XH[1], 0, 0, 0);
+        XH[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AH1, wh.w0, XH[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      int j = 1;
+      for (; j + 1 < NT; j += 2) {
+        lb = frag(j + 1); hb = frag(-(j + 1));
+        trip(la, ha);
+        la = frag(j + 2); ha = frag(-(j + 2));
+        trip(lb, hb);
       }
-    };
-    // lift_v (a Newton round of the key inversion in its lifted form, ntru_invert_key_batch_dev): what leaves is not the product w but
-    // v <- (v - 2^lift_k w) mod lift_q on the item's row of lift_v, read here in the accumulator layout (it is the b row this item
-    // staged a moment ago: an L2 hit) -- the round's third kernel and its two passes over HBM are gone.
-    const int kl = 128 * hh + r;                                         // see k_verify_keys_m: indices >= N are dropped
-    u16 vold[16];
-    if (lift_v) {
-      const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(lift_v + row, 2L * N);
-#pragma unroll
-      for (int i = 0; i < 16; i++) vold[i] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_v, 2 * kl, 2 * 32 * ((i & 3) + 8 * (i >> 2)), 0);
+      if (j < NT) trip(la, ha);
     }
-    loops();
-    STAMP(5);                                              // matrix loops
-    if (lift_v) {
-      const __amdgpu_buffer_rsrc_t rs_v = rows_rsrc(lift_v + row, 2L * N);
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
-        const u32 w = ((u32)L0[i] + 128u * (u32)L1[i] + (u32)H0[i] + 128u * (u32)H1[i]) & (q - 1);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)(((u32)vold[i] - (w << lift_k)) & (lift_q - 1)), rs_v, 2 * kl, 2 * ko, 0);
-      }
-    } else {
+    STAMP(4);                                              // matrix loops
+    {
+      const int ln = opaque(lane), kl = 128 * (ln >> 5) + (ln & 31);     // see k_verify_keys_m: indices >= N are dropped
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
       const __amdgpu_buffer_rsrc_t rs_q = rows_rsrc(want_q ? quot + row : nullptr, want_q ? 2L * N : 0L);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
-        const u32 lo = (u32)L0[i] + 128u * (u32)L1[i], hi = (u32)H0[i] + 128u * (u32)H1[i];
+        const u32 lo = (u32)XL[0][i] + 128u * (u32)XL[1][i], hi = (u32)XH[0][i] + 128u * (u32)XH[1][i];
         __builtin_amdgcn_raw_buffer_store_b16((u16)((lo + hi) & (q - 1)), rs_r, 2 * kl, 2 * ko, 0);
         if (want_q) __builtin_amdgcn_raw_buffer_store_b16((u16)((0u - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
       }
     }
     wave_lds_fence();
-    STAMP(6);                                              // result stores issued
+    STAMP(5);                                              // result stores issued
   }
 }
 NTRU_STAMPS_READER(ntru_debug_read_stamps_pi)
@@ -834,36 +677,33 @@ static int peritem_grid(ntru_engine *eng, Kern kern, size_t lds, long B, dim3 *g
 }
 
 int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t *d_a, const uint16_t *d_b, int64_t B, uint16_t *d_quot,
-                               uint16_t *d_rem, uint16_t *d_lift_v, int lift_k, int lift_q) {
+                               uint16_t *d_rem) {
   if (!peritem_applies(eng, N, mod)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
   dim3 grid;
   auto go = [&](auto kern, size_t lds) -> int {
     if (int rc = peritem_grid(eng, kern, lds, (long)B, &grid)) return rc;
     snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_polymul_m");
-    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b, (long)B, d_quot, d_rem, (u16 *)d_lift_v,
-                       (u32)lift_k, (u32)lift_q);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)mod, d_a, d_b, (long)B, d_quot, d_rem);
     HIP_TRY(hipGetLastError());
     return NTRU_OK;
   };
-  return mod <= 256 ? go(k_polymul_m<true>, PI_WAVES * pi_one_bytes(pg)) : go(k_polymul_m<false>, PI_WAVES * pi_wave_bytes2(pg));
+  return mod <= 256 ? go(k_polymul_m<true>, PI_WAVES * pi_reg_wave_bytes(pg)) : go(k_polymul_m<false>, PI_WAVES * pi_reg_wave_bytes2(pg));
 }
 
 bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q) { return peritem_applies(eng, N, q); }
 
 int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s, long B,
-                                    uint16_t *d_quot, uint16_t *d_rem, uint32_t nshift, int abits) {
+                                    uint16_t *d_quot, uint16_t *d_rem) {
   const PGeom pg = make_pgeom(N);
   dim3 grid;
   auto go = [&](auto kern, size_t lds) -> int {
     if (int rc = peritem_grid(eng, kern, lds, B, &grid)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, (u32)mul, (u32)nshift, d_a, d_s, B, d_quot, d_rem);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)q, (u32)mul, d_a, d_s, B, d_quot, d_rem);
     HIP_TRY(hipGetLastError());
     return NTRU_OK;
   };
-  // one digit plane: q <= 256, or every a[i] below 2^abits <= 128 (then mul must be 1)
-  return q <= 256 || (abits <= 7 && mul == 1u) ? go(k_product_tern_m<true>, PI_WAVES * pi_one_bytes(pg))
-                                               : go(k_product_tern_m<false>, PI_WAVES * pi_wave_bytes(pg));
+  return q <= 256 ? go(k_product_tern_m<true>, PI_WAVES * pi_reg_wave_bytes(pg)) : go(k_product_tern_m<false>, PI_WAVES * pi_reg_wave_bytes(pg));
 }
 
 int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const int8_t *d_g, const uint16_t *d_fq,
@@ -883,10 +723,13 @@ int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const 
 
 
 // One Newton round (v from kb to m bits) of the key inversion as ONE kernel: kb <= 7 (v below 128: one digit plane), per-item matrix path.
+bool ntru_newton_round_matrix_applies(const ntru_engine *eng, int N, int kb, int m) {
+  return kb <= 7 && m <= 2 * kb && m > kb && peritem_applies(eng, N, 1 << m);
+}
 int ntru_launch_newton_round_matrix(ntru_engine *eng, int N, int kb, int m, const int8_t *d_f, uint16_t *d_v, long B) {
-  if (kb > 7 || m > 2 * kb || m <= kb || !peritem_applies(eng, N, 1 << m)) return NTRU_NOT_TAKEN;
+  if (!ntru_newton_round_matrix_applies(eng, N, kb, m)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
-  const size_t lds = PI_WAVES * pi_one_bytes(pg);
+  const size_t lds = PI_WAVES * pi_reg_wave_bytes(pg);
   dim3 grid;
   if (int rc = peritem_grid(eng, k_newton_round_m, lds, B, &grid)) return rc;
   hipLaunchKernelGGL(k_newton_round_m, grid, dim3(64 * PI_WAVES), lds, eng->stream, pg, (u32)kb, (u32)m, d_f, d_v, B);

@@ -1,5 +1,5 @@
 # Socket power / shader clock while ONE kernel runs back to back for a few seconds (hwmon sampling as in bench.py):
-#   python tools/power_kernel.py encrypt|decrypt PATH [PATH ...]
+#   python tools/power_kernel.py encrypt|decrypt|verify PATH [PATH ...]
 import importlib, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import bench
@@ -18,8 +18,17 @@ fp = torch.randint(0, 3, (N,), dtype=torch.uint8, device=dev, generator=g)
 e = torch.randint(0, q, (B, N), dtype=torch.int32, device=dev, generator=g).to(torch.int16); qe = torch.empty_like(e)
 v = torch.empty((B, N), dtype=torch.uint8, device=dev); q2 = torch.empty_like(v); q1 = torch.empty_like(e); r1 = torch.empty_like(e)
 e2 = torch.empty_like(e)
+if what == 'verify':                                       # verifyKeysInputs on 2^18 synthetic per-item key pairs
+    Bk = 1 << 18
+    kf = (torch.randint(0, 3, (Bk, N), device=dev, generator=g) - 1).to(torch.int8); kg = (torch.randint(0, 3, (Bk, N), device=dev, generator=g) - 1).to(torch.int8)
+    kfq = e[:Bk].contiguous(); kfp = r[:Bk].contiguous(); kh = qe[:Bk].random_(0, q)
+    o16 = [torch.empty((Bk, N), dtype=torch.int16, device=dev) for _ in range(4)]; o8 = [torch.empty((Bk, N), dtype=torch.uint8, device=dev) for _ in range(2)]
+    fl = torch.empty(Bk, dtype=torch.uint8, device=dev)
 def call():
-    if what == 'encrypt':
+    if what == 'verify':
+        eng.verify_keys_batch_dev(N, q, p, kf.data_ptr(), kg.data_ptr(), kfq.data_ptr(), kfp.data_ptr(), kh.data_ptr(), Bk, o16[0].data_ptr(), o16[1].data_ptr(),
+                                  o8[0].data_ptr(), o8[1].data_ptr(), o16[2].data_ptr(), o16[3].data_ptr(), fl.data_ptr())
+    elif what == 'encrypt':
         eng.encrypt_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e2.data_ptr(), qe.data_ptr())
     else:
         eng.decrypt_batch_dev(N, q, p, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr(), q1.data_ptr(), r1.data_ptr(), q2.data_ptr())
