@@ -3,6 +3,8 @@
 
   python bench.py --gpus 1 --steps K --warmup W
   python bench.py --workload {roundtrip,encrypt_n701,verify_keys} ...   (BASELINE.json configs 3 [default], 4 and 5, same launcher)
+  python bench.py --gpus 8 --workload verify_keys --total-batch-log2 18     (config 5 AS WORDED: 2^18 key pairs over the 8 GPUs)
+  python bench.py --gpus 8 --workload encrypt_n701 --total-batch-log2 23    (config 4 as worded: 2^23 encrypts over the 8 GPUs)
   python bench.py --gpus N --steps K --warmup W          (no RANK in the environment: bench.py starts the N ranks itself, as
                                                           a CHILD `python -m torch.distributed.run`, before anything touches HIP)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -54,6 +56,11 @@ def parse_args(argv=None):
                          "(N=701 q=8192 encryptBits, 2^20 per GPU); verify_keys: config 5 (N=821 verifyKeysInputs with per-item keys, "
                          "2^18 per GPU)")
     ap.add_argument("--batch-log2", type=int, default=None, help="items per GPU per step (2^k); default: the workload's")
+    ap.add_argument("--total-batch-log2", type=int, default=None,
+                    help="items per step over ALL ranks (2^k, split evenly: --gpus must be a power of two); the line then says "
+                         "scaling = strong.  BASELINE.json words configs 4 and 5 this way (2^23 encrypts / 2^18 keys on 8 GPUs)")
+    ap.add_argument("--synthetic-keys", action="store_true",
+                    help="verify_keys: uniform random operands (every flag `invalid`) instead of key pairs generated on the device")
     ap.add_argument("--profile", default=None, help="golden key / parameter set under tests/golden; default: the workload's")
     ap.add_argument("--mode", choices=["witness", "value"], default="witness",
                     help="witness: every array the reference returns; value: ciphertext / plaintext only")
@@ -85,6 +92,12 @@ def parse_args(argv=None):
                          "sampler sees the GPU busy too")
     args = ap.parse_args(argv)
     w = WORKLOADS[args.workload]
+    if args.total_batch_log2 is not None:
+        if args.batch_log2 is not None:
+            ap.error("--batch-log2 and --total-batch-log2 exclude each other")
+        if args.gpus & (args.gpus - 1) or (1 << args.total_batch_log2) < args.gpus:
+            ap.error("--total-batch-log2 needs a power-of-two --gpus that does not exceed the batch")
+        args.batch_log2 = args.total_batch_log2 - (args.gpus.bit_length() - 1)
     if args.batch_log2 is None:
         args.batch_log2 = w["batch_log2"]
     if args.profile is None:
@@ -169,6 +182,54 @@ def make_inputs(torch, dev, B, N, d, seed, ld=None):
         mp[:, :N] = m
         m = mp
     return r, m
+
+
+def generate_key_pairs(torch, eng, dev, o, B, first_item, max_redraws=8):
+    """B TRUE key pairs on the device (index.js:51-79): f, g from the on-device sampler (generateCustomArray's
+    shuffle on a ChaCha20 stream: df ones and df - 1 minus ones / dg and dg), fq = f^-1 mod q and fp = f^-1 mod p from
+    ntru_invert_key_batch_dev, h = p fq g from ntru_public_key_batch_dev.  Rows whose f is not a unit are drawn again (the
+    reference's generatePrivateKeyF retries the same way, index.js:51-66).  Returns (f, g, fq, fp, h, info)."""
+    N, q, p, df, dg = o["N"], o["q"], o["p"], o["df"], o["dg"]
+    key = (np.arange(8, dtype=np.uint32) * 0x85EBCA6B + 7).astype(np.uint32)
+    fs = torch.empty((B, N), dtype=torch.uint8, device=dev); gs = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    eng.sample_ternary_dev(N, df, df - 1, 255, key, first_item, B, fs.data_ptr())                    # 255 = -1 as int8
+    eng.sample_ternary_dev(N, dg, dg, 255, key, (1 << 40) + first_item, B, gs.data_ptr())
+    f, g = fs.view(torch.int8), gs.view(torch.int8)
+    fq = torch.empty((B, N), dtype=torch.int16, device=dev); fp = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    fl = torch.empty(B, dtype=torch.uint8, device=dev); h = torch.empty((B, N), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.invert_key_batch_dev(N, q, p, f.data_ptr(), B, fq.data_ptr(), fp.data_ptr(), fl.data_ptr())
+    torch.cuda.synchronize(); t_inv = time.perf_counter() - t0
+    redrawn, rounds = 0, 0
+    bad = torch.nonzero(fl).flatten()
+    while bad.numel():
+        rounds += 1
+        if rounds > max_redraws:
+            raise SystemExit("bench: %d private keys still not invertible after %d redraws" % (bad.numel(), max_redraws))
+        n = int(bad.numel()); redrawn += n
+        f2 = torch.empty((n, N), dtype=torch.uint8, device=dev)
+        eng.sample_ternary_dev(N, df, df - 1, 255, key, (rounds << 44) + first_item + int(bad[0]), n, f2.data_ptr())
+        fq2 = torch.empty((n, N), dtype=torch.int16, device=dev); fp2 = torch.empty((n, N), dtype=torch.uint8, device=dev)
+        fl2 = torch.empty(n, dtype=torch.uint8, device=dev)
+        eng.invert_key_batch_dev(N, q, p, f2.data_ptr(), n, fq2.data_ptr(), fp2.data_ptr(), fl2.data_ptr())
+        torch.cuda.synchronize()
+        good = fl2 == 0
+        f[bad[good]] = f2.view(torch.int8)[good]; fq[bad[good]] = fq2[good]; fp[bad[good]] = fp2[good]
+        bad = bad[~good]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.public_key_batch_dev(N, q, p, fq.data_ptr(), g.data_ptr(), B, h.data_ptr())
+    torch.cuda.synchronize(); t_h = time.perf_counter() - t0
+    return f, g, fq, fp, h, {"source": "generated on the device: ntru_sample_ternary_dev (f: %d ones, %d minus ones; g: %d / %d) -> "
+                                       "ntru_invert_key_batch_dev -> ntru_public_key_batch_dev" % (df, df - 1, dg, dg),
+                             "invert_ms": t_inv * 1e3, "public_key_ms": t_h * 1e3, "non_units_redrawn": redrawn, "key_pairs": B}
+
+
+def check_keys_against_oracle(orc, N, q, p, host_rows):
+    """A strided sample of generated keys against the CPU oracle: h = p fq g, and verifyKeysInputs raises no flag -- i.e. the oracle's
+    own products f fq = 1 (mod q) and f fp = 1 (mod p) hold, and the inverses are unique."""
+    f, g, fq, fp, h = host_rows
+    want = orc.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+    return bool(np.array_equal(orc.public_key_batch(N, q, p, fq, g), h)) and not want["flags"].any(), want
 
 
 def engine_source_hash():
@@ -356,10 +417,20 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.ones(1, device=dev)             # the first collective is where RCCL really starts: fail HERE, loudly,
+                dist.all_reduce(probe); torch.cuda.synchronize()     # not in the middle of the timed region
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce over %d ranks returned %r" % (world, probe.item()))
+            else:
+                dist.init_process_group("gloo")
+        except Exception as exc:                              # noqa: BLE001 -- no fallback to another backend, no re-exec: a clear non-zero exit
+            sys.stderr.write("bench: rank %s: process group (%s, world %d) did not come up: %r\n"
+                             % (os.environ.get("RANK", "0"), args.dist_backend, world, exc))
+            sys.stderr.flush()
+            os._exit(3)
     red_dev = dev if args.dist_backend == "nccl" else None        # where the timing all_reduce lives
 
     o, h_np, f_np, fp_np = load_key(args.profile)
@@ -428,13 +499,17 @@ def main():
                 if wl == "roundtrip":
                     orc.decrypt_batch(N, q, p, f_np, fp_np, e_c, mode)
             return unit
-    else:       # verify_keys: per-item operands.  2^18 TRUE key pairs would take the reference ~100 h, so the operands are synthetic
-        gk = torch.Generator(device=dev); gk.manual_seed(seed + 5)          # (SURVEY.md 8d config 5): every output is still defined
-        tern = lambda: (torch.randint(0, 3, (B, N), device=dev, generator=gk) - 1).to(torch.int8)
-        kf, kg = tern(), tern()
-        kfq = torch.randint(0, q, (B, N), device=dev, generator=gk).to(torch.int16)
-        kh = torch.randint(0, q, (B, N), device=dev, generator=gk).to(torch.int16)
-        kfp = torch.randint(0, p, (B, N), device=dev, generator=gk).to(torch.uint8)
+    else:       # verify_keys (config 5): per-item operands -- TRUE key pairs generated on the device, outside the timed region
+        keys_info = None
+        if args.synthetic_keys:                                # uniform random operands: every output is still defined, every flag says invalid
+            gk = torch.Generator(device=dev); gk.manual_seed(seed + 5)
+            tern = lambda: (torch.randint(0, 3, (B, N), device=dev, generator=gk) - 1).to(torch.int8)
+            kf, kg = tern(), tern()
+            kfq = torch.randint(0, q, (B, N), device=dev, generator=gk).to(torch.int16)
+            kh = torch.randint(0, q, (B, N), device=dev, generator=gk).to(torch.int16)
+            kfp = torch.randint(0, p, (B, N), device=dev, generator=gk).to(torch.uint8)
+        else:
+            kf, kg, kfq, kfp, kh, keys_info = generate_key_pairs(torch, eng, dev, o, B, rank * B)
         kouts = [b16(), b16(), b8(), b8(), b16(), b16()]           # quotient / remainder of fq * f, fp * f, (p fq) * g
         kflags = torch.empty(B, dtype=torch.uint8, device=dev)
         n_ev = 2
@@ -475,7 +550,7 @@ def main():
         for k in range(args.steps):
             step(events[k])
 
-    elapsed = sh.timed_region(run_steps, torch.cuda.synchronize, dist, red_dev, always=args.force_dist)
+    elapsed, elapsed_local = sh.timed_region(run_steps, torch.cuda.synchronize, dist, red_dev, always=args.force_dist, return_local=True)
     seg_ms = [float(np.mean([ev[i].elapsed_time(ev[i + 1]) for ev in events])) for i in range(n_ev - 1)]
 
     # ---- bit-exact check of a strided sample against the CPU oracle (outside the timed region): every output array ---
@@ -504,6 +579,12 @@ def main():
         knames = ("quot_fq", "rem_fq", "quot_fp", "rem_fp", "quot_h", "rem_h")
         got = {n_: host(t) for n_, t in zip(knames, kouts)}
         got["flags"] = kflags[rows].cpu().numpy()
+        if keys_info is not None:                              # the generated keys themselves: h = p fq g and no flag from the oracle's own products
+            keys_ok, _ = check_keys_against_oracle(orc, N, q, p, [a[:256] for a in ins])
+            keys_info["sample_equals_oracle"] = keys_ok
+            keys_info["flags_valid"] = int((kflags == 0).sum())
+            if not keys_ok or keys_info["flags_valid"] != B:
+                raise SystemExit("bench: generated keys fail verifyKeysInputs (%d of %d valid; oracle sample %s)" % (keys_info["flags_valid"], B, keys_ok))
 
         def oracle_rows(lo, hi):
             return orc.verify_keys_batch(N, q, p, *[a[lo:hi] for a in ins])
@@ -532,19 +613,6 @@ def main():
 
     # ---- multi-rank evidence: who took part, and the final gather-to-root (outside the timed region) --------------------------
     dist_info, gathered = None, None
-    if dist:
-        me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "pid": os.getpid(),
-              "pci_bus_id": os.path.basename(os.path.realpath(device_sysfs_dir(dev_index) or "?")),
-              "name": torch.cuda.get_device_name(dev_index)}
-        everyone = [None] * world
-        dist.all_gather_object(everyone, me)
-        try:
-            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
-        except Exception:                                   # noqa: BLE001 -- reporting only
-            rccl = None
-        dist_info = {"backend": args.dist_backend, "world": world, "rccl_version": rccl if args.dist_backend == "nccl" else None,
-                     "ranks": sorted(everyone, key=lambda x: x["rank"]),
-                     "timing": "barrier + synchronize on both sides of the K steps, all_reduce(MAX) of the ranks' seconds"}
     if dist and (args.gather or world > 1):
         # The final gather: every rank's result rows onto rank 0, once (gather-to-root; nccl = RCCL over xGMI, GPU
         # memory to GPU memory; gloo = through host memory).  Its time is reported, not hidden.
@@ -570,7 +638,8 @@ def main():
     if rank == 0:
         total = world * B * args.steps
         common = {"value": total / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                  "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                  "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                  "scaling": "strong" if args.total_batch_log2 is not None else "weak", "vs_baseline": None,
                   "data": "synthetic", "verified_bit_exact_rows": int(rows.numel()), "verified_arrays": sorted(got.keys())}
         par = "batch-sharded x%d, no collective" % world
     if rank == 0 and wl == "roundtrip":
@@ -666,15 +735,11 @@ def main():
             del ref_out
         if world == 1 and args.kernel_path == "auto" and not ablation:
             # The other function of the path with per-item operands, verifyKeysInputs (index.js:141-197, BASELINE config 5),
-            # outside the timed region: 2^18 synthetic key pairs (config 5's size), kernel time of 3 launches
-            # (`--workload verify_keys` is the same thing as a bench line of its own, oracle-checked).
+            # outside the timed region: 2^18 TRUE key pairs generated on the device (config 5's size), kernel time of 3 launches,
+            # a sample of the keys and of every witness array against the oracle (`--workload verify_keys` is the same thing as a
+            # bench line of its own).
             Bk = 1 << 18
-            gk = torch.Generator(device=dev); gk.manual_seed(5)
-            tern = lambda: (torch.randint(0, 3, (Bk, N), device=dev, generator=gk) - 1).to(torch.int8)
-            kf, kg = tern(), tern()
-            kfq = torch.randint(0, q, (Bk, N), device=dev, generator=gk).to(torch.int16)
-            kh = torch.randint(0, q, (Bk, N), device=dev, generator=gk).to(torch.int16)
-            kfp = torch.randint(0, p, (Bk, N), device=dev, generator=gk).to(torch.uint8)
+            kf, kg, kfq, kfp, kh, kinfo = generate_key_pairs(torch, eng, dev, o, Bk, 0)
             k16 = lambda: torch.empty((Bk, N), dtype=torch.int16, device=dev)
             k8 = lambda: torch.empty((Bk, N), dtype=torch.uint8, device=dev)
             kouts = [k16(), k16(), k8(), k8(), k16(), k16()]
@@ -688,11 +753,21 @@ def main():
                 vk(); kev[i + 1].record(stream)
             torch.cuda.synchronize()
             vms = float(np.mean([kev[i].elapsed_time(kev[i + 1]) for i in range(3)]))
+            krows = torch.arange(0, Bk, Bk // 256, device=dev)
+            khost = lambda t: to_u16(t[krows].contiguous().cpu().numpy())
+            keys_ok, kwant = check_keys_against_oracle(orc, N, q, p, [khost(t) for t in (kf, kg, kfq, kfp, kh)])
+            kgot = [khost(t) for t in kouts] + [kflags[krows].cpu().numpy()]
+            witness_ok = all(np.array_equal(a, b) for a, b in zip(kgot, kwant.values()))
+            kinfo.update(sample_equals_oracle=keys_ok, flags_valid=int((kflags == 0).sum()))
+            if not (keys_ok and witness_ok and kinfo["flags_valid"] == Bk) and not ablation:
+                raise SystemExit("bench: verify_keys leg differs from the oracle (keys %s, witness %s, %d of %d valid)"
+                                 % (keys_ok, witness_ok, kinfo["flags_valid"], Bk))
             out["verify_keys"] = {"value": Bk / (vms * 1e-3), "unit": "key_pairs/s", "kernel": eng.last_kernel(), "ms": vms,
-                                  "batch": Bk, "hbm_gbs": 17.0 * N * Bk / (vms * 1e-3) / 1e9,
+                                  "batch": Bk, "hbm_gbs": 17.0 * N * Bk / (vms * 1e-3) / 1e9, "keys": kinfo,
+                                  "flags_valid": kinfo["flags_valid"], "witness_rows_equal_oracle": int(krows.numel()),
                                   "roofline": hbm_roofline(eng.last_kernel(), 17 * N, Bk, vms, None,
                                                            "PMC passes: profiles/*_secondary_pmc_hbm.json", 3 * N * N),
-                                  "note": "verifyKeysInputs with per-item keys (synthetic operands), kernel time only"}
+                                  "note": "verifyKeysInputs on 2^18 true key pairs generated on the device (every flag valid), kernel time only"}
             del kf, kg, kfq, kh, kfp, kouts
     elif rank == 0 and wl == "encrypt_n701":
         enc_ms = seg_ms[0]
@@ -714,10 +789,13 @@ def main():
         out.update({
             "metric": "NTRU verifyKeysInputs key pairs per second at N=%d, q=%d (BASELINE.json config 5)" % (N, q), "unit": "key_pairs/s",
             "dtype": "i8" if vname.startswith("k_verify_keys_m") else "u16",
-            "config": {"workload": "N=%d q=%d p=%d, batch=2^%d key pairs per GPU per step with PER-ITEM operands (config 5: 2^18 keys; "
-                                   "synthetic operands -- f, g ternary, fq, h uniform mod q, fp uniform mod p -- every witness array)"
-                                   % (N, q, p, args.batch_log2),
+            "config": {"workload": "N=%d q=%d p=%d, batch=2^%d key pairs per GPU per step (%d over %d GPU%s; config 5: 2^18 keys on 8 GPUs) "
+                                   "with PER-ITEM operands, every witness array; %s"
+                                   % (N, q, p, args.batch_log2, world * B, world, "" if world == 1 else "s",
+                                      "synthetic operands (f, g ternary, fq, h uniform mod q, fp uniform mod p)" if keys_info is None else
+                                      "TRUE key pairs generated on the device"),
                        "kernel_path": args.kernel_path, "seed": 20240, "parallelism": par},
+            "keys": keys_info,
             "kernels_ms": {vname: vms},
             "roofline": hbm_roofline(vname, 17 * N, B, vms, None, "PMC passes: profiles/*_secondary_pmc_hbm.json", 3 * N * N),
         })
@@ -726,8 +804,8 @@ def main():
     # same steps (outside the timed region; also long enough for a coarse external GPU-activity sampler to see the GPU busy)
     power = None
     if args.power_seconds > 0:
-        sampler = PowerSampler(device_sysfs_dir(dev_index)) if rank == 0 else None
-        if sampler: sampler.start()
+        sampler = PowerSampler(device_sysfs_dir(dev_index))      # every rank samples ITS device (reported per rank under `dist`)
+        sampler.start()
         tp0 = time.perf_counter(); n_sus = 0
         while time.perf_counter() - tp0 < args.power_seconds:
             for _ in range(20):
@@ -755,6 +833,26 @@ def main():
                                            "close the step is to what the socket power cap allows for this instruction mix"}
             power["note"] = ("the workload's steps back to back; the matrix-core kernels run against the socket power cap with the shader "
                              "clock pulled below its 2.4 GHz top (profiles/r03_clock_power.txt, r04_rowimage_encrypt.txt)")
+    if dist:
+        # who took part, and how each rank fared: its own seconds for the K steps (up to its own synchronize, before the closing
+        # barrier), its kernels' HIP-event times, socket power and shader clock of ITS device over the sustained phase -- the
+        # metric is a maximum over ranks, so a straggler must be visible by itself
+        me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "pid": os.getpid(),
+              "pci_bus_id": os.path.basename(os.path.realpath(device_sysfs_dir(dev_index) or "?")),
+              "name": torch.cuda.get_device_name(dev_index), "ms_per_step": elapsed_local / args.steps * 1e3,
+              "kernels_ms": dict(zip([names.get(k, k) for k in (("encrypt", "decrypt") if wl == "roundtrip" else
+                                                                 ("encrypt",) if wl == "encrypt_n701" else ("verify_keys",))], seg_ms)),
+              "items_per_step": B,
+              "power": {k: power[k] for k in ("socket_W", "cap_W", "sclk_MHz", "sustained_ms_per_step")} if power else None}
+        everyone, straggler = sh.rank_reports(me, dist, always=args.force_dist)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:                                   # noqa: BLE001 -- reporting only
+            rccl = None
+        dist_info = {"backend": args.dist_backend, "world": world, "rccl_version": rccl if args.dist_backend == "nccl" else None,
+                     "ranks": everyone, "straggler": straggler,
+                     "timing": "barrier + synchronize on both sides of the K steps, all_reduce(MAX) of the ranks' seconds; "
+                               "ranks[].ms_per_step is each rank's own time up to its synchronize"}
     if rank == 0:
         out["power"] = power
         if ablation:       # timing-only build of the engine (tools/ablate.sh): results are NOT checked, not a benchmark line

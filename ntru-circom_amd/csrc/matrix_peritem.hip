@@ -54,19 +54,6 @@ static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 m
   }
 }
 
-static __device__ __forceinline__ int wave_max(int v) {
-  // the lane index is re-materialised here: otherwise the six permute addresses are hoisted out of the item loop and,
-  // at the register limit of three waves per SIMD, spilled to scratch
-  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  asm volatile("" : "+v"(l));
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const int o = __builtin_amdgcn_ds_bpermute((l ^ off) << 2, v);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-
 // ---- chunk rows in REGISTERS (k_verify_keys_m) -----------------------------------------------------------------------------------
 // The A operand of tile distance d is the chunk matrix moved down by d rows: lane (r, hh) holds bytes 16 hh .. 16 hh + 15 of chunk
 // r - d.  Going from d to d + 1 (d >= 0) every lane takes its lower neighbour's 16 bytes and nothing enters at row 0; going from d to
@@ -179,13 +166,23 @@ static __device__ __forceinline__ void pi_build_array_ch(unsigned char *nat, u32
     dk[c] = c <= e ? 0 : -1;                                              // ... which is dword K or K - 1
     sel[c] = 0x00010203u + 0x01010101u * (u32)al;                         // bytes al+3, al+2, al+1, al of the pair (reversed)
   }
-  for (int w = lane; w < g.tpitch; w += 64) {
-    int K = (Y0 + 2 * N - 3 - 4 * w) >> 2;
-    K = K < 1 ? 1 : K;                                                    // pad words of a copy are never read
-    const u32 dm = D[K - 1], d0 = D[K], dp = D[K + 1];
+  // A lane makes FOUR consecutive words of all four copies per trip (one 16-byte store per copy) from six consecutive source dwords:
+  // two trips cover a copy at N = 821 where word-per-lane trips took seven dependent LDS round trips.
+  const int K0 = (Y0 + 2 * N - 3) >> 2;
+  for (int w0 = 4 * lane; w0 < g.tpitch; w0 += 256) {      // tpitch is a multiple of 4 (and a copy's size of 16 bytes)
+    int base = K0 - w0 - 4;                                // words w0 + j need dwords K0 - w0 - j - 1 .. K0 - w0 - j + 1
+    base = base < 0 ? 0 : base;                            // (only pad words of a copy, which are never read, lie that far out)
+    u32 d[6];
 #pragma unroll
-    for (int c = 0; c < 4; c++)
-      T[c * g.tpitch + w] = dk[c] == 0 ? __builtin_amdgcn_perm(dp, d0, sel[c]) : __builtin_amdgcn_perm(d0, dm, sel[c]);
+    for (int i = 0; i < 6; i++) d[i] = D[base + i];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      v4i o;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        o[j] = (int)(dk[c] == 0 ? __builtin_amdgcn_perm(d[5 - j], d[4 - j], sel[c]) : __builtin_amdgcn_perm(d[4 - j], d[3 - j], sel[c]));
+      *(v4i *)(T + c * g.tpitch + w0) = o;
+    }
   }
   wave_lds_fence();
 }
@@ -359,9 +356,15 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
           df |= ((x & 0xFFFFu) ? 1u : 0u) << (2 * c) | ((x >> 16) ? 2u : 0u) << (2 * c);
         }
       }
-      const int top = nz ? i0 + 31 - __builtin_clz(nz) : -1;
-      const int wtop = wave_max(top);
-      const int hl = wtop >= 0 ? wtop + 1 : 1;             // trimmed length of h (1 for the zero polynomial)
+      // trimmed length of h (1 for the zero polynomial): the chunks are in lane order, so the top non-zero coefficient sits in the
+      // highest lane that has one -- found on the scalar side (one ballot, one v_readlane), not by a wave-wide maximum
+      const unsigned long long has = __ballot(nz != 0);
+      int hl = 1;
+      if (has) {
+        const int ltop = 63 - __builtin_clzll(has);
+        const u32 nzt = (u32)__builtin_amdgcn_readlane((int)nz, ltop);
+        hl = 16 * ltop + 32 - __builtin_clz(nzt);
+      }
       const int nv = hl - i0 < 0 ? 0 : (hl - i0 > 16 ? 16 : hl - i0);   // this lane's indices below hl
       if (__ballot((df & ((1u << nv) - 1u)) != 0) != 0) fl |= NTRU_FLAG_INVALID_H;
     }

@@ -32,8 +32,10 @@ def max_over_ranks(seconds, dist=None, device=None, always=False):
     return float(t.item())
 
 
-def timed_region(run_steps, sync, dist=None, device=None, always=False):
-    """barrier + sync, run, sync + barrier; returns max-over-ranks seconds (bench.py contract)."""
+def timed_region(run_steps, sync, dist=None, device=None, always=False, return_local=False):
+    """barrier + sync, run, sync + barrier; returns max-over-ranks seconds (bench.py contract).  return_local: (max over ranks,
+    THIS rank's seconds up to its own sync, before the closing barrier) -- the per-rank figure a scaling record needs to show a
+    straggler (one throttled GPU, a node-level power budget) instead of only its effect on the maximum."""
     multi = _active(dist, always)
     sync()
     if multi:
@@ -42,10 +44,28 @@ def timed_region(run_steps, sync, dist=None, device=None, always=False):
     t0 = time.perf_counter()
     run_steps()
     sync()
+    local = time.perf_counter() - t0
     if multi:
         dist.barrier()
     sync()
-    return max_over_ranks(time.perf_counter() - t0, dist, device, always)
+    worst = max_over_ranks(time.perf_counter() - t0, dist, device, always)
+    return (worst, local) if return_local else worst
+
+
+def rank_reports(me, dist=None, always=False):
+    """Every rank's own record (a dict with at least "rank" and "ms_per_step"), gathered onto every rank and sorted by rank, plus a
+    summary that names the slowest rank: (records, summary).  Without a process group: ([me], summary of one)."""
+    if _active(dist, always):
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, me)
+    else:
+        everyone = [me]
+    everyone = sorted(everyone, key=lambda x: x["rank"])
+    ms = [float(x["ms_per_step"]) for x in everyone]
+    slow = max(range(len(ms)), key=lambda i: ms[i])
+    summary = {"slowest_rank": everyone[slow]["rank"], "ms_per_step_max": ms[slow], "ms_per_step_min": min(ms),
+               "spread": ms[slow] / min(ms) - 1.0 if min(ms) > 0 else None}
+    return everyone, summary
 
 
 def gather_rows(local, dist, always=False, root=0):

@@ -118,6 +118,11 @@ def test_bench_gpus_2_starts_two_ranks_by_itself_and_gathers():
     d = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--batch-log2", "16", "--power-seconds", "0"])   # no --gather: it runs anyway
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["dist"]["backend"] == "gloo" and d["dist"]["world"] == 2 and len(d["dist"]["ranks"]) == 2
+    # every rank reports its own time, kernel times and items: a straggler shows by itself, and the maximum is the line's ms_per_step
+    ranks = d["dist"]["ranks"]
+    assert all(r["ms_per_step"] > 0 and r["items_per_step"] == 1 << 16 and len(r["kernels_ms"]) == 2 for r in ranks)
+    assert max(r["ms_per_step"] for r in ranks) <= d["ms_per_step"] * 1.0001
+    assert d["dist"]["straggler"]["slowest_rank"] in (0, 1) and d["dist"]["straggler"]["ms_per_step_max"] == max(r["ms_per_step"] for r in ranks)
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s" and d["mfma"]["unit"].startswith("TOP/s")
     g = d["gather"]
     assert g["kind"] == "gather_to_root" and g["ranks"] == 2 and g["rows"] == 2 << 16
@@ -138,6 +143,9 @@ def test_bench_workloads_config_4_and_5_have_a_multi_rank_entry():
         assert d["verified_bit_exact_rows"] >= 500
         ranks = d["dist"]["ranks"]
         assert d["dist"]["world"] == 2 and [r["rank"] for r in ranks] == [0, 1] and ranks[0]["pid"] != ranks[1]["pid"]
+        assert all(r["ms_per_step"] > 0 and any(k.startswith(kern) for k in r["kernels_ms"]) for r in ranks)
+        if wl == "verify_keys":                             # config 5 runs on TRUE key pairs generated on the device: every flag valid
+            assert d["keys"]["flags_valid"] == 1 << 14 and d["keys"]["sample_equals_oracle"] and "generated on the device" in d["keys"]["source"]
         g = d["gather"]
         assert g["kind"] == "gather_to_root" and g["ranks"] == 2 and g["rows"] == 2 << 14
         assert g["rows_equal_local_shard"] and g["every_shard_checksum_matches_its_owner"]
@@ -159,3 +167,27 @@ def test_rccl_one_rank_process_group_times_and_gathers():
     assert d["dist"]["backend"] == "nccl" and d["dist"]["rccl_version"] and d["dist"]["ranks"][0]["device"] == 0
     assert d["n_gpus"] == 1 and g["backend"] == "nccl" and g["consumed_on"].startswith("GPU 0")
     assert g["rows_equal_local_shard"] and g["every_shard_checksum_matches_its_owner"]
+
+
+def test_bench_total_batch_is_config_5_as_worded_and_power_is_per_rank():
+    """`--gpus 2 --workload verify_keys --total-batch-log2 15`: the TOTAL is split over the ranks (strong scaling, as BASELINE words
+    config 5: 2^18 keys over 8 GPUs), and with the sustained phase on every rank reports the power and clock of its own device."""
+    d = _run_bench(["--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--workload", "verify_keys", "--total-batch-log2", "15",
+                    "--power-seconds", "1"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["keys"]["key_pairs"] == 1 << 14
+    ranks = d["dist"]["ranks"]
+    assert all(r["items_per_step"] == 1 << 14 for r in ranks)
+    assert all(r["power"] is None or (r["power"]["socket_W"] > 0 and r["power"]["sustained_ms_per_step"] > 0) for r in ranks)
+    assert abs(d["value"] - (1 << 15) / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_exits_non_zero_when_the_process_group_does_not_come_up():
+    """RCCL refuses two ranks on ONE device: bench.py must fail loudly (no fallback to another backend, no result line)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "0", "--steps", "1", "--warmup", "0",
+                           "--no-cpu-baseline", "--batch-log2", "12", "--power-seconds", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          env=env, timeout=300)
+    assert proc.returncode != 0 and not proc.stdout.strip()
+    assert b"did not come up" in proc.stderr or b"Duplicate GPU" in proc.stderr

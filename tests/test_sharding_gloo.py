@@ -41,7 +41,10 @@ def _worker(rank, world, port, q_out):
         m = rng.integers(0, 2, (total, N), dtype=np.uint8)
         lo, hi = sh.shard_range(total, rank, world)
         e_local, _ = orc.encrypt_batch(N, q, h, r[lo:hi], m[lo:hi])
-        elapsed = sh.timed_region(lambda: None, lambda: None, dist, None)
+        import time as _t
+        elapsed, mine = sh.timed_region(lambda: _t.sleep(0.05 * (1 + rank)), lambda: None, dist, None, return_local=True)
+        reports, straggler = sh.rank_reports({"rank": rank, "ms_per_step": mine * 1e3, "kernels_ms": {"k": 1.0 + rank},
+                                              "power": {"socket_W": 100.0 * (1 + rank), "sclk_MHz": 2400.0}}, dist)
         slow = sh.max_over_ranks(1.0 + rank, dist, None)
         local = torch.from_numpy(e_local.astype(np.int32))
         sums = sh.shard_checksums(local, dist)
@@ -49,7 +52,11 @@ def _worker(rank, world, port, q_out):
         if rank == 0:
             e_full, _ = orc.encrypt_batch(N, q, h, r, m)
             per = [int(sh.shard_checksums(allrows[a:b], None)[0]) for a, b in (sh.shard_range(total, k, world) for k in range(world))]
-            q_out.put((bool(np.array_equal(allrows.numpy(), e_full)) and per == sums.tolist(), slow, elapsed >= 0.0, (lo, hi)))
+            per_rank_ok = ([x["rank"] for x in reports] == list(range(world)) and all("kernels_ms" in x and "power" in x for x in reports)
+                           and straggler["slowest_rank"] == world - 1 and straggler["ms_per_step_max"] == reports[-1]["ms_per_step"]
+                           and reports[0]["ms_per_step"] < reports[-1]["ms_per_step"] and elapsed >= mine
+                           and elapsed * 1e3 >= straggler["ms_per_step_max"] and straggler["spread"] > 0.3)
+            q_out.put((bool(np.array_equal(allrows.numpy(), e_full)) and per == sums.tolist() and per_rank_ok, slow, elapsed >= 0.0, (lo, hi)))
         else:
             assert allrows is None
         dist.barrier()
@@ -108,3 +115,21 @@ def test_bench_launcher_runs_the_child_and_returns_its_code(tmp_path, capsys):
     assert bench.spawn_ranks([_sys.executable, str(child), "0"]) == 0
     assert json.loads(capsys.readouterr().out.strip())["n_gpus"] == 2
     assert bench.spawn_ranks([_sys.executable, str(child), "3"]) == 3
+
+
+def test_bench_total_batch_splits_over_the_ranks_and_says_strong_scaling():
+    """BASELINE.json words configs 4 and 5 as a TOTAL over 8 GPUs: --total-batch-log2 turns that into the per-rank batch."""
+    a = bench.parse_args(["--gpus", "8", "--workload", "verify_keys", "--total-batch-log2", "18"])
+    assert a.batch_log2 == 15 and a.total_batch_log2 == 18
+    a = bench.parse_args(["--gpus", "8", "--workload", "encrypt_n701", "--total-batch-log2", "23"])
+    assert a.batch_log2 == 20
+    assert bench.parse_args(["--workload", "verify_keys"]).batch_log2 == 18
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--gpus", "3", "--total-batch-log2", "18"])
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--gpus", "2", "--total-batch-log2", "18", "--batch-log2", "17"])
+
+
+def test_rank_reports_without_a_process_group():
+    reports, s = sh.rank_reports({"rank": 0, "ms_per_step": 2.5})
+    assert reports == [{"rank": 0, "ms_per_step": 2.5}] and s["slowest_rank"] == 0 and s["spread"] == 0.0
