@@ -161,6 +161,13 @@ int ntru_sample_ternary(ntru_engine_t *eng, int N, int n1, int n2, int other, co
                         int64_t B, uint8_t *out);
 int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2, int other, const uint32_t *key,
                             uint64_t first_item, int64_t B, uint8_t *d_out);
+/* Rounds of the sampler's block function: 20 (ChaCha20 as in RFC 8439: the default), 12 or 8 (ChaCha12 / ChaCha8: the same
+ * quarter round, state and output rule, fewer double rounds).  generateCustomArray's contract (index.js:461-488) is the shuffle
+ * order and its `u32 % (i + 1)` draws, not the generator behind crypto.getRandomValues; the sampler kernel is bound by the
+ * vector issue of these rounds, and a host replays whichever variant it asked for.  Applies to ntru_sample_ternary[_dev] and to the
+ * sampler stage of ntru_pipeline_batch of this engine until changed. */
+int ntru_engine_set_sampler_rounds(ntru_engine_t *eng, int rounds);
+int ntru_engine_get_sampler_rounds(ntru_engine_t *eng);
 
 /* ---- encryptBits (index.js:87-110) for B plaintexts under one public key.
  *      h[N] in [0,q); r[B][N] in {0,1,2} (the sampler output with -1 already mapped to p-1, index.js:89);

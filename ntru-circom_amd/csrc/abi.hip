@@ -127,6 +127,7 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
   eng->stream = nullptr;
   eng->cus = prop.multiProcessorCount;
   eng->path = 0;
+  eng->sampler_rounds = 20;
   eng->last_kernel[0] = 0;
   eng->n_occ = 0;
   eng->cur_scratch = &eng->scratch_dev;
@@ -184,6 +185,16 @@ extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   eng->path = path;
   return NTRU_OK;
 }
+
+extern "C" int ntru_engine_set_sampler_rounds(ntru_engine_t *eng, int rounds) {
+  if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");
+  if (rounds != 20 && rounds != 12 && rounds != 8)
+    return fail(NTRU_ERR_ARG, "sampler rounds must be 20 (ChaCha20, RFC 8439: the default), 12 or 8");
+  eng->sampler_rounds = rounds;
+  return NTRU_OK;
+}
+
+extern "C" int ntru_engine_get_sampler_rounds(ntru_engine_t *eng) { return eng ? eng->sampler_rounds : 0; }
 
 extern "C" const char *ntru_engine_last_kernel(ntru_engine_t *eng) {
   if (!eng) return "";

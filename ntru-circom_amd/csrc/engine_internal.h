@@ -63,6 +63,7 @@ struct ntru_engine {
   int path;                 // ntru_engine_set_kernel_path: 0 auto, 1 MAC kernels, 2 add path, 3 add path without dot8, 4 matrix cores as two
                             // workgroups per CU, 5 matrix cores with the lock-step decrypt; 6-9 only in -DNTRU_EXPERIMENTS builds
   int max_blocks_per_cu;    // NTRU_MAX_BLOCKS_PER_CU read once at creation (tuning experiments); 0 = no cap
+  int sampler_rounds;       // ntru_engine_set_sampler_rounds: 20 (RFC 8439, default), 12 or 8 rounds of the sampler's ChaCha block function
   char last_kernel[64];     // name of the kernel the last *_dev call launched (reporting only)
   HostSlot slot[NTRU_HOST_SLOTS];
   hipStream_t st_up, st_comp, st_down;   // the three stage streams of the host path (created at first use)

@@ -80,7 +80,10 @@ static __device__ __forceinline__ u32 sampler_start_word(int w, int n1, int n2) 
   return (0x55555555u & m1) | (0xAAAAAAAAu & m2 & ~m1);
 }
 
-template <bool BIGN, int WAVES>     // BIGN: N + 1 >= 2048, reciprocals from an LDS table behind the rows
+// DR: double rounds of the block function: 10 = ChaCha20 (RFC 8439, the default), 6 = ChaCha12, 4 = ChaCha8 (ntru_engine_set_sampler_rounds:
+// the kernel is bound by the vector issue of these rounds; generateCustomArray's contract is the shuffle and its `u32 % (i + 1)` draws,
+// not the generator behind them, and a host replays whichever variant it asked for).
+template <bool BIGN, int WAVES, int DR>     // BIGN: N + 1 >= 2048, reciprocals from an LDS table behind the rows
 __global__ __launch_bounds__(WAVES * 64) void k_sample_ternary(int N, int n1, int n2, u32 other, ChaChaKey key,
                                                        unsigned long long first_item, long B,
                                                        uint8_t *__restrict__ out, int NW) {
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample_ternary(int N, int n1, in
       u32 x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
       u32 x4 = key.k[0], x5 = key.k[1], x6 = key.k[2], x7 = key.k[3], x8 = key.k[4], x9 = key.k[5], x10 = key.k[6],
           x11 = key.k[7], x12 = ctr, x13 = n0, x14 = nn1, x15 = nn2;
-      for (int r = 0; r < (NTRU_SAMPLER_ABLATE & 1 ? 0 : 10); r++) {
+#pragma unroll
+      for (int r = 0; r < (NTRU_SAMPLER_ABLATE & 1 ? 0 : DR); r++) {
         CHACHA_QR(x0, x4, x8, x12) CHACHA_QR(x1, x5, x9, x13) CHACHA_QR(x2, x6, x10, x14) CHACHA_QR(x3, x7, x11, x15)
         CHACHA_QR(x0, x5, x10, x15) CHACHA_QR(x1, x6, x11, x12) CHACHA_QR(x2, x7, x8, x13) CHACHA_QR(x3, x4, x9, x14)
       }
@@ -790,20 +794,20 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   return NTRU_OK;
 }
 
-template <bool BIGN, int WAVES>
+template <bool BIGN, int WAVES, int DR>
 static int launch_sampler(ntru_engine *eng, int N, int n1, int n2, int other, const ChaChaKey &ck, uint64_t first_item, int64_t B,
                           uint8_t *d_out) {
   const int NW = (N + 15) / 16;                          // dwords of 16 symbols per row
   const size_t lds = WAVES * ((size_t)64 * NW * 4 + (BIGN ? (size_t)((N + 2) & ~1) * 4 : 0));
   if (lds > 160 * 1024) return fail(NTRU_ERR_UNSUPPORTED, "N too large for the sampler's LDS rows");
-  const void *fn = (const void *)k_sample_ternary<BIGN, WAVES>;
+  const void *fn = (const void *)k_sample_ternary<BIGN, WAVES, DR>;
   int per_cu = 0;
   if (int rc = ntru_blocks_per_cu(eng, fn, WAVES * 64, lds, &per_cu)) return rc;
   if (eng->max_blocks_per_cu && eng->max_blocks_per_cu < per_cu) per_cu = eng->max_blocks_per_cu;     // NTRU_MAX_BLOCKS_PER_CU (experiments)
   long blocks = (B + WAVES * 64 - 1) / (WAVES * 64), cap = (long)eng->cus * (per_cu < 1 ? 1 : per_cu);
   if (blocks > cap) blocks = cap;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_sample_ternary");
-  hipLaunchKernelGGL((k_sample_ternary<BIGN, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, eng->stream, N, n1, n2, (u32)other, ck,
+  hipLaunchKernelGGL((k_sample_ternary<BIGN, WAVES, DR>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, eng->stream, N, n1, n2, (u32)other, ck,
                      (unsigned long long)first_item, (long)B, d_out, NW);
   HIP_TRY(hipGetLastError());
   return NTRU_OK;
@@ -821,8 +825,16 @@ extern "C" int ntru_sample_ternary_dev(ntru_engine_t *eng, int N, int n1, int n2
   HIP_TRY(hipSetDevice(eng->device));
   ChaChaKey ck;
   memcpy(ck.k, key, 32);
-  return N + 1 < 2048 ? launch_sampler<false, 4>(eng, N, n1, n2, other, ck, first_item, B, d_out)     // <= 32 KB of rows per wave
-                      : launch_sampler<true, 1>(eng, N, n1, n2, other, ck, first_item, B, d_out);
+  auto go = [&](auto dr) -> int {
+    constexpr int DR = decltype(dr)::value;
+    return N + 1 < 2048 ? launch_sampler<false, 4, DR>(eng, N, n1, n2, other, ck, first_item, B, d_out)     // <= 32 KB of rows per wave
+                        : launch_sampler<true, 1, DR>(eng, N, n1, n2, other, ck, first_item, B, d_out);
+  };
+  switch (eng->sampler_rounds) {
+    case 8: return go(std::integral_constant<int, 4>{});
+    case 12: return go(std::integral_constant<int, 6>{});
+    default: return go(std::integral_constant<int, 10>{});
+  }
 }
 
 extern "C" int ntru_pack_params(int max_val, int data_len, int *bits, int *per_output, int *arr_len, int *output_size) {

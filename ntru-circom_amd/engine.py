@@ -42,6 +42,8 @@ _SIGS = {
 for _sfx in ("", "_dev"):
     _SIGS["ntru_public_key_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp])
     _SIGS["ntru_invert_key_batch" + _sfx] = (C.c_int, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp])
+_SIGS["ntru_engine_set_sampler_rounds"] = (C.c_int, [_vp, _i])
+_SIGS["ntru_engine_get_sampler_rounds"] = (C.c_int, [_vp])
 _SIGS["ntru_sample_ternary"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _SIGS["ntru_sample_ternary_dev"] = (C.c_int, [_vp, _i, _i, _i, _i, _vp, C.c_uint64, _i64, _vp])
 _ip = C.POINTER(C.c_int)
@@ -225,6 +227,13 @@ class Engine:
         out = np.empty((B, S * per), np.uint16)
         self._chk(self._lib.ntru_unpack_batch(self._h, max_val, packed_bits, _ptr(limbs), S, B, _ptr(out)))
         return out
+
+    def set_sampler_rounds(self, rounds):
+        """Rounds of the sampler's ChaCha block function: 20 (RFC 8439, default), 12 or 8."""
+        self._chk(self._lib.ntru_engine_set_sampler_rounds(self._h, int(rounds)))
+
+    def sampler_rounds(self):
+        return int(self._lib.ntru_engine_get_sampler_rounds(self._h))
 
     def sample_ternary(self, N, n1, n2, other, key, first_item, B):
         """generateCustomArray on the device (ChaCha20 draw stream under `key`, 8 uint32)."""

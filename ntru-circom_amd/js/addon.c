@@ -119,6 +119,20 @@ static napi_value Supports(napi_env env, napi_callback_info info) {
   napi_value r; NAPI_OK(napi_get_boolean(env, ntru_engine_supports(N, mod) != 0, &r)); return r;
 }
 
+/* setSamplerRounds(rounds) -> rounds in force: 20 (ChaCha20, RFC 8439: the default), 12 or 8 for the draw stream of sampleTernary /
+ * sampleTernaryDev / pipelineBatch (ntru_engine_set_sampler_rounds); setSamplerRounds(0) only reads the setting. */
+static napi_value SetSamplerRounds(napi_env env, napi_callback_info info) {
+  ARGS(1)
+  int32_t rounds;
+  if (!get_i32(env, argv[0], &rounds)) BAD_ARGS();
+  if (!ensure_engine(env)) return NULL;
+  if (rounds != 0) {
+    int rc = ntru_engine_set_sampler_rounds(g_engine, rounds);
+    if (rc) return throw_engine(env, rc);
+  }
+  napi_value r; NAPI_OK(napi_create_int32(env, ntru_engine_get_sampler_rounds(g_engine), &r)); return r;
+}
+
 /* polymulSplit(N, mod, a:Uint16Array, b:Uint16Array, B, quot:Uint16Array, rem:Uint16Array) */
 static napi_value PolymulSplit(napi_env env, napi_callback_info info) {
   ARGS(7)
@@ -742,6 +756,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     {"destroy", NULL, Destroy, NULL, NULL, NULL, napi_default, NULL},
     {"useDevices", NULL, UseDevices, NULL, NULL, NULL, napi_default, NULL},
     {"supports", NULL, Supports, NULL, NULL, NULL, napi_default, NULL},
+    {"setSamplerRounds", NULL, SetSamplerRounds, NULL, NULL, NULL, napi_default, NULL},
     {"polymulSplit", NULL, PolymulSplit, NULL, NULL, NULL, napi_default, NULL},
     {"splitByI", NULL, SplitByI, NULL, NULL, NULL, napi_default, NULL},
     {"addBatch", NULL, AddBatch, NULL, NULL, NULL, napi_default, NULL},

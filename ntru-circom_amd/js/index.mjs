@@ -436,6 +436,11 @@ export default class NTRU {
 
   // r for B encryptions drawn on the GPU: generateCustomArray(N, dr, dr) with -1 -> p-1 (index.js:89) on the ChaCha20
   // stream of `key` (Uint32Array[8]) for item indices firstItem .. firstItem+B-1; replayable on any host.
+  // NTRU.samplerRounds(rounds): 20 (ChaCha20 as in RFC 8439, the default), 12 or 8 rounds of the block function behind sampleR and the
+  // sampler stage of pipeline(); returns the count in force (no argument: only reads it).  Additive: the reference has no such knob because
+  // its draws come from crypto.getRandomValues; generateCustomArray's shuffle and `u32 % (i + 1)` reduction are unchanged.
+  static samplerRounds(rounds = 0) { return engine().setSamplerRounds(rounds); }
+
   sampleR(key, firstItem, B) {
     const r = new Uint8Array(B * this.N);
     engine().sampleTernary(this.N, this.dr, this.dr, this.p - 1, key, firstItem, B, r);

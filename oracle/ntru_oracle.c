@@ -411,40 +411,50 @@ static inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 -
   a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); \
   a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7);
 
-void orc_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]) {
+/* rounds: 20 (RFC 8439), 12 or 8 -- the engine's ntru_engine_set_sampler_rounds; rounds / 2 double rounds */
+void orc_chacha_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], int rounds, uint32_t out[16]) {
   uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
                     key[4], key[5], key[6], key[7], counter, nonce[0], nonce[1], nonce[2]};
   uint32_t x[16];
   for (int i = 0; i < 16; i++) x[i] = s[i];
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < rounds / 2; r++) {
     QR(x[0], x[4], x[8], x[12]) QR(x[1], x[5], x[9], x[13]) QR(x[2], x[6], x[10], x[14]) QR(x[3], x[7], x[11], x[15])
     QR(x[0], x[5], x[10], x[15]) QR(x[1], x[6], x[11], x[12]) QR(x[2], x[7], x[8], x[13]) QR(x[3], x[4], x[9], x[14])
   }
   for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
+void orc_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]) {
+  orc_chacha_block(key, counter, nonce, 20, out);
+}
 
 /* draws[t], t = 0..n-1, of item `item` */
-void orc_draw_stream(const uint32_t key[8], uint64_t item, int n, uint32_t *draws) {
+void orc_draw_stream_rounds(const uint32_t key[8], uint64_t item, int n, int rounds, uint32_t *draws) {
   uint32_t nonce[3] = {(uint32_t)item, (uint32_t)(item >> 32), 0x4e545255u}, blk[16];
   for (int t = 0; t < n; t++) {
-    if ((t & 15) == 0) orc_chacha20_block(key, (uint32_t)(t >> 4), nonce, blk);
+    if ((t & 15) == 0) orc_chacha_block(key, (uint32_t)(t >> 4), nonce, rounds, blk);
     draws[t] = blk[t & 15];
   }
 }
+void orc_draw_stream(const uint32_t key[8], uint64_t item, int n, uint32_t *draws) { orc_draw_stream_rounds(key, item, n, 20, draws); }
 
 /* r rows for items first_item .. first_item+B-1: n1 ones, n2 entries equal to `other`, zeros; stride N. */
-int orc_sample_ternary_batch(int N, int n1, int n2, int other, const uint32_t key[8], uint64_t first_item, int64_t B,
-                             uint8_t *out) {
+int orc_sample_ternary_batch_rounds(int N, int n1, int n2, int other, const uint32_t key[8], uint64_t first_item, int64_t B,
+                                    int rounds, uint8_t *out) {
   if (n1 + n2 > N) return ORC_ERR_SAMPLER;
+  if (rounds != 20 && rounds != 12 && rounds != 8) return ORC_ERR_ARG;
   uint32_t *draws = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(N > 1 ? N - 1 : 1));
   int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
   for (int64_t b = 0; b < B; b++) {
-    orc_draw_stream(key, first_item + (uint64_t)b, N - 1, draws);
+    orc_draw_stream_rounds(key, first_item + (uint64_t)b, N - 1, rounds, draws);
     orc_generate_custom_array(N, n1, n2, draws, tmp);
     for (int k = 0; k < N; k++) out[b * N + k] = (uint8_t)(tmp[k] == -1 ? other : tmp[k]);
   }
   free(draws); free(tmp);
   return ORC_OK;
+}
+int orc_sample_ternary_batch(int N, int n1, int n2, int other, const uint32_t key[8], uint64_t first_item, int64_t B,
+                             uint8_t *out) {
+  return orc_sample_ternary_batch_rounds(N, n1, n2, other, key, first_item, B, 20, out);
 }
 
 /* ---- BN254 field-element packing, index.js:572-620 -------------------------------------------

@@ -227,10 +227,11 @@ def public_key_batch(N, q, p, fq, g, mode=EXACT):
     return rem
 
 
-def chacha20_block(key, counter, nonce):
+def chacha20_block(key, counter, nonce, rounds=20):
+    """The ChaCha block function: rounds = 20 is RFC 8439's; 12 and 8 are the reduced variants ntru_engine_set_sampler_rounds offers."""
     key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32)); nonce = np.ascontiguousarray(np.asarray(nonce, dtype=np.uint32))
     out = np.zeros(16, np.uint32)
-    lib().orc_chacha20_block(_p(key), C.c_uint32(counter), _p(nonce), _p(out))
+    lib().orc_chacha_block(_p(key), C.c_uint32(counter), _p(nonce), C.c_int(rounds), _p(out))
     return out
 
 
@@ -241,11 +242,11 @@ def draw_stream(key, item, n):
     return out[:n]
 
 
-def sample_ternary_batch(N, n1, n2, other, key, first_item, B):
+def sample_ternary_batch(N, n1, n2, other, key, first_item, B, rounds=20):
     key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32))
     out = np.zeros((B, N), np.uint8)
-    _check(lib().orc_sample_ternary_batch(C.c_int(N), C.c_int(n1), C.c_int(n2), C.c_int(other), _p(key),
-                                          C.c_uint64(first_item), C.c_int64(B), _p(out)))
+    _check(lib().orc_sample_ternary_batch_rounds(C.c_int(N), C.c_int(n1), C.c_int(n2), C.c_int(other), _p(key),
+                                                 C.c_uint64(first_item), C.c_int64(B), C.c_int(rounds), _p(out)))
     return out
 
 

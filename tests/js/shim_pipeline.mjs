@@ -16,6 +16,8 @@ const key = g.keys[0];
 const ntru = new NTRU({ ...g.options, f: key.f, fp: key.fp, fq: key.fq, g: key.g, h: key.h });
 const { N, p, q } = ntru;
 const chacha = Uint32Array.from([11, 22, 33, 44, 55, 66, 77, 88]);
+// NTRU_SAMPLER_ROUNDS=12|8: the reduced-round draw streams (NTRU.samplerRounds); default ChaCha20
+const rounds = NTRU.samplerRounds(Number(process.env.NTRU_SAMPLER_ROUNDS || 0));
 const firstItem = 4294967296 + 5;                      // item indices above 2^32: both nonce words matter
 const m = new Uint8Array(B * N);
 for (let i = 0; i < m.length; i++) m[i] = (Math.imul(i, 2654435761) >>> 9) & 1;
@@ -63,7 +65,7 @@ const viaPromise = await ntru.pipelineAsync({ m, B, sampleR: { key: chacha, firs
 clearInterval(timer);
 for (let i = 0; i < viaPromise.value.length; i++) if (viaPromise.value[i] !== all.value[i]) throw new Error('pipelineAsync: value differs at ' + i);
 for (let i = 0; i < viaPromise.packed.length; i++) if (viaPromise.packed[i] !== all.packed[i]) throw new Error('pipelineAsync: packed differs at ' + i);
-writeFileSync(join(outDir, 'meta.json'), JSON.stringify({ N, q, p, dr: ntru.dr, B, outputSizeValue: os, outputSizeE: enc.outputSize,
+writeFileSync(join(outDir, 'meta.json'), JSON.stringify({ N, q, p, dr: ntru.dr, B, samplerRounds: rounds, outputSizeValue: os, outputSizeE: enc.outputSize,
   key: Array.from(chacha), firstItem }));
 console.log('shim_pipeline: OK', profile, B);
 })().catch(e => { console.error(e); process.exit(1); });

@@ -840,16 +840,28 @@ def test_split_and_add_kernels(eng):
 
 @pytest.mark.parametrize("N,n1,n2", [(821, 273, 273), (701, 233, 233), (509, 169, 169), (167, 18, 18), (17, 2, 2),
                                      (17, 17, 0), (5, 0, 0), (2, 1, 1), (1000, 1, 998)])
-def test_device_sampler_equals_oracle(eng, N, n1, n2):
-    """generateCustomArray on the device: same Fisher-Yates procedure on the same (ChaCha20) draw stream."""
+@pytest.mark.parametrize("rounds", [20, 12, 8])
+def test_device_sampler_equals_oracle(eng, N, n1, n2, rounds):
+    """generateCustomArray on the device: same Fisher-Yates procedure on the same draw stream -- ChaCha20 (RFC 8439, the default) or
+    the reduced-round variants ntru_engine_set_sampler_rounds offers (12, 8): the oracle replays whichever the caller asked for."""
     key = (np.arange(8, dtype=np.uint64) * 0x9E3779B9 + 12345).astype(np.uint32)
-    for first, B in ((0, 1), (7, 64), (2 ** 33 + 5, 65), (123456, 200)):
-        got = eng.sample_ternary(N, n1, n2, 2, key, first, B)
-        want = orc.sample_ternary_batch(N, n1, n2, 2, key, first, B)
-        assert np.array_equal(got, want), (first, B)
-        assert ((got == 1).sum(axis=1) == n1).all() and ((got == 2).sum(axis=1) == n2).all()
-    with pytest.raises(pkg.EngineError, match="cannot exceed the array length"):
-        eng.sample_ternary(4, 3, 2, 2, key, 0, 1)
+    assert eng.sampler_rounds() == 20                               # the default is RFC 8439's
+    eng.set_sampler_rounds(rounds)
+    try:
+        assert eng.sampler_rounds() == rounds
+        for first, B in ((0, 1), (7, 64), (2 ** 33 + 5, 65), (123456, 200)):
+            got = eng.sample_ternary(N, n1, n2, 2, key, first, B)
+            want = orc.sample_ternary_batch(N, n1, n2, 2, key, first, B, rounds=rounds)
+            assert np.array_equal(got, want), (first, B)
+            assert ((got == 1).sum(axis=1) == n1).all() and ((got == 2).sum(axis=1) == n2).all()
+            if rounds != 20 and N > 2 and n1 + n2 not in (0, N) and B > 1:    # and it is NOT the 20-round stream
+                assert not np.array_equal(got, orc.sample_ternary_batch(N, n1, n2, 2, key, first, B))
+        with pytest.raises(pkg.EngineError, match="cannot exceed the array length"):
+            eng.sample_ternary(4, 3, 2, 2, key, 0, 1)
+        with pytest.raises(pkg.EngineError, match="sampler rounds must be"):
+            eng.set_sampler_rounds(10)
+    finally:
+        eng.set_sampler_rounds(20)
 
 
 @pytest.mark.parametrize("N", [16, 17, 31, 33, 100, 821, 2046, 2047, 2100])

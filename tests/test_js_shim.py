@@ -75,8 +75,8 @@ def test_generic_exports_reproduce_reference():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(NODE is None, reason="node is not installed")
-@pytest.mark.parametrize("profile,B", [("n167_q128", 9001), ("n821_q4096", 2050)])
-def test_device_resident_pipeline_through_the_shim_equals_oracle_replay(profile, B, tmp_path):
+@pytest.mark.parametrize("profile,B,rounds", [("n167_q128", 9001, 20), ("n821_q4096", 2050, 20), ("n821_q4096", 300, 12)])
+def test_device_resident_pipeline_through_the_shim_equals_oracle_replay(profile, B, rounds, tmp_path):
     """ntru.pipeline({sampleR, decrypt, pack}) keeps r, e and value on the GPU between the stages (index.js:461-488 -> :87-110 ->
     :111-140 -> :572-596); the CPU oracle replays the ChaCha20 draw stream and every stage from m alone.  B = 9001 runs as four
     chunks through the three-stage pipeline; the script also composes the stages by hand on device-buffer handles."""
@@ -85,16 +85,18 @@ def test_device_resident_pipeline_through_the_shim_equals_oracle_replay(profile,
     from oracle import ntru_oracle as orc
     from conftest import load_golden
     ge.build()
-    r = _node([os.path.join(ge.ROOT, "tests", "js", "shim_pipeline.mjs"), profile, str(B), str(tmp_path)])
+    r = _node([os.path.join(ge.ROOT, "tests", "js", "shim_pipeline.mjs"), profile, str(B), str(tmp_path)],
+              env=dict(os.environ, NTRU_SAMPLER_ROUNDS=str(rounds)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     meta = json.load(open(tmp_path / "meta.json"))
+    assert meta["samplerRounds"] == rounds                  # NTRU.samplerRounds: ChaCha20 by default, 12 / 8 on request
     N, q, p, dr = meta["N"], meta["q"], meta["p"], meta["dr"]
     rd = lambda name, dt: np.fromfile(tmp_path / (name + ".bin"), dtype=dt)
     m = rd("m", np.uint8).reshape(B, N)
     key = load_golden("scheme_%s.json" % profile)["keys"][0]
     pad = lambda a, dt: np.array(list(a) + [0] * (N - len(a)), dtype=dt)
     h, f, fp = pad(key["h"], np.uint16), pad(key["f"], np.int8), pad(key["fp"], np.uint8)
-    r_o = orc.sample_ternary_batch(N, dr, dr, p - 1, np.array(meta["key"], np.uint32), meta["firstItem"], B)
+    r_o = orc.sample_ternary_batch(N, dr, dr, p - 1, np.array(meta["key"], np.uint32), meta["firstItem"], B, rounds=rounds)
     assert np.array_equal(rd("r", np.uint8).reshape(B, N), r_o)
     e_o, _ = orc.encrypt_batch(N, q, h, r_o, m)
     assert np.array_equal(rd("e", np.uint16).reshape(B, N), e_o)

@@ -167,6 +167,24 @@ def test_chacha20_block_rfc8439_vector():
     assert out.tolist() == want
 
 
+def test_chacha_reduced_round_variants_published_vectors():
+    """The all-zero key / nonce / counter keystream block of ChaCha20, ChaCha12 and ChaCha8 (Bernstein's reference vectors, as listed in
+    draft-strombergson-chacha-test-vectors TC1, 256-bit key; with everything zero the RFC 8439 state layout coincides with the original):
+    the round counts ntru_engine_set_sampler_rounds offers are the established variants, not something home-made."""
+    z = np.zeros(8, np.uint32)
+    want = {20: "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586",
+            12: "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be",
+            8: "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42"}
+    for rounds, hexs in want.items():
+        assert orc.chacha20_block(z, 0, [0, 0, 0], rounds).astype("<u4").tobytes().hex() == hexs, rounds
+    key = np.arange(8, dtype=np.uint32) * 0x01010101
+    r20 = orc.sample_ternary_batch(167, 18, 18, 2, key, 3, 4)
+    for rounds in (12, 8):
+        r = orc.sample_ternary_batch(167, 18, 18, 2, key, 3, 4, rounds=rounds)
+        assert not np.array_equal(r, r20) and ((r == 1).sum(1) == 18).all() and ((r == 2).sum(1) == 18).all()
+    assert np.array_equal(orc.sample_ternary_batch(167, 18, 18, 2, key, 3, 4, rounds=20), r20)
+
+
 def test_sampler_stream_and_procedure(pure_golden):
     key = np.arange(8, dtype=np.uint32) * 0x01010101
     d = orc.draw_stream(key, 5, 40)

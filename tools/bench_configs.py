@@ -95,13 +95,17 @@ def sampler_config(profile, logB):
     B = 1 << logB
     r = torch.empty((B, N), dtype=torch.uint8, device=dev)
     key = np.arange(8, dtype=np.uint32) + 1
-    ms = timed(lambda: eng.sample_ternary_dev(N, d, d, p - 1, key, 0, B, r.data_ptr()))
-    first = orc.sample_ternary_batch(N, d, d, p - 1, key, 0, 8)
-    last = orc.sample_ternary_batch(N, d, d, p - 1, key, B - 8, 8)
-    ok = bool(np.array_equal(r[:8].cpu().numpy(), first) and np.array_equal(r[B - 8:].cpu().numpy(), last))
+    per_rounds, ok = {}, True
+    for rounds in (8, 12, 20):                               # ntru_engine_set_sampler_rounds: ChaCha8 / ChaCha12 / ChaCha20 (default, last)
+        eng.set_sampler_rounds(rounds)
+        ms = timed(lambda: eng.sample_ternary_dev(N, d, d, p - 1, key, 0, B, r.data_ptr()))
+        first = orc.sample_ternary_batch(N, d, d, p - 1, key, 0, 8, rounds=rounds)
+        last = orc.sample_ternary_batch(N, d, d, p - 1, key, B - 8, 8, rounds=rounds)
+        ok = ok and bool(np.array_equal(r[:8].cpu().numpy(), first) and np.array_equal(r[B - 8:].cpu().numpy(), last))
+        per_rounds[str(rounds)] = {"ms": ms, "samples_per_s": B / (ms * 1e-3)}
     return {"config": "N=%d d=%d batch=2^%d on-device generateCustomArray (ChaCha20 draws), 1 GPU" % (N, d, logB),
             "kernel": eng.last_kernel(), "ms": ms, "samples_per_s": B / (ms * 1e-3), "hbm_GBps": N * B / (ms * 1e-3) / 1e9,
-            "rows_equal_oracle": ok, "rows_checked": 16}
+            "per_chacha_rounds": per_rounds, "rows_equal_oracle": ok, "rows_checked": 48}
 
 
 def keygen_config(profile, logB):
@@ -197,24 +201,35 @@ def pipeline_dev_config(profile, logB, log_chunk=17):
         t1 = time.perf_counter()
         pw = sampler.summary(t0, t1) or {}
         return (t1 - t0) / n * 1e3, pw.get("socket_W"), pw.get("sclk_MHz")
+    rows = torch.tensor([0, 1, C - 1], device=dev)
+    k = nch - 1
+
+    def replay(rounds):                                      # oracle replay of a few rows of the last chunk: the stream position is the item index
+        r_o = orc.sample_ternary_batch(N, d, d, p - 1, key, k * C + C - 8, 8, rounds=rounds)
+        r_o = np.concatenate([orc.sample_ternary_batch(N, d, d, p - 1, key, k * C, 2, rounds=rounds), r_o[-1:]])
+        e_o, _ = orc.encrypt_batch(N, q, h_np, r_o, host(m[k * C:(k + 1) * C], rows))
+        v_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)[0]
+        return bool(np.array_equal(host(value[k * C:(k + 1) * C], rows), v_o))
+    reduced, ok = {}, True
+    for rounds in (8, 12):                                   # the serial pipeline at the reduced round counts of the sampler
+        eng.set_sampler_rounds(rounds)
+        ms_r, w_r, f_r = wall(serial)
+        ok = ok and replay(rounds)
+        reduced[str(rounds)] = {"ms": ms_r, "round_trips_per_s": B / (ms_r * 1e-3), "socket_W": w_r, "sclk_MHz": f_r}
+    eng.set_sampler_rounds(20)
     ms_s, w_s, f_s = wall(serial)
     v_serial = value.clone()
     ms_o, w_o, f_o = wall(overlapped)
     same = bool(torch.equal(v_serial, value))
     eng.set_stream(stream.cuda_stream)
-    # oracle replay of a few rows of the last chunk: the sampler's stream position is the item index
-    rows = torch.tensor([0, 1, C - 1], device=dev)
-    k = nch - 1
-    r_o = orc.sample_ternary_batch(N, d, d, p - 1, key, k * C, C)[rows.cpu().numpy()]
-    e_o, _ = orc.encrypt_batch(N, q, h_np, r_o, host(m[k * C:(k + 1) * C], rows))
-    v_o = orc.decrypt_batch(N, q, p, f_np, fp_np, e_o)[0]
-    ok = bool(np.array_equal(host(value[k * C:(k + 1) * C], rows), v_o))
+    ok = ok and replay(20)
     return {"config": "N=%d q=%d batch=2^%d device-resident sampled round trip (sampler -> encryptBits -> decryptBits, value only), "
                       "chunks of 2^%d, 1 GPU" % (N, q, logB, log_chunk),
             "serial": {"ms": ms_s, "round_trips_per_s": B / (ms_s * 1e-3), "socket_W": w_s, "sclk_MHz": f_s},
             "sampler_on_second_stream": {"ms": ms_o, "round_trips_per_s": B / (ms_o * 1e-3), "socket_W": w_o, "sclk_MHz": f_o,
                                          "values_equal_serial": same},
-            "rows_equal_oracle": ok, "rows_checked": 3}
+            "serial_at_reduced_sampler_rounds": reduced,
+            "rows_equal_oracle": ok, "rows_checked": 9}
 
 
 def decrypt_pack_config(profile, logB):
