@@ -146,7 +146,7 @@ def keygen_config(profile, logB):
             "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
 
 
-def pipeline_dev_config(profile, logB, log_chunk=17):
+def pipeline_dev_config(profile, logB, log_chunk=19):
     """Device-resident sampled round trip (no PCIe): generateCustomArray -> encryptBits -> decryptBits (value only), chunk by
     chunk; m and every result stay in HBM.  "serial": the three kernels of a chunk one after the other on ONE stream (what
     ntru_pipeline_batch enqueues on its compute stream); "overlapped": the sampler of chunk k+1 on a SECOND stream next to the
@@ -334,11 +334,12 @@ if __name__ == "__main__":
                ("polymul", lambda: polymul_config(821, 4096, 18)), ("sampler", lambda: sampler_config("n821_q4096", 20)),
                ("add", lambda: add_config(821, 4096, 20)), ("decrypt_pack", lambda: decrypt_pack_config("n821_q4096", 20)),
                ("encrypt_pack", lambda: encrypt_pack_config("n821_q4096", 20)),
-               ("pipeline", lambda: pipeline_dev_config("n821_q4096", 20))]      # (uses its own streams: kept out of the rocprofv3 passes)
+               ("pipeline", lambda: pipeline_dev_config("n821_q4096", 20)),
+               ("pipeline20", lambda: pipeline_dev_config("n821_q4096", 20, 20)), ("pipeline17", lambda: pipeline_dev_config("n821_q4096", 20, 17))]      # (uses its own streams: kept out of the rocprofv3 passes)
     only = None
     if "--only" in sys.argv:
         only = sys.argv[sys.argv.index("--only") + 1].split(",")
     for name, fn in configs:
-        if (only is not None and name not in only) or (only is None and name == "pipeline" and "--no-pipeline" in sys.argv):
+        if (only is not None and name not in only) or (only is None and name.startswith("pipeline") and (name != "pipeline" or "--no-pipeline" in sys.argv)):
             continue
         print(json.dumps(fn()), flush=True)

@@ -66,7 +66,9 @@ if (pinned.checksum !== pageable.checksum) throw new Error('pinned and pageable 
 function pipelineRate(opts, bytesUp, bytesDown) {
   const mPin = NTRU.allocUint8(B * N); mPin.set(mSrc);
   const out = {};
-  if (!opts.pack) out.value = NTRU.allocUint8(B * N);
+  const decrypt = opts.decrypt !== false;
+  if (!opts.pack && decrypt) out.value = NTRU.allocUint8(B * N);
+  if (!opts.pack && !decrypt) out.e = NTRU.allocUint16(B * N);
   const chacha = Uint32Array.from([1, 2, 3, 4, 5, 6, 7, 8]);
   const run = () => ntru.pipeline({ m: mPin, B, sampleR: { key: chacha, firstItem: 0 }, decrypt: true, out, ...opts });
   let res = run();
@@ -77,10 +79,14 @@ function pipelineRate(opts, bytesUp, bytesDown) {
   const up = bytesUp * B / (ms * 1e-3) / 1e9, down = bytesDown * B / (ms * 1e-3) / 1e9;
   return { ms_per_batch: ms, round_trips_per_s: B / (ms * 1e-3), pcie_bytes_up_per_round_trip: bytesUp, pcie_bytes_down_per_round_trip: bytesDown,
     up_GBs: up, down_GBs: down, frac_of_pcie_one_direction: Math.max(up, down) / PCIE_GBS,
-    checksum: opts.pack ? Number(res.packed[res.packed.length - 4] & 0xffffn) : res.value.reduce((s, x) => (s + x) >>> 0, 0) };
+    checksum: opts.pack ? Number(res.packed[res.packed.length - 4] & 0xffffn) : (decrypt ? res.value : res.e).reduce((s, x) => (s + x) >>> 0, 0) };
 }
 const pipeValue = pipelineRate({}, N, N);
 const pipePacked = pipelineRate({ pack: true }, N, 32 * Math.max(3, Math.ceil(N / Math.floor(252 / 2))));
+// encrypt only: the ciphertext comes down plain (2N bytes) or as packOutput(q - 1, N, e) from the fused encrypt + pack kernel
+const qBits = Math.floor(Math.log2(ntru.q - 1)) + 1;
+const encPlain = pipelineRate({ decrypt: false }, N, 2 * N);
+const encPacked = pipelineRate({ decrypt: false, pack: true }, N, 32 * Math.max(3, Math.ceil(N / Math.floor(252 / qBits))));
 
 // single calls through the reference's own API (plain Arrays in, witness objects out)
 const lat = (fn, n) => { const t = []; for (let i = 0; i < n; i++) { const t0 = now(); fn(); t.push(now() - t0); } t.sort((a, b) => a - b); return { median_ms: t[n >> 1], p90_ms: t[Math.floor(n * 0.9)], min_ms: t[0] }; };
@@ -97,7 +103,9 @@ console.log(JSON.stringify({
   pinned, pageable,
   pipeline_value_only: { what: 'ntru.pipeline({sampleR, decrypt}): sampler -> encryptBits -> decryptBits on the GPU, m up, value down (page-locked arrays)',
     bound_round_trips_per_s_at_N_each_way: PCIE_GBS * 1e9 / N, ...pipeValue },
-  pipeline_packed_value: { what: 'the same with pack: true: packOutput(2, N, value) comes down instead of value', ...pipePacked },
+  pipeline_packed_value: { what: 'the same with pack: true: packOutput(2, N, value) comes down instead of value (decrypt + pack fused: k_decrypt_mp)', ...pipePacked },
+  pipeline_encrypt_plain: { what: 'ntru.pipeline({sampleR, decrypt: false}): sampler -> encryptBits, m up, e (2N bytes) down', ...encPlain },
+  pipeline_encrypt_packed: { what: 'the same with pack: true: packOutput(q - 1, N, e) comes down instead of e (encrypt + pack fused: k_encrypt_wp)', ...encPacked },
   single_call_latency: { encryptBits: encLat, decryptBits: decLat, verifyKeysInputs: verLat,
     note: 'includes sampling r in JS (N-1 CSPRNG draws), Array <-> TypedArray conversion, one H2D, one launch, one D2H' },
 }));

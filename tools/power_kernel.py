@@ -1,5 +1,7 @@
 # Socket power / shader clock while ONE kernel runs back to back for a few seconds (hwmon sampling as in bench.py):
 #   python tools/power_kernel.py encrypt|decrypt|verify PATH [PATH ...]
+#   python tools/power_kernel.py decrypt-operands 0      the UNCHANGED decrypt kernel on operands of different entropy: which operand carries the
+#                                                        energy a matrix instruction costs above its bare price (results are not checked here)
 import importlib, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import bench
@@ -32,7 +34,23 @@ def call():
         eng.encrypt_batch_dev(N, q, h.data_ptr(), r.data_ptr(), m.data_ptr(), B, e2.data_ptr(), qe.data_ptr())
     else:
         eng.decrypt_batch_dev(N, q, p, f.data_ptr(), fp.data_ptr(), e.data_ptr(), B, v.data_ptr(), q1.data_ptr(), r1.data_ptr(), q2.data_ptr())
-for path in [int(x) for x in sys.argv[2:]]:
+variants = [("as measured", None)]
+if what == 'decrypt-operands':
+    what = 'decrypt'
+    rnd = e.clone()
+    fz = torch.zeros_like(f); fone = torch.ones_like(f)
+    variants = [("e uniform mod q, golden f (the benchmark's operands)", lambda: (e.copy_(rnd), None)),
+                ("e = 0 (both digit planes constant zero)", lambda: (e.zero_(), None)),
+                ("e = 1365 everywhere (constant non-zero digits)", lambda: (e.fill_(1365), None)),
+                ("e < 128 (high digit plane zero, low plane random)", lambda: (e.copy_(rnd & 127), None)),
+                ("e = 128 * (e >> 7) (low digit plane zero, high plane random)", lambda: (e.copy_(rnd & ~127), None)),
+                ("e uniform, f = 0 (Toeplitz fragments all zero)", lambda: (e.copy_(rnd), f.copy_(fz))),
+                ("e uniform, f = 1 everywhere (fragments constant)", lambda: (e.copy_(rnd), f.copy_(fone)))]
+    f_saved = f.clone()
+for label, prep in variants:
+  if prep:
+    f.copy_(f_saved); prep(); torch.cuda.synchronize(); print('--', label, flush=True)
+  for path in [int(x) for x in sys.argv[2:]]:
     eng.set_kernel_path(path)
     for _ in range(3): call()
     torch.cuda.synchronize()
