@@ -125,7 +125,7 @@ def pick_result_line(text):
                 d = json.loads(line)
             except ValueError:
                 continue
-            if isinstance(d, dict) and ("metric" in d or "ABLATION_NOT_A_RESULT" in d):
+            if isinstance(d, dict) and "metric" in d:
                 return line
     return None
 
@@ -397,8 +397,6 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    if os.environ.get("NTRU_BENCH_ABLATION") == "1":
-        os.environ["NTRU_ALLOW_TIMING_ONLY"] = "1"  # tools/ablate.sh: the library under test is a timing-only build and says so
     import torch
     import __graft_entry__ as ge
     pkg = ge.load_package()
@@ -607,8 +605,7 @@ def main():
     if sum(done) != len(ins[0]) and not bad:
         bad.append("only %d of %d rows were compared" % (sum(done), len(ins[0])))
     ok = not bad
-    ablation = bool(os.environ.get("NTRU_ENGINE_LIB")) and os.environ.get("NTRU_BENCH_ABLATION") == "1"
-    if not ok and not ablation:
+    if not ok:
         raise SystemExit("bench: GPU results differ from the oracle (%s) -- refusing to report a number" % sorted(set(bad)))
 
     # ---- multi-rank evidence: who took part, and the final gather-to-root (outside the timed region) --------------------------
@@ -733,7 +730,7 @@ def main():
             names["encrypt"], names["decrypt"] = list(out["kernels_ms"])
             eng.set_kernel_path(0)
             del ref_out
-        if world == 1 and args.kernel_path == "auto" and not ablation:
+        if world == 1 and args.kernel_path == "auto":
             # The other function of the path with per-item operands, verifyKeysInputs (index.js:141-197, BASELINE config 5),
             # outside the timed region: 2^18 TRUE key pairs generated on the device (config 5's size), kernel time of 10 launches,
             # a sample of the keys and of every witness array against the oracle (`--workload verify_keys` is the same thing as a
@@ -761,7 +758,7 @@ def main():
             kgot = [khost(t) for t in kouts] + [kflags[krows].cpu().numpy()]
             witness_ok = all(np.array_equal(a, b) for a, b in zip(kgot, kwant.values()))
             kinfo.update(sample_equals_oracle=keys_ok, flags_valid=int((kflags == 0).sum()))
-            if not (keys_ok and witness_ok and kinfo["flags_valid"] == Bk) and not ablation:
+            if not (keys_ok and witness_ok and kinfo["flags_valid"] == Bk):
                 raise SystemExit("bench: verify_keys leg differs from the oracle (keys %s, witness %s, %d of %d valid)"
                                  % (keys_ok, witness_ok, kinfo["flags_valid"], Bk))
             out["verify_keys"] = {"value": Bk / (vms * 1e-3), "unit": "key_pairs/s", "kernel": eng.last_kernel(), "ms": vms,
@@ -857,9 +854,6 @@ def main():
                                "ranks[].ms_per_step is each rank's own time up to its synchronize"}
     if rank == 0:
         out["power"] = power
-        if ablation:       # timing-only build of the engine (tools/ablate.sh): results are NOT checked, not a benchmark line
-            out = {"ABLATION_NOT_A_RESULT": os.environ["NTRU_ENGINE_LIB"], "results_match_oracle": bool(ok),
-                   "kernels_ms": out["kernels_ms"], "ms_per_step": out["ms_per_step"]}
         if dist_info:
             out["dist"] = dist_info
         if gathered:

@@ -66,10 +66,6 @@ typedef struct ntru_engine ntru_engine_t;
 
 /* Number of HIP devices visible to the process (0 if none / runtime unusable). */
 int ntru_engine_device_count(void);
-/* 1 when this library is a TIMING-ONLY build (-DNTRU_ABLATE / -DRI_ABL: kernels with parts compiled out, wrong values on purpose;
- * tools/ablate.sh).  ntru_engine_create refuses such a build unless NTRU_ALLOW_TIMING_ONLY=1 is in the environment, and
- * ntru_engine_last_kernel prefixes every name with "TIMING-ONLY ".  0 for every library that is shipped. */
-int ntru_engine_is_timing_only_build(void);
 
 /* Create an engine bound to HIP device `device`.  Work is enqueued on the NULL stream until
  * ntru_engine_set_stream is called. */
@@ -312,8 +308,10 @@ int ntru_pack_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uin
 int ntru_pack_bytes_batch_dev(ntru_engine_t *eng, int max_val, int data_len, const uint8_t *d_data, int64_t B, uint64_t *d_out);
 /* decryptBits (index.js:111-140) + packOutput(p - 1, N, value) (index.js:572-596) of its result, value-only mode, device pointers:
  * d_packed [B][output_size][4] (sizes from ntru_pack_params(p - 1, N, ...)).  Where the matrix-core decrypt applies (shared key, p == 3,
- * q <= 8192, N <= 1024, d_packed 16-byte aligned) this is ONE kernel -- the field elements come straight out of the second product's
- * epilogue and d_value may be NULL (nothing but the packed rows is written); elsewhere it is decrypt + pack and d_value is needed. */
+ * q <= 8192, N <= 1024, d_packed 16-byte aligned) AND the kernel's 2-bit image of the values fits behind its mod-p tables in the LDS
+ * (it does from N of about 100 up; every BASELINE size) this is ONE kernel -- the field elements come straight out of the second
+ * product's epilogue and d_value may be NULL (nothing but the packed rows is written); elsewhere it is decrypt + pack, d_value is
+ * needed as the intermediate and a NULL d_value is NTRU_ERR_ARG. */
 int ntru_decrypt_pack_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t *d_f, const uint8_t *d_fp,
                                 const uint16_t *d_e, int64_t B, uint8_t *d_value, uint64_t *d_packed);
 /* encryptBits (index.js:87-110) + packOutput(q - 1, N, e) (index.js:572-596) of its result, device pointers: d_packed

@@ -93,17 +93,6 @@ extern "C" int ntru_engine_device_count(void) {
 
 extern "C" const char *ntru_last_error(void) { return g_err.c_str(); }
 
-// A library built with -DNTRU_ABLATE=bits / -DRI_ABL=bits (tools/ablate.sh, tools/ab_rowimage.py: kernels with stores, matrix loops,
-// loads ... compiled out to see what the rest costs) computes WRONG VALUES on purpose.  Such a build only creates an engine for a
-// caller that says it knows (NTRU_ALLOW_TIMING_ONLY=1 in the environment -- the timing scripts set it), and every kernel name it
-// reports starts with "TIMING-ONLY ": it can never serve the C ABI or the Node addon silently.
-#if (defined(NTRU_ABLATE) && NTRU_ABLATE != 0) || (defined(RI_ABL) && RI_ABL != 0)
-#define NTRU_TIMING_ONLY_BUILD 1
-#else
-#define NTRU_TIMING_ONLY_BUILD 0
-#endif
-extern "C" int ntru_engine_is_timing_only_build(void) { return NTRU_TIMING_ONLY_BUILD; }
-
 extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
   if (!out) return fail(NTRU_ERR_ARG, "ntru_engine_create: out is NULL");
   *out = nullptr;
@@ -113,12 +102,6 @@ extern "C" int ntru_engine_create(int device, ntru_engine_t **out) {
     return fail(NTRU_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
                                         "); this engine has no CPU fallback");
   if (device < 0 || device >= n) return fail(NTRU_ERR_NO_DEVICE, "device id out of range");
-  if (NTRU_TIMING_ONLY_BUILD) {
-    const char *ok = getenv("NTRU_ALLOW_TIMING_ONLY");
-    if (!ok || strcmp(ok, "1") != 0)
-      return fail(NTRU_ERR_UNSUPPORTED, "this libntru_engine was built with -DNTRU_ABLATE / -DRI_ABL: a timing-only build whose kernels compute "
-                                        "wrong values on purpose; set NTRU_ALLOW_TIMING_ONLY=1 to time it, never to use it");
-  }
   HIP_TRY(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -196,13 +179,7 @@ extern "C" int ntru_engine_set_sampler_rounds(ntru_engine_t *eng, int rounds) {
 
 extern "C" int ntru_engine_get_sampler_rounds(ntru_engine_t *eng) { return eng ? eng->sampler_rounds : 0; }
 
-extern "C" const char *ntru_engine_last_kernel(ntru_engine_t *eng) {
-  if (!eng) return "";
-  if (!NTRU_TIMING_ONLY_BUILD) return eng->last_kernel;
-  static thread_local char tagged[96];
-  snprintf(tagged, sizeof tagged, "TIMING-ONLY %s", eng->last_kernel);
-  return tagged;
-}
+extern "C" const char *ntru_engine_last_kernel(ntru_engine_t *eng) { return eng ? eng->last_kernel : ""; }
 
 extern "C" int ntru_engine_synchronize(ntru_engine_t *eng) {
   if (!eng) return fail(NTRU_ERR_ARG, "engine is NULL");

@@ -69,9 +69,6 @@ static __constant__ const RecipTable g_recip = RecipTable();
 #define CHACHA_QR(a, b, c, d)                                                          \
   a += b; d ^= a; d = __builtin_rotateleft32(d, 16); c += d; b ^= c; b = __builtin_rotateleft32(b, 12); \
   a += b; d ^= a; d = __builtin_rotateleft32(d, 8);  c += d; b ^= c; b = __builtin_rotateleft32(b, 7);
-#ifndef NTRU_SAMPLER_ABLATE
-#define NTRU_SAMPLER_ABLATE 0      // timing-only builds: 1 = no ChaCha20 rounds, 2 = no Fisher-Yates steps (wrong values; never shipped)
-#endif
 
 // word w (symbols 16 w .. 16 w + 15) of the start row [1]*n1 ++ [2]*n2 ++ [0]*...
 static __device__ __forceinline__ u32 sampler_start_word(int w, int n1, int n2) {
@@ -115,20 +112,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample_ternary(int N, int n1, in
       u32 x4 = key.k[0], x5 = key.k[1], x6 = key.k[2], x7 = key.k[3], x8 = key.k[4], x9 = key.k[5], x10 = key.k[6],
           x11 = key.k[7], x12 = ctr, x13 = n0, x14 = nn1, x15 = nn2;
 #pragma unroll
-      for (int r = 0; r < (NTRU_SAMPLER_ABLATE & 1 ? 0 : DR); r++) {
+      for (int r = 0; r < DR; r++) {
         CHACHA_QR(x0, x4, x8, x12) CHACHA_QR(x1, x5, x9, x13) CHACHA_QR(x2, x6, x10, x14) CHACHA_QR(x3, x7, x11, x15)
         CHACHA_QR(x0, x5, x10, x15) CHACHA_QR(x1, x6, x11, x12) CHACHA_QR(x2, x7, x8, x13) CHACHA_QR(x3, x4, x9, x14)
       }
       const u32 ks[16] = {x0 + 0x61707865u, x1 + 0x3320646eu, x2 + 0x79622d32u, x3 + 0x6b206574u,
                           x4 + key.k[0], x5 + key.k[1], x6 + key.k[2], x7 + key.k[3], x8 + key.k[4], x9 + key.k[5],
                           x10 + key.k[6], x11 + key.k[7], x12 + ctr, x13 + n0, x14 + nn1, x15 + nn2};
-#if NTRU_SAMPLER_ABLATE & 2
-      u32 fold = 0;
-#pragma unroll
-      for (int w = 0; w < 16; w++) fold ^= ks[w] ^ (BIGN ? 0u : rc[w]);
-      if (fold == 0x12345678u) a = fold;
-      i -= 16;
-#else
 #pragma unroll
       for (int w = 0; w < 16; w++) {
         if (i >= 1) {
@@ -154,7 +144,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample_ternary(int N, int n1, in
           }
         }
       }
-#endif
     }
     col[0] = a;                                          // i == 0: the register copy of word 0 (N == 1: unchanged)
     wave_lds_fence();
@@ -740,6 +729,9 @@ extern "C" int ntru_invert_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
     // (joined below even when a launch fails: what is enqueued on the forked stream must not outlive this call)
     const hipError_t ej = hipEventRecord(eng->ev_join, eng->st_aux);
     forked = ej == hipSuccess;
+    // Without a join event nothing orders the caller's stream (or the scratch buffer's next user) behind what is already enqueued on the
+    // forked stream -- the mod-p kernel writes d_fp and the flag bytes in the shared scratch: wait for that stream on the host instead.
+    if (!forked) (void)hipStreamSynchronize(eng->st_aux);
     if (rc3) { if (forked) (void)hipStreamWaitEvent(main_stream, eng->ev_join, 0); return rc3; }
     HIP_TRY(ej);
   }

@@ -54,12 +54,6 @@ static __device__ unsigned long long g_stamps[1024][8][STAMP_BLOCKS][STAMP_SLOTS
 #define NTRU_STAMPS_READER(name)
 #endif
 
-// -DNTRU_ABLATE=1|2|3 builds timing-only variants (1: no result stores, 2: no matrix loops); never shipped.
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 1)
-#define ABL_STORE(x) && (x) == 0x7fffffff
-#else
-#define ABL_STORE(x)
-#endif
 
 template <class D>
 static __device__ __forceinline__ void build_toeplitz_array(u32 *T, const MGeom &g, D digit, int tid, int nthr) {
@@ -105,18 +99,12 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
                                                       const MGeom &g, int kb0, const u32 (&mlow)[4], Epi epi,
                                                       int stamp_iter = 0, int stamp_base = 0, int pause_ib = 0x7fffffff,
                                                       Pause pause = Pause(), Diag diag = Diag()) {
-#ifndef NTRU_ABLATE
-#define NTRU_ABLATE 0
-#endif
   constexpr bool TWO = MODE != M_DEC2;
   // The accumulators are never zeroed: the first matrix instruction of each takes the inline constant 0 as its C operand
   // (accL: contraction step 0, peeled below; accH: its own diagonal sub-step) -- 2 x 16 x NT_S moves per strip less.
   v16i accL[NT_S], accH[NT_S];
   v4i W0[NT_S], W1[NT_S];
   auto load_w = [&](int d, v4i &w0, v4i &w1) {
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 262144)       // timing only: no operand reads inside the loops (wrong values)
-    if (d != kb0) { asm volatile("" : "+v"(w0), "+v"(w1)); return; }
-#endif
     const u32 *p = tb0 - 8 * d;
     w0 = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
     if (MODE == M_ENC) {
@@ -130,9 +118,6 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
     }
   };
   auto load_a = [&](int ib, v4i &a0, v4i &a1) {
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 262144)
-    if (ib != 0) { asm volatile("" : "+v"(a0), "+v"(a1)); return; }
-#endif
     a0 = *(const v4i *)(st0 + 32 * ib);
     if (MODE == M_ENC) {                               // 32 r: r <= 3, no carry between bytes
 #pragma unroll
@@ -158,15 +143,6 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   // slide the window physically.  The next operand fragment is requested before the current step's products.
 #pragma unroll
   for (int t = 0; t < NT_S; t++) load_w(kb0 + t, W0[t], W1[t]);
-#if NTRU_ABLATE & 2
-  const int kb0_ = kb0; kb0 = 0; const int NT_ = 0;
-#pragma unroll
-  for (int t = 0; t < NT_S; t++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) accH[t][i] = 0;
-#else
-  const int NT_ = g.NT;
-#endif
   u32 mhigh[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
@@ -209,7 +185,7 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   };
   int ib = 0;
   bool paused = false;
-  if (kb0 > 0 && NT_ > 0) {                              // contraction step 0: the first term of every `low`
+  if (kb0 > 0 && g.NT > 0) {                              // contraction step 0: the first term of every `low`
     if (!std::is_same<Pause, NoPause>::value && pause_ib <= 0) { pause(); paused = true; load_a(0, a0, a1); }
     v4i n0, n1;
     load_a(1, n0, n1);
@@ -240,22 +216,13 @@ static __device__ __forceinline__ void toeplitz_strip(const unsigned char *__res
   for (; ib < kb0; ib++) { maybe_pause(ib, ib); single(ib, accL); }
   maybe_pause(kb0, kb0 + NT_S - 1);
   block(kb0, std::integral_constant<int, 2>{});                                        // ib = kb0 .. kb0 + NT_S - 1
-  for (ib = kb0 + NT_S; ib + NT_S <= NT_; ib += NT_S) { maybe_pause(ib, ib + NT_S - 1); block(ib, std::integral_constant<int, 1>{}); }   // below: high
-  for (; ib < NT_; ib++) { maybe_pause(ib, ib); single(ib, accH); }
+  for (ib = kb0 + NT_S; ib + NT_S <= g.NT; ib += NT_S) { maybe_pause(ib, ib + NT_S - 1); block(ib, std::integral_constant<int, 1>{}); }   // below: high
+  for (; ib < g.NT; ib++) { maybe_pause(ib, ib); single(ib, accH); }
   __builtin_amdgcn_s_setprio(0);
   if (!std::is_same<Pause, NoPause>::value && !paused) pause();
   STAMP(stamp_base);
-#if NTRU_ABLATE & 128
-  if (MODE == M_DEC1) { if (accL[0][0] == 0x7fffffff) epi(accL, accH); return; }
-#endif
-#if NTRU_ABLATE & 256
-  if (MODE == M_DEC2) { if (accL[0][0] == 0x7fffffff) epi(accL, accH); return; }
-#endif
   epi(accL, accH);
   STAMP(stamp_base + 1);
-#if NTRU_ABLATE & 2
-  (void)kb0_;
-#endif
 }
 
 #ifdef NTRU_EXPERIMENTS
@@ -482,14 +449,6 @@ static __device__ __forceinline__ RawChunks<NCH> load_raw(const AlignedSrc &src,
 #pragma unroll
   for (int c = 0; c < NCH; c++) r.c[c] = __builtin_amdgcn_raw_buffer_load_b128(src.rs, al + 16 * c, 0, 0);
   r.tail = __builtin_amdgcn_raw_buffer_load_b32(src.rs, al + 16 * NCH, 0, 0);
-  return r;
-}
-template <int NCH>
-static __device__ __forceinline__ RawChunks<NCH> fake_raw(int v) {        // timing-only builds (NTRU_ABLATE)
-  RawChunks<NCH> r;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) r.c[c] = (v4i){v, 1, 2, 1};
-  r.tail = 0;
   return r;
 }
 template <int NCH>

@@ -192,11 +192,7 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
       for (int j = 0; j < RPW; j++) {
         const int pos0 = src_e.a0 + 2 * (wave + WAVES_PER_BLOCK * j) * LD;
         sh[j] = __builtin_amdgcn_readfirstlane(pos0 & 15);
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
-        raw[j] = fake_raw<2>(pos0 + lane);
-#else
         raw[j] = load_raw<2>(src_e, pos0 + 32 * lane, sh[j]);
-#endif
       }
     };
     wg_barrier();
@@ -280,24 +276,16 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
                 const u32 x = (u32)(lo[t][i] + hi[t][i]) & (q - 1);
                 xs[t][ii] = x;
                 const int so = 2 * (ro * LD + 32 * (kb0 + t));
-                if (1 ABL_STORE(lo[t][i])) {
-#if NTRU_ABLATE & 32768
-                  __builtin_amdgcn_raw_buffer_store_b16((u16)(x ^ (u32)hi[t][i]), rs_r1, voff[t], so, ST_AUX);       // timing only: one store
-#else
+                {
                   if (decltype(wr)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)x, rs_r1, voff[t], so, ST_AUX);
                   if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi[t][i]) & (q - 1)), rs_q1, voff[t], so, ST_AUX);
-#endif
                 }
               }
             }
 #pragma unroll
             for (int t = 0; t < NTS; t++)
 #pragma unroll
-#if NTRU_ABLATE & 16384
-              for (int ii = 0; ii < 4; ii++) lv[t][ii] = xs[t][ii] & 1u;                       // timing only: no lift lookups
-#else
               for (int ii = 0; ii < 4; ii++) lv[t][ii] = lift_lut[xs[t][ii]];
-#endif
 #pragma unroll
             for (int t = 0; t < NTS; t++) {
               const int col = 32 * (kb0 + t) + (lane & 31);
@@ -324,14 +312,11 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
     wg_barrier();                                    // every wave is done with the e stages; packed image complete
     STAMP(8);
     if (PACK) pack_wipe();
-#if !(NTRU_ABLATE & 64)
     if (!DMA) for (int x = tid0; x <= (int)((p - 1) * (p - 1)) * N; x += BLOCK_THREADS) {
       const u32 rm = mod_small((u32)x, p);
       m3_lut[x] = (unsigned char)(rm ? p - rm : 0u);
       m3_lut[M3V + x] = (unsigned char)rm;
     }
-#endif
-#if !(NTRU_ABLATE & 32)
     {   // packed image -> byte stage: all of a wave's reads in flight before the first write (as a read-write loop this
         // pass was one LDS round trip per dword: 7 k cycles per row block in the phase stamps)
       constexpr int RPW = 32 / WAVES_PER_BLOCK;
@@ -374,7 +359,6 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
         }
       }
     }
-#endif
     STAMP(9);
     wg_barrier();
     STAMP(10);
@@ -408,12 +392,8 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
             for (int t = 0; t < NTS; t++)
 #pragma unroll
               for (int ii = 0; ii < 4; ii++) {
-#if NTRU_ABLATE & 4096
-                va[t][ii] = (u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii]); vb[t][ii] = (u32)hi[t][4 * j + ii];   // timing only: no lookups
-#else
                 va[t][ii] = m3_lut[(u32)(lo[t][4 * j + ii] + hi[t][4 * j + ii] + M3V)];
                 vb[t][ii] = decltype(wq)::value ? (u32)m3_lut[(u32)hi[t][4 * j + ii]] : 0u;
-#endif
               }
             if (PACK) {
 #pragma unroll
@@ -429,13 +409,9 @@ static __device__ __forceinline__ void decrypt_m_body(MGeom g, u32 q, u32 p, con
 #pragma unroll
               for (int t = 0; t < NTS; t++) {
                 const int so = (ii + 8 * j) * LD + 32 * (kb0 + t);
-                if (1 ABL_STORE(lo[t][4 * j + ii])) {
-#if NTRU_ABLATE & 8192
-                  __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(va[t][ii] ^ vb[t][ii]), rs_v, voff[t], so, ST_AUX);   // timing only: one store
-#else
+                {
                   __builtin_amdgcn_raw_buffer_store_b8((uint8_t)va[t][ii], rs_v, voff[t], so, ST_AUX);
                   if (decltype(wq)::value) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)vb[t][ii], rs_q2, voff[t], so, ST_AUX);
-#endif
                 }
               }
             }

@@ -115,20 +115,12 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
         const int pos0 = src_r.a0 + (wave + WAVES_PER_BLOCK * j) * LD;
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 4)
-        in_r[j] = fake_raw<1>(pos0 + lane);
-#else
         in_r[j] = load_raw<1>(src_r, pos0 + 16 * lane, 0);
-#endif
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int i = tid * 16 + j * BLOCK_THREADS * 16;
-#if defined(NTRU_ABLATE) && (NTRU_ABLATE & 8)
-        in_m[j] = fake_raw<1>(i);
-#else
         in_m[j] = load_raw<1>(src_m, src_m.a0 + i, 0);   // past the row block: next rows or zeros, not written
-#endif
       }
     }
     wg_barrier();                                    // the previous row block's readers are done (first pass: key arrays built)
@@ -197,9 +189,6 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
         phase();                                         // matrix loop | epilogue
         epi_sync();
         long bb = b0;                                    // descriptors made where they are used: see k_decrypt_m
-#if NTRU_ABLATE & 512
-        bb = 0;                                          // timing only: every workgroup writes the first row block (L2-resident)
-#endif
         asm volatile("" : "+s"(bb));
         const long lf = (B - bb) * LD;
         const __amdgpu_buffer_rsrc_t rs_e = rows_rsrc(e + bb * LD, 2 * lf);
@@ -239,7 +228,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
               for (int ii = 0; ii < 4; ii++) {
                 const auto se = __builtin_amdgcn_permlane32_swap(ev[t][ii], ev[t + 1][ii], false, false);
                 const int so = 2 * ((8 * j + ii) * LD + 32 * (kb0 + t));
-                if (1 ABL_STORE(lo[t][4 * j])) {
+                {
                   __builtin_amdgcn_raw_buffer_store_b16((u16)se[0], rs_e, pvoff, so, ST_AUX);
                   __builtin_amdgcn_raw_buffer_store_b16((u16)se[1], rs_e, pvoff, so + 8 * LD, ST_AUX);
                   if (decltype(wq)::value) {
@@ -253,7 +242,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
             if (NTS & 1) {                               // the odd tile out: two rows of 32 columns per store
               constexpr int t = NTS - 1;
               const int so = 2 * (8 * j * LD + 32 * (kb0 + t));
-              if (1 ABL_STORE(lo[t][4 * j])) {
+              {
 #pragma unroll
                 for (int ii = 0; ii < 4; ii++) {
                   __builtin_amdgcn_raw_buffer_store_b16((u16)ev[t][ii], rs_e, voff[t], so + 2 * ii * LD, ST_AUX);
@@ -319,7 +308,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
               // registers the NEXT instruction overwrites stores the overwritten first dword on gfx950 under load
               // (profiles/r02_hazard_store_x4_soffset.txt); the compiler only separates the two when soffset is no
               // register (tests/test_build_quality.py scans the ISA for the pattern).
-              if (1 ABL_STORE(lo[0][0])) {
+              {
                 __builtin_amdgcn_raw_buffer_store_b128(pv[0], rs, pvo[0], 0, ST_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(pv[1], rs, pvo[1], 0, ST_AUX);
                 __builtin_amdgcn_raw_buffer_store_b16(ev[0], rs, evo[0], 0, ST_AUX);
@@ -619,13 +608,11 @@ __global__ __launch_bounds__(512, 1) void k_encrypt_m2(MGeom g, u32 q, const u16
   long drain_rb = -1; int drain_round = 0;                           // what the chunk holds
   M2EncPre pre;                                                      // the plaintext bytes of that chunk's rows
   auto drain = [&]() {
-#if !(NTRU_ABLATE & 1024)
     if (drain_rb < 0) return;
     int dk, dn;
     m2_strip(g.NT, 4 * drain_round + w4, &dk, &dn);
     if (want_q) m2_drain_encrypt<true>(chunk, cp, dk, dn, drain_rb << 5, B, g.N, g.ld, q, pre, e, quotE, lane0);
     else m2_drain_encrypt<false>(chunk, cp, dk, dn, drain_rb << 5, B, g.N, g.ld, q, pre, e, quotE, lane0);
-#endif
   };
   int it = 0;
   for (long rb = blockIdx.x; rb < nrb; rb += gridDim.x, it++) {

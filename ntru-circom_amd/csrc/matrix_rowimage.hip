@@ -25,7 +25,7 @@
 // MEASURED (profiles/r04_rowimage_encrypt.txt): bit-exact, and exactly as fast as k_encrypt_md (1.50 against 1.51 ms per 2^20 at
 // N = 821; 1.58 against 1.58 ms in a sustained loop) at exactly the same energy (1.74 J dynamic per launch, both at the 1400 W cap):
 // inside a kernel the store pattern does not change what an HBM byte costs.  Kept as an experiment (kernel path 10 of a library built
-// with -DNTRU_EXPERIMENTS); -DRI_ABL=bits builds timing-only variants of it (1 no drain, 2 drain without stores, 4 no image writes).
+// with -DNTRU_EXPERIMENTS).
 #include "matrix_common.h"
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -76,10 +76,6 @@ static __device__ __forceinline__ void ri_store_encrypt(const RiRaw &rw, int pi,
     ev[c] = (int)(as_u32(as_pair(lowp) + as_pair(mm[c])) & qm2);
     qv[c] = (int)(as_u32((u16x2){0, 0} - as_pair(highp)) & qm2);
   }
-#if defined(RI_ABL) && (RI_ABL & 2)
-  if (ev[0] == 0x12345678 && qv[1] == 0x7654321) __builtin_amdgcn_raw_buffer_store_b128(ev, rsE, voff, 0, ST_AUX);
-  return;
-#endif
   __builtin_amdgcn_raw_buffer_store_b128(ev, rsE, voff, 0, ST_AUX);
   if (WQ) __builtin_amdgcn_raw_buffer_store_b128(qv, rsQ, voff, 0, ST_AUX);
 }
@@ -157,9 +153,6 @@ __global__ __launch_bounds__(RI_THREADS, 2) void k_encrypt_w(MGeom g, u32 q, con
   bool have_prev = false;
   // Pieces 8 j + wave, j = j0 .. j1-1, of the previous row block: every LDS read of the group first, then the arithmetic and the stores.
   auto drain = [&](int j0, int j1, int lane) {
-#if defined(RI_ABL) && (RI_ABL & 1)
-    return;
-#endif
     RiPrev pv = prev;
     asm volatile("" : "+s"(pv.b0), "+s"(pv.L));
     const int end = a0 + pv.L;
@@ -215,9 +208,6 @@ __global__ __launch_bounds__(RI_THREADS, 2) void k_encrypt_w(MGeom g, u32 q, con
     auto image = [&](auto &lo, auto &hi) {
       constexpr int NTS = sizeof(lo) / sizeof(lo[0]);
       const int colb = 32 * kb0 + (lane & 31), rowb = 4 * (lane >> 5);
-#if defined(RI_ABL) && (RI_ABL & 4)
-      if (lo[0][0] != 0x12345678) return;
-#endif
 #pragma unroll
       for (int t = 0; t < NTS; t++) {
         if (colb + 32 * t < N) {

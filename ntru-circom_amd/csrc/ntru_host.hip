@@ -420,10 +420,10 @@ extern "C" int ntru_pipeline_batch(ntru_engine_t *eng, int N, int q, int p, cons
   return P.run(B, chunk_items(B), [&](int64_t o, int64_t n, void **d) {
     if (key) if (int rc = ntru_sample_ternary_dev(eng, N, n1, n2, p - 1, key, first_item + (uint64_t)o, n, (uint8_t *)d[ir])) return rc;
     if (!decrypt && packed) {   // packOutput of e: out of the encrypt kernel itself when e is not an output too and the row-image kernel applies
-      if (!e) {
-        const int rc = ntru_encrypt_pack_batch_dev(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
-                                                   nullptr, (uint64_t *)d[ip]);
-        if (rc != NTRU_ERR_ARG) return rc;                 // (NTRU_ERR_ARG: outside the fused kernel's range -- e as the intermediate, below)
+      if (!e && (eng->path == 0 || eng->path >= 4)) {       // the launcher itself says whether the fused kernel applies (NTRU_NOT_TAKEN:
+        const int rc = ntru_launch_encrypt_pack_rowimage(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
+                                                         (uint64_t *)d[ip], os);     // e as the intermediate, below); no public error
+        if (rc != NTRU_NOT_TAKEN) return rc;               // code doubles as control flow
       }
       return ntru_encrypt_pack_batch_dev(eng, N, q, (const uint16_t *)d[ih], (const uint8_t *)d[ir], (const uint8_t *)d[im], n,
                                          (uint16_t *)d[ie], (uint64_t *)d[ip]);

@@ -29,7 +29,6 @@ def library_path():
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
 _SIGS = {
     "ntru_engine_device_count": (C.c_int, []),
-    "ntru_engine_is_timing_only_build": (C.c_int, []),
     "ntru_engine_create": (C.c_int, [_i, C.POINTER(_vp)]),
     "ntru_engine_destroy": (None, [_vp]),
     "ntru_engine_set_stream": (C.c_int, [_vp, _vp]),

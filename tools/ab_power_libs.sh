@@ -1,6 +1,5 @@
 # time / shader clock / socket power of the headline kernels for several builds of the library on ONE device
 #   LIBS="new ntru-circom_amd/lib/ab/libntru_base.so ..." LOADS=encrypt,decrypt KPS="0 4" bash tools/ab_power_libs.sh
-export NTRU_ALLOW_TIMING_ONLY=1      # the libraries these scripts time compute wrong values on purpose (ntru_engine_create asks)
 for lib in ${LIBS:-new ntru-circom_amd/lib/ab/libntru_base.so}; do
  for kp in ${KPS:-0}; do
   echo "# lib=$lib kernel_path=$kp"

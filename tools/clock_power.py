@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--kernel-path", type=int, default=0, help="ntru_engine_set_kernel_path for the encrypt / decrypt loops")
     ap.add_argument("--row-pitch", type=int, default=0, help="row pitch in elements (0 = dense)")
     ap.add_argument("--loads", default="all", help="comma list of: idle,mfma,encrypt,decrypt,decrypt_value,verify (default all), sampler; with "
-                                                   "NTRU_ENGINE_LIB pointing at a timing-only build (tools/ablate.sh) this prices its energy")
+                                                   "NTRU_ENGINE_LIB pointing at another build of the library this prices its energy")
     args = ap.parse_args()
     import numpy as np
     import torch

@@ -1,5 +1,4 @@
 # time / shader clock / socket power of the encrypt and decrypt kernels per kernel path (same device, one call)
-export NTRU_ALLOW_TIMING_ONLY=1      # the libraries these scripts time compute wrong values on purpose (ntru_engine_create asks)
 mkdir -p gpurun_out
 OUT=gpurun_out/r03_power_kernel_paths.txt
 : > $OUT

@@ -1,5 +1,4 @@
 # J per GB of the store patterns of bench_micro/store_pattern (and the fp4 matrix instruction's rate / power)
-export NTRU_ALLOW_TIMING_ONLY=1      # the libraries these scripts time compute wrong values on purpose (ntru_engine_create asks)
 set -e
 mkdir -p gpurun_out
 OUT=gpurun_out/r03_power_store_patterns.txt
