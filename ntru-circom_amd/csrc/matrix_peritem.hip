@@ -69,6 +69,18 @@ static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 m
 // spilled at three waves per SIMD).
 static __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// diag_low_mask (matrix_common.h) for kernels that make the mask once per PRODUCT instead of once per launch: byte jj of dword c is
+// set iff r >= 16 hh + 4 c + jj, i.e. the n = clamp(r - 16 hh - 4 c + 1, 0, 4) low bytes -- a handful of instructions per dword
+// where sixteen byte-wise compare / select pairs cost ~50.
+static __device__ __forceinline__ void pi_diag_low_mask(int lane, u32 (&mlow)[4]) {
+  const int u = (lane & 31) - 16 * (lane >> 5) + 1;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int n = min(max(u - 4 * c, 0), 4);
+    mlow[c] = n >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n)) - 1u);
+  }
+}
+
 static __device__ __forceinline__ v4i rows_up(v4i a, int seam) {          // lane l <- lane l - 1 (lane 0 <- 0)
   v4i o;
 #pragma unroll
@@ -103,7 +115,7 @@ static __device__ __forceinline__ void pi_product_reg(const v4i (&F)[NPL], const
   v4i wl_a = frag(1), wh_a = frag(-1), wl_b, wh_b;
   {                                                        // d = 0: split by the diagonal mask; the first term of every accumulator
     u32 mlow[4];
-    diag_low_mask(lane, mlow);
+    pi_diag_low_mask(lane, mlow);
     const v4i wl = and4(w0, mlow);
     const v4i wh = {(int)((u32)w0[0] & ~mlow[0]), (int)((u32)w0[1] & ~mlow[1]), (int)((u32)w0[2] & ~mlow[2]), (int)((u32)w0[3] & ~mlow[3])};
 #pragma unroll
@@ -255,9 +267,15 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       u32 xq[8];
       fq_pairs(xq);
       pi_digits(xq, q, 1u, 16 * ch, N, F[0], F[1]);
+      // fp mod 3 as the third plane.  A key's fp is already reduced: one wave-wide test (is any byte >= 3?) skips the byte-wise division
       union { v4i v; unsigned char c[16]; } u; u.v = bytes_of(r_fp, fp + row) & cmask;
+      u32 big = 0;
 #pragma unroll
-      for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
+      for (int c = 0; c < 4; c++) big |= ((((u32)u.v[c] & 0x7F7F7F7Fu) + 0x7D7D7D7Du) | (u32)u.v[c]) & 0x80808080u;
+      if (__ballot(big != 0) != 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
+      }
       F[2] = u.v;
     }
     STAMP(2);                                              // the three planes in registers
@@ -274,34 +292,41 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       // stores through one-row descriptors: index k = 32 kb + r is a per-lane offset (128 hh + r) plus a compile-time
       // one per register, indices >= N fall outside the descriptor and are dropped -- no address arithmetic per store
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fq + row, 2L * N), rs_q = rows_rsrc(quot_fq + row, 2L * N);
-      bool nz_hi = false, first_not_one = false;
+      // index.js:159: invalid iff the remainder has a non-zero coefficient above the constant one AND its constant one is not 1.
+      // Register i of this lane holds index ko_i + kl: it exists iff ko_i < N - kl (one compare against a per-lane limit, ko_i a
+      // constant); coefficient 0 is register 0 of lane 0.
+      u32 any_hi = 0, c0 = 0;
+      const int lim = N - kl;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const int lo = L[0][i] + 128 * L[1][i], hi = H[0][i] + 128 * H[1][i];
         const u32 rv = (u32)(lo + hi) & (q - 1);
         __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
         __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
-        nz_hi |= k >= 1 && k < N && rv != 0;
-        first_not_one |= k == 0 && rv != 1;
+        if (i == 0) { c0 = rv; any_hi |= kl == 0 ? 0u : rv; }
+        else any_hi |= ko < lim ? rv : 0u;
       }
+      const bool nz_hi = any_hi != 0, first_not_one = kl == 0 && c0 != 1;
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
     }
     STAMP(4);                                              // product 1's epilogue
     {
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
-      bool nz_hi = false, first_not_one = false;
+      u32 any_hi = 0, c0 = 0;                              // as for product 1
+      const int lim = N - kl;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int ko = 32 * ((i & 3) + 8 * (i >> 2)), k = ko + kl;
+        const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         // |L + H|, |H| <= 127 N (f is an int8, fp < 3): a multiple of 3 above that keeps the dividend non-negative
         const u32 x = (u32)(L[2][i] + H[2][i] + 3 * 131072), y = (u32)(3 * 131072 - H[2][i]);
         const u32 rv = x % 3u, qv = y % 3u;
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
-        nz_hi |= k >= 1 && k < N && rv != 0;
-        first_not_one |= k == 0 && rv != 1;
+        if (i == 0) { c0 = rv; any_hi |= kl == 0 ? 0u : rv; }
+        else any_hi |= ko < lim ? rv : 0u;
       }
+      const bool nz_hi = any_hi != 0, first_not_one = kl == 0 && c0 != 1;
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
     }
     STAMP(5);                                              // product 2's epilogue
@@ -343,30 +368,46 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       v4i hc[2];
       shift_raw<2>(r_h, __builtin_amdgcn_readfirstlane(s_h.a0), hc);
       const int i0 = 16 * opaque(lane);
-      u32 nz = 0, df = 0;                                  // bit j: h[i0 + j] != 0 / != remainder[i0 + j]
+      // Per lane two 16-bit sets in a SPLIT layout (coefficient i0 + 2 c in bit c, i0 + 2 c + 1 in bit 16 + c: what one packed
+      // 16-bit minimum and one shift-or per dword give): nz = h is non-zero there, df = h differs from the remainder there;
+      // coefficients at and beyond N are cut off the sets, not off the data.  h is invalid iff its FIRST difference from the
+      // remainder lies at or below its LAST non-zero coefficient (index.js:165 compares below h's trimmed length); both are
+      // found on the scalar side from one ballot and one v_readlane each.
+      u32 nz = 0, df = 0;
       if (i0 < 32 * NT) {
         const v4i rc0 = *(const v4i *)(nat + 2 * i0), rc1 = *(const v4i *)(nat + 2 * i0 + 16);
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-          const int lf = N - (i0 + 2 * c);
-          const u32 keep = lf >= 2 ? 0xFFFFFFFFu : (lf == 1 ? 0x0000FFFFu : 0u);
-          const u32 hx = (u32)(c < 4 ? hc[0][c] : hc[1][c - 4]) & keep, rx = (u32)(c < 4 ? rc0[c] : rc1[c - 4]) & keep;
-          const u32 x = hx ^ rx;
-          nz |= ((hx & 0xFFFFu) ? 1u : 0u) << (2 * c) | ((hx >> 16) ? 2u : 0u) << (2 * c);
-          df |= ((x & 0xFFFFu) ? 1u : 0u) << (2 * c) | ((x >> 16) ? 2u : 0u) << (2 * c);
+          const u32 hx = (u32)(c < 4 ? hc[0][c] : hc[1][c - 4]), rx = (u32)(c < 4 ? rc0[c] : rc1[c - 4]);
+          nz |= as_u32(__builtin_elementwise_min(as_pair(hx), (u16x2){1, 1})) << c;
+          df |= as_u32(__builtin_elementwise_min(as_pair(hx ^ rx), (u16x2){1, 1})) << c;
         }
+        const int left = N - i0;                           // coefficients of this lane's chunk that exist
+        const u32 ne = left >= 16 ? 0xFFu : (1u << ((left + 1) >> 1)) - 1u, no = left >= 16 ? 0xFFu : (1u << (left >> 1)) - 1u;
+        const u32 valid = left <= 0 ? 0u : (ne | no << 16);
+        nz &= valid; df &= valid;
       }
-      // trimmed length of h (1 for the zero polynomial): the chunks are in lane order, so the top non-zero coefficient sits in the
-      // highest lane that has one -- found on the scalar side (one ballot, one v_readlane), not by a wave-wide maximum
-      const unsigned long long has = __ballot(nz != 0);
-      int hl = 1;
-      if (has) {
-        const int ltop = 63 - __builtin_clzll(has);
-        const u32 nzt = (u32)__builtin_amdgcn_readlane((int)nz, ltop);
-        hl = 16 * ltop + 32 - __builtin_clz(nzt);
+      auto last_of = [](u32 m) {                           // highest coefficient (0..15) of a non-empty split set
+        const u32 ev = m & 0xFFFFu, od = m >> 16;
+        const int te = ev ? 2 * (31 - __builtin_clz(ev)) : -1, to = od ? 2 * (31 - __builtin_clz(od)) + 1 : -1;
+        return te > to ? te : to;
+      };
+      auto first_of = [](u32 m) {                          // lowest coefficient of a non-empty split set
+        const u32 ev = m & 0xFFFFu, od = m >> 16;
+        const int fe = ev ? 2 * __builtin_ctz(ev) : 64, fo = od ? 2 * __builtin_ctz(od) + 1 : 64;
+        return fe < fo ? fe : fo;
+      };
+      const unsigned long long has = __ballot(nz != 0), dif = __ballot(df != 0);
+      if (dif) {
+        const int lf = __builtin_ctzll(dif);
+        const int first_diff = 16 * lf + first_of((u32)__builtin_amdgcn_readlane((int)df, lf));
+        int top = 0;                                       // the zero polynomial has trimmed length 1: index 0 is compared
+        if (has) {
+          const int lt = 63 - __builtin_clzll(has);
+          top = 16 * lt + last_of((u32)__builtin_amdgcn_readlane((int)nz, lt));
+        }
+        if (first_diff <= top) fl |= NTRU_FLAG_INVALID_H;
       }
-      const int nv = hl - i0 < 0 ? 0 : (hl - i0 > 16 ? 16 : hl - i0);   // this lane's indices below hl
-      if (__ballot((df & ((1u << nv) - 1u)) != 0) != 0) fl |= NTRU_FLAG_INVALID_H;
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
     wave_lds_fence();
@@ -604,7 +645,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
       Fr la = frag(1), ha = frag(-1), lb, hb;
       {
         u32 mlow[4], mhigh[4];
-        diag_low_mask(ln, mlow);
+        pi_diag_low_mask(ln, mlow);
 #pragma unroll
         for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
         XL[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, and4(f0.w0, mlow), zero, 0, 0, 0);

@@ -75,7 +75,65 @@ def product_split(a, s_planes, scales, N):
     return accL.reshape(-1)[:N], accH.reshape(-1)[:N], n_mfma
 
 
+def product_split_registers(a_planes, s, N):
+    """The form the kernels use since round 5 (csrc/matrix_peritem.hip, "chunk rows in REGISTERS"): lane (r, hh) of the wave holds
+    bytes 16 hh .. 16 hh + 15 of chunk r of every plane; the low part walks d = 1, 2, ... by moving every lane's 16 bytes one lane UP
+    (wave_shr:1, lane 0 takes zero, lane 32 -- the seam between the half-waves -- is cut to zero), the high part walks d = -1, -2, ...
+    one lane DOWN (wave_shl:1, lanes 63 and 31 take zero).  No row of the chunk matrix is ever read from the LDS again; the fragment of
+    distance d is read once for ALL planes.  Returns (low[p], high[p]) per plane and the number of fragment reads."""
+    NT = tiles(N)
+    lowm = np.arange(32)[None, :] >= np.arange(32)[:, None]
+    lanes = []                                                          # [plane][64 lanes][16 bytes]
+    for a in a_planes:
+        ap = np.zeros(32 * 32, np.int64); ap[:N] = a                    # chunks >= NT are zero: lanes r >= NT hold zeros
+        lanes.append(np.stack([ap[32 * r + 16 * hh: 32 * r + 16 * hh + 16] for hh in (0, 1) for r in range(32)]))
+    def as_matrix(L):                                                   # the MFMA A operand of these 64 lanes: rows r, K = 16 hh + j
+        return np.concatenate([L[:32], L[32:]], axis=1)
+    def up(L):
+        M = np.zeros_like(L); M[1:] = L[:-1]; M[32] = 0; return M      # wave_shr:1 + seam mask (lane 32)
+    def down(L):
+        M = np.zeros_like(L); M[:-1] = L[1:]; M[31] = 0; return M      # wave_shl:1 + seam mask (lane 31)
+    out, reads = [], 0
+    G0 = toeplitz_tile(s, N, 0); reads += 1
+    accL = [as_matrix(L) @ np.where(lowm, G0, 0) for L in lanes]
+    accH = [as_matrix(L) @ np.where(~lowm, G0, 0) for L in lanes]
+    AL, AH = [L.copy() for L in lanes], [L.copy() for L in lanes]
+    for j in range(1, NT):
+        Gl, Gh = toeplitz_tile(s, N, j), toeplitz_tile(s, N, -j); reads += 2
+        for p in range(len(lanes)):
+            AL[p] = up(AL[p]); accL[p] = accL[p] + as_matrix(AL[p]) @ Gl
+            AH[p] = down(AH[p]); accH[p] = accH[p] + as_matrix(AH[p]) @ Gh
+    for p in range(len(lanes)):
+        out.append((accL[p].reshape(-1)[:N], accH[p].reshape(-1)[:N]))
+    return out, reads
+
+
+def tile_shapes(N):
+    """Go / no-go on paper for the 16-row tile (v_mfma_i32_16x16x64_i8) against the 32-row one, per digit plane and product:
+    matrix work issued, the useful share of it, operand bytes an instruction needs and lane shifts per plane when the rows live
+    in registers."""
+    NT = tiles(N)
+    useful = NT * NT                                                    # tile pairs (kb, ib), 32 x 32 x 32 MACs each
+    issued32 = 2 * NT * 32                                              # 2 NT instructions x 32 rows
+    # 16-row tile: row groups of 16 output tiles; a (group, d) unit is issued when any of its rows is in range
+    units = 0
+    for part, ds in (("low", range(0, NT)), ("high", range(-(NT - 1), 0))):
+        for g0 in range(0, NT, 16):
+            rows = range(g0, min(g0 + 16, NT))
+            units += sum(1 for d in ds if any(0 <= kb - d < NT for kb in rows))
+    instr16 = 2 * ((units + 1) // 2)                                    # K = 64: two distances per instruction, two 16-column halves
+    print("N=%d (NT=%d), per plane and product:" % (N, NT))
+    print("  32x32x32: %3d instructions (%5d clocks), useful MACs %.0f %%; operand bytes per instruction: 1 KB fragment (+ 1 KB of rows when "
+          "they are read from the LDS); 4 lane shifts per distance with the rows in registers" % (2 * NT, 2 * NT * 32, 100.0 * useful / issued32))
+    print("  16x16x64: %3d instructions (%5d clocks), useful MACs %.0f %%; operand bytes per instruction: 1 KB fragment per (distance pair, "
+          "column half) shared by the row groups; 4 + 8 lane shifts per distance PAIR and plane (two row groups, the second takes its entering rows "
+          "from the first: 6 per distance)" % (instr16, instr16 * 16, 100.0 * useful / (units * 16.0)))
+    print("  -> matrix clocks %.2fx, lane shifts 1.5x: with the vector port as loaded as the matrix pipe (round 5 counters: 0.9 against 0.67) the "
+          "16-row tile is not built" % (instr16 * 16 / (2 * NT * 32.0)))
+
+
 def main():
+    tile_shapes(821)
     rng = np.random.default_rng(11)
     for N, q in ((821, 4096), (701, 8192), (509, 2048), (167, 128), (1024, 8192), (33, 32)):
         f = rng.integers(-1, 2, N)                                      # ternary operand
@@ -90,8 +148,16 @@ def main():
         low3, high3, n3 = product_split(f, [fp], [1], N)
         lin3 = np.convolve(f, fp); lin3 = np.concatenate([lin3, np.zeros(2 * N - len(lin3), np.int64)])
         assert np.array_equal(low3, lin3[:N]) and np.array_equal(high3, lin3[N:]), (N, "mod p")
-        print("N=%d q=%d: %d + %d matrix instructions per item for (f * fq, f * fp); packed-MAC wave instructions today: %d  OK"
-              % (N, q, n, n3, 2 * ((N * N + 127) // 128)))
+        # rows in registers: operands swapped (the 13-bit operand's planes are the rows, the ternary one the Toeplitz fragments), as
+        # k_verify_keys_m runs products 1 and 2: planes fq lo, fq hi, fp against the fragments of f -- ONE fragment read per distance
+        v = fq % q
+        planes, reads = product_split_registers([v & 127, v >> 7, fp], f, N)
+        lo = planes[0][0] + 128 * planes[1][0]; hi = planes[0][1] + 128 * planes[1][1]
+        assert np.array_equal((lo + hi) % q, (lin[:N] + lin[N:]) % q) and np.array_equal((-hi) % q, (-lin[N:]) % q), (N, q, "registers")
+        assert np.array_equal(planes[2][0], low3) and np.array_equal(planes[2][1], high3), (N, "registers, mod p")
+        print("N=%d q=%d: %d + %d matrix instructions per item for (f * fq, f * fp); rows in registers: %d fragment reads for the three "
+              "planes and no row reads (rows in the LDS: %d fragment + %d row reads); packed-MAC wave instructions of the vector-ALU family: %d  OK"
+              % (N, q, n, n3, reads, 2 * reads, 3 * reads, 2 * ((N * N + 127) // 128)))
 
 
 if __name__ == "__main__":
