@@ -199,35 +199,43 @@ static __device__ __forceinline__ void pi_build_array_ch(unsigned char *nat, u32
   wave_lds_fence();
 }
 
-// verifyKeysInputs (index.js:141-197) for one key pair per wave.  Lane (r, hh) = 32 hh + r holds chunk ch = 2 r + hh (16 coefficients)
-// of every operand row -- the layout the matrix instruction wants its A operand in -- so the rows go from HBM to the matrix cores
-// through registers only; the LDS holds the reversed array of the ternary operand (f for products 1 and 2, which share every
-// fragment read: three planes, six matrix instructions per trip; then g for product 3).
-__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_verify_keys_m(
+// verifyKeysInputs (index.js:141-197) for one key pair per wave, ALL THREE products in one pass over the tile distances.
+// Lane (r, hh) = 32 hh + r holds chunk ch = 2 r + hh (16 coefficients) of every operand row -- the layout the matrix instruction
+// wants its A operand in -- so the rows go from HBM to the matrix cores through registers only.  Product 3 is taken as
+// p (fq * g): ((p fq) mod q) * g = p (fq * g) modulo q for the low and the high half alike, so its rows are the SAME two digit
+// planes of fq that product 1 multiplies, and the factor p goes into its epilogue.  The three planes (fq lo, fq hi, fp mod 3)
+// are shifted once per distance and direction and meet the fragments of BOTH reversed arrays (f: products 1 and 2; g: product 3):
+// ten matrix instructions per trip for 24 lane-shift instructions (two loops took 40), one set of planes, one loop prologue, fq
+// read once.  Five accumulator pairs = 160 registers: two waves per SIMD.  Same device: 2.12-2.13 ms per 2^18 against 2.18-2.20 ms for
+// the two-loop form at three waves per SIMD (products 1 + 2, then product 3 with its own planes), 2.09 against 2.18 J per launch.
+static __host__ __device__ inline size_t pi_verify_wave_bytes(const PGeom &g) { return pi_nat_bytes(g) + (size_t)32 * g.tpitch; }
+
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_verify_keys_m(
     PGeom g, u32 q, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
     const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
     u16 *__restrict__ rem_fq, uint8_t *__restrict__ quot_fp, uint8_t *__restrict__ rem_fp, u16 *__restrict__ quot_h,
     u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned char *nat = lds + (size_t)wave * pi_reg_wave_bytes(g);
-  u32 *T = (u32 *)(nat + pi_nat_bytes(g));
+  unsigned char *nat = lds + (size_t)wave * pi_verify_wave_bytes(g);
+  u32 *Tf = (u32 *)(nat + pi_nat_bytes(g)), *Tg = Tf + 4 * g.tpitch;
   const int N = g.N, NT = g.NT;
   auto chunk_of = [](int ln) { return 2 * (ln & 31) + (ln >> 5); };      // this lane's chunk of every operand row
   auto index_of = [](int ln) { return 128 * (ln >> 5) + (ln & 31); };    // accumulator register i holds index 32 ((i&3) + 8 (i>>2)) + this
   const long item_step = (long)gridDim.x * PI_WAVES;
-  // The first operand rows of an item (fq, f, fp: products 1 and 2) are requested at the end of the PREVIOUS item's last epilogue
-  // (a wave that fetched them where it needs them sat idle for a round trip to HBM per item) and stay in these registers across
-  // the loop back-edge.
+  // An item's operand rows are requested at the end of the PREVIOUS item's last epilogue (a wave that fetched them where it needs
+  // them sat idle for a round trip to HBM per item) and stay in these registers across the loop back-edge.
   RawChunks<2> r_fq;
-  RawChunks<1> r_f, r_fp;
-  auto request_first = [&](long it) {
+  RawChunks<1> r_f, r_fp, r_g;
+  auto request_rows = [&](long it) {
     const long row = it * N, left = (B - it) * N;
     const int ch = chunk_of(opaque(lane));
-    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_fp = aligned_src(fp + row, left);
-    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * ch, 0); r_f = load_raw<1>(s_f, s_f.a0 + 16 * ch, 0); r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * ch, 0);
+    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_fp = aligned_src(fp + row, left),
+                     s_g = aligned_src(gg + row, left);
+    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * ch, 0); r_f = load_raw<1>(s_f, s_f.a0 + 16 * ch, 0);
+    r_g = load_raw<1>(s_g, s_g.a0 + 16 * ch, 0); r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * ch, 0);
   };
-  if ((long)blockIdx.x * PI_WAVES + wave < B) request_first((long)blockIdx.x * PI_WAVES + wave);
+  if ((long)blockIdx.x * PI_WAVES + wave < B) request_rows((long)blockIdx.x * PI_WAVES + wave);
   [[maybe_unused]] int stamp_iter = -1;                    // -DNTRU_STAMPS: phase stamps of the first items (tools/phase_stamps_peritem.py)
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
     const long row = item * N, left = (B - item) * N;
@@ -239,33 +247,32 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       shift_raw<1>(rw, __builtin_amdgcn_readfirstlane((int)((unsigned long long)p & 15)), v);
       return v[0];
     };
-    auto fq_pairs = [&](u32 (&x)[8]) {                     // 16 coefficients per lane as u16 pairs
-      v4i v[2];
-      shift_raw<2>(r_fq, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(fq + row) & 15)), v);
-#pragma unroll
-      for (int c = 0; c < 4; c++) { x[c] = (u32)v[0][c]; x[4 + c] = (u32)v[1][c]; }
-    };
     // ternary operands: any negative byte is -1 (ValTernary), bytes at and beyond N are zero -- four bytes at a time
     auto ternary = [&](v4i v, const v4i &cmask) {
       v4i o;
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const u32 w = (u32)(v[c] & cmask[c]);
-        u32 neg = (w >> 7) & 0x01010101u;                  // 1 in every negative byte ...
-        neg |= neg << 1; neg |= neg << 2; neg |= neg << 4; // ... spread to 0xFF
-        o[c] = (int)(w | neg);
+        const u32 neg = (w >> 7) & 0x01010101u;            // 1 in every negative byte ...
+        o[c] = (int)(w | neg * 0xFFu);                     // ... spread to 0xFF (no carries: the factors are below 2^8 and 2^25)
       }
       return o;
     };
-    // ---- products 1 and 2: fq * f mod q and fp * f mod p (index.js:158-163): the reversed array of f, planes fq lo / fq hi / fp mod 3
+    // ---- operands: the reversed arrays of f and g, the planes fq lo / fq hi / fp mod 3 (index.js:155-166)
     v4i F[3];
     {
       const int ch = chunk_of(opaque(lane));
       const v4i cmask = col_mask16(16 * ch, N);            // bytes of this lane's chunk that are below N
-      pi_build_array_ch(nat, T, g, lane, ch, ternary(bytes_of(r_f, f + row), cmask));
-      STAMP(1);                                            // the reversed array of f
+      pi_build_array_ch(nat, Tf, g, lane, ch, ternary(bytes_of(r_f, f + row), cmask));
+      pi_build_array_ch(nat, Tg, g, lane, ch, ternary(bytes_of(r_g, gg + row), cmask));
+      STAMP(1);                                            // the two reversed arrays
       u32 xq[8];
-      fq_pairs(xq);
+      {
+        v4i v[2];
+        shift_raw<2>(r_fq, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(fq + row) & 15)), v);
+#pragma unroll
+        for (int c = 0; c < 4; c++) { xq[c] = (u32)v[0][c]; xq[4 + c] = (u32)v[1][c]; }
+      }
       pi_digits(xq, q, 1u, 16 * ch, N, F[0], F[1]);
       // fp mod 3 as the third plane.  A key's fp is already reduced: one wave-wide test (is any byte >= 3?) skips the byte-wise division
       union { v4i v; unsigned char c[16]; } u; u.v = bytes_of(r_fp, fp + row) & cmask;
@@ -278,15 +285,81 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
       F[2] = u.v;
     }
+    // h is requested before the loop whose remainder it is compared with, as a natural-order row chunk (16 coefficients per lane);
+    // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
+    const AlignedSrc s_h = aligned_src(h + row, 2 * left);
+    const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * opaque(lane), 0);
     STAMP(2);                                              // the three planes in registers
-    v16i L[3], H[3];
-    pi_product_reg<3>(F, T, g, lane, L, H);
-    STAMP(3);                                              // the matrix loops of products 1 and 2
-    // product 3's rows (g; fq again: an L2 hit) have the two epilogues to arrive
-    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_g = aligned_src(gg + row, left);
-    const int ch3 = chunk_of(opaque(lane));
-    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * ch3, 0);
-    const RawChunks<1> r_g = load_raw<1>(s_g, s_g.a0 + 16 * ch3, 0);
+    // ---- the loop: L1 / H1 (two planes) = fq * f, L2 / H2 = fp * f, L3 / H3 (two planes) = fq * g
+    v16i L1[2], H1[2], L2, H2, L3[2], H3[2];
+    {
+      const int ln = opaque(lane);
+      const int y0 = 32 * NT - 1 - (ln & 31) + 16 * (ln >> 5);
+      const u32 *tb = Tf + (y0 & 3) * g.tpitch + (y0 >> 2);     // this lane's fragment of f at distance 0; g's lies 4 tpitch dwords above
+      const int tstep = 4 * g.tpitch;
+      int seam_up = ln == 32 ? 0 : -1, seam_dn = ln == 31 ? 0 : -1;
+      asm volatile("" : "+v"(seam_up), "+v"(seam_dn));
+      struct Fr { v4i f, g; };
+      auto frag = [&](int d) {                             // |d| <= NT - 1; requests past the last step read the last fragment again
+        d = d > NT - 1 ? NT - 1 : (d < 1 - NT ? 1 - NT : d);
+        const u32 *p = tb - 8 * d, *p1 = p + tstep;
+        Fr fr;
+        fr.f = (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+        fr.g = (v4i){(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+        return fr;
+      };
+      const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const Fr f0 = frag(0);
+      Fr la = frag(1), ha = frag(-1), lb, hb;
+      {                                                    // d = 0: split by the diagonal mask; the first term of every accumulator
+        u32 mlow[4], mhigh[4];
+        pi_diag_low_mask(ln, mlow);
+#pragma unroll
+        for (int c = 0; c < 4; c++) mhigh[c] = ~mlow[c];
+        const v4i fl_ = and4(f0.f, mlow), fh_ = and4(f0.f, mhigh), gl_ = and4(f0.g, mlow), gh_ = and4(f0.g, mhigh);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          L1[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[p], fl_, zero, 0, 0, 0);
+          H1[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[p], fh_, zero, 0, 0, 0);
+          L3[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[p], gl_, zero, 0, 0, 0);
+          H3[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[p], gh_, zero, 0, 0, 0);
+        }
+        L2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2], fl_, zero, 0, 0, 0);
+        H2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2], fh_, zero, 0, 0, 0);
+      }
+      v4i AL[3] = {F[0], F[1], F[2]}, AH[3] = {F[0], F[1], F[2]};
+      auto trip = [&](const Fr &wl, const Fr &wh) {        // every shifted plane feeds two matrix instructions (the fp plane one)
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          AL[p] = rows_up(AL[p], seam_up);
+          L1[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AL[p], wl.f, L1[p], 0, 0, 0);
+          L3[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AL[p], wl.g, L3[p], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);               // the next plane's shifts issue under these matrix instructions
+        }
+        AL[2] = rows_up(AL[2], seam_up);
+        L2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(AL[2], wl.f, L2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          AH[p] = rows_down(AH[p], seam_dn);
+          H1[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AH[p], wh.f, H1[p], 0, 0, 0);
+          H3[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AH[p], wh.g, H3[p], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        AH[2] = rows_down(AH[2], seam_dn);
+        H2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(AH[2], wh.f, H2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      int j = 1;
+      for (; j + 1 < NT; j += 2) {
+        lb = frag(j + 1); hb = frag(-(j + 1));
+        trip(la, ha);
+        la = frag(j + 2); ha = frag(-(j + 2));
+        trip(lb, hb);
+      }
+      if (j < NT) trip(la, ha);
+    }
+    STAMP(3);                                              // the matrix loop
     const int kl = index_of(opaque(lane));
     {
       // stores through one-row descriptors: index k = 32 kb + r is a per-lane offset (128 hh + r) plus a compile-time
@@ -300,7 +373,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
-        const int lo = L[0][i] + 128 * L[1][i], hi = H[0][i] + 128 * H[1][i];
+        const int lo = L1[0][i] + 128 * L1[1][i], hi = H1[0][i] + 128 * H1[1][i];
         const u32 rv = (u32)(lo + hi) & (q - 1);
         __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
         __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
@@ -319,7 +392,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         // |L + H|, |H| <= 127 N (f is an int8, fp < 3): a multiple of 3 above that keeps the dividend non-negative
-        const u32 x = (u32)(L[2][i] + H[2][i] + 3 * 131072), y = (u32)(3 * 131072 - H[2][i]);
+        const u32 x = (u32)(L2[i] + H2[i] + 3 * 131072), y = (u32)(3 * 131072 - H2[i]);
         const u32 rv = x % 3u, qv = y % 3u;
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
@@ -330,40 +403,22 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
       if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
     }
     STAMP(5);                                              // product 2's epilogue
-    // ---- product 3: ((p fq) mod q) * g mod q, compared with h below its trimmed length (index.js:155,164-166)
-    v4i G[2];
     {
-      const int ch = chunk_of(opaque(lane));
-      pi_build_array_ch(nat, T, g, lane, ch, ternary(bytes_of(r_g, gg + row), col_mask16(16 * ch, N)));
-      STAMP(6);                                            // the reversed array of g
-      u32 xq[8];
-      fq_pairs(xq);
-      pi_digits(xq, q, 3u, 16 * ch, N, G[0], G[1]);
-    }
-    // h is requested before the product whose remainder it is compared with, as a natural-order row chunk (16 coefficients per lane);
-    // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
-    const AlignedSrc s_h = aligned_src(h + row, 2 * left);
-    const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * opaque(lane), 0);
-    STAMP(7);                                              // product 3: planes in registers
-    v16i L3[2], H3[2];
-    pi_product_reg<2>(G, T, g, lane, L3, H3);
-    STAMP(8);
-    {
+      // product 3 = p (fq * g) mod q (index.js:155,164): the factor p = 3 is applied here, to the low and the high half alike
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
       u16 *remx = (u16 *)nat;
-      const int kl = index_of(opaque(lane));
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int ko = 32 * ((i & 3) + 8 * (i >> 2));
         const int lo = L3[0][i] + 128 * L3[1][i], hi = H3[0][i] + 128 * H3[1][i];
-        const u32 rv = (u32)(lo + hi) & (q - 1);
+        const u32 rv = (u32)(3 * (lo + hi)) & (q - 1);
         __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - 3 * hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
         remx[ko + kl] = (u16)rv;                           // ko + kl <= 1151: inside the area for every N (pi_nat_bytes)
       }
-      if (item + item_step < B) request_first(item + item_step);   // the next item's first rows: in flight from here on (the accumulators are dead)
+      if (item + item_step < B) request_rows(item + item_step);   // the next item's rows: in flight from here on (the accumulators are dead)
       wave_lds_fence();
-      STAMP(9);                                            // product 3's result stores issued
+      STAMP(6);                                            // product 3's result stores issued
       // index.js:165: h[k] must equal the remainder for every k below h's trimmed length
       v4i hc[2];
       shift_raw<2>(r_h, __builtin_amdgcn_readfirstlane(s_h.a0), hc);
@@ -411,7 +466,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(3
     }
     if (lane == 0) flags[item] = (uint8_t)fl;
     wave_lds_fence();
-    STAMP(10);                                             // the comparison with h
+    STAMP(7);                                              // the comparison with h
   }
 }
 
@@ -714,6 +769,7 @@ template <class Kern>
 static int peritem_grid(ntru_engine *eng, Kern kern, size_t lds, long B, dim3 *grid) {
   int per_cu = 0;
   if (int rc = ntru_blocks_per_cu(eng, (const void *)kern, 64 * PI_WAVES, lds, &per_cu)) return rc;
+  if (eng->max_blocks_per_cu && eng->max_blocks_per_cu < per_cu) per_cu = eng->max_blocks_per_cu;     // NTRU_MAX_BLOCKS_PER_CU (experiments)
   long blocks = (long)eng->cus * (per_cu < 1 ? 1 : per_cu), work = (B + PI_WAVES - 1) / PI_WAVES;
   if (blocks > work) blocks = work;
   *grid = dim3((unsigned)blocks);
@@ -755,7 +811,7 @@ int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const 
                                    uint8_t *d_quot_fp, uint8_t *d_rem_fp, uint16_t *d_quot_h, uint16_t *d_rem_h, uint8_t *d_flags) {
   if (p != 3 || !peritem_applies(eng, N, q)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
-  const size_t lds = PI_WAVES * pi_reg_wave_bytes(pg);
+  const size_t lds = PI_WAVES * pi_verify_wave_bytes(pg);
   dim3 grid;
   if (int rc = peritem_grid(eng, k_verify_keys_m, lds, (long)B, &grid)) return rc;
   snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_verify_keys_m");

@@ -41,8 +41,8 @@ for _ in range(2):
 torch.cuda.synchronize()
 assert lib.ntru_debug_read_stamps_pi(buf.ctypes.data_as(C.c_void_p)) == 0
 show("k_verify_keys_m, N = %d, q = %d (%s)" % (N, q, eng.last_kernel()), buf[:768, :2].astype(np.int64),
-     [(0, 1, "array of f"), (1, 2, "planes fq lo/hi, fp"), (2, 3, "P1+P2 loops (3 planes)"), (3, 4, "P1 epilogue"), (4, 5, "P2 epilogue"),
-      (5, 6, "array of g"), (6, 7, "planes p fq"), (7, 8, "P3 loops (2 planes)"), (8, 9, "P3 stores"), (9, 10, "h comparison")], 10)
+     [(0, 1, "arrays of f and g"), (1, 2, "planes fq lo/hi, fp"), (2, 3, "the loop (5 plane products)"), (3, 4, "P1 epilogue"), (4, 5, "P2 epilogue"),
+      (5, 6, "P3 stores"), (6, 7, "h comparison")], 7)
 
 for mod in (16, 4096):
     a = torch.randint(0, mod, (B, N), dtype=torch.int32, device=dev).to(torch.int16)
