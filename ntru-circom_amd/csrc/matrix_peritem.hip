@@ -228,17 +228,18 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(2
   RawChunks<2> r_fq;
   RawChunks<1> r_f, r_fp, r_g;
   auto request_rows = [&](long it) {
-    const long row = it * N, left = (B - it) * N;
+    // (descriptors of ONE row: the lanes whose chunk lies beyond it -- chunks NT .. 63 -- read zeros instead of fetching the next items' rows)
+    const long row = it * N;
     const int ch = chunk_of(opaque(lane));
-    const AlignedSrc s_fq = aligned_src(fq + row, 2 * left), s_f = aligned_src(f + row, left), s_fp = aligned_src(fp + row, left),
-                     s_g = aligned_src(gg + row, left);
+    const AlignedSrc s_fq = aligned_src(fq + row, 2L * N), s_f = aligned_src(f + row, (long)N), s_fp = aligned_src(fp + row, (long)N),
+                     s_g = aligned_src(gg + row, (long)N);
     r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * ch, 0); r_f = load_raw<1>(s_f, s_f.a0 + 16 * ch, 0);
     r_g = load_raw<1>(s_g, s_g.a0 + 16 * ch, 0); r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * ch, 0);
   };
   if ((long)blockIdx.x * PI_WAVES + wave < B) request_rows((long)blockIdx.x * PI_WAVES + wave);
   [[maybe_unused]] int stamp_iter = -1;                    // -DNTRU_STAMPS: phase stamps of the first items (tools/phase_stamps_peritem.py)
   for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
-    const long row = item * N, left = (B - item) * N;
+    const long row = item * N;
     u32 fl = 0;
     stamp_iter++;
     STAMP(0);
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(2
     }
     // h is requested before the loop whose remainder it is compared with, as a natural-order row chunk (16 coefficients per lane);
     // the remainder gets into the same layout through the wave's LDS (the natural-order area is free again by then)
-    const AlignedSrc s_h = aligned_src(h + row, 2 * left);
+    const AlignedSrc s_h = aligned_src(h + row, 2L * N);
     const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * opaque(lane), 0);
     STAMP(2);                                              // the three planes in registers
     // ---- the loop: L1 / H1 (two planes) = fq * f, L2 / H2 = fp * f, L3 / H3 (two planes) = fq * g
@@ -491,9 +492,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
   RawChunks<2> ra;
   RawChunks<1> rs;
   auto request = [&](long it) {
-    const long rw = it * N, lf = (B - it) * N;
+    const long rw = it * N;                                // (one-row descriptors: see k_verify_keys_m)
     const int ch = chunk_of(opaque(lane));
-    const AlignedSrc sa = aligned_src(a + rw, 2 * lf), ss = aligned_src(s + rw, lf);
+    const AlignedSrc sa = aligned_src(a + rw, 2L * N), ss = aligned_src(s + rw, (long)N);
     ra = load_raw<2>(sa, sa.a0 + 32 * ch, 0);
     rs = load_raw<1>(ss, ss.a0 + 16 * ch, 0);
   };
@@ -556,9 +557,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(4
   RawChunks<2> rv;
   RawChunks<1> rf;
   auto request = [&](long it) {
-    const long rw = it * N, lf = (B - it) * N;
+    const long rw = it * N;
     const int ch = chunk_of(opaque(lane));
-    const AlignedSrc sv = aligned_src(v + rw, 2 * lf), sf = aligned_src(f + rw, lf);
+    const AlignedSrc sv = aligned_src(v + rw, 2L * N), sf = aligned_src(f + rw, (long)N);
     rv = load_raw<2>(sv, sv.a0 + 32 * ch, 0);
     rf = load_raw<1>(sf, sf.a0 + 16 * ch, 0);
   };
@@ -637,9 +638,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
   const long item_step = (long)gridDim.x * PI_WAVES;         // the NEXT item's operands are requested early: see k_product_tern_m
   RawChunks<2> rwa, rwb;
   auto request = [&](long it) {
-    const long rw = it * N, lf = (B - it) * N;
+    const long rw = it * N;
     const int ch = chunk_of(opaque(lane));
-    const AlignedSrc sa = aligned_src(a + rw, 2 * lf), sb = aligned_src(b + rw, 2 * lf);
+    const AlignedSrc sa = aligned_src(a + rw, 2L * N), sb = aligned_src(b + rw, 2L * N);
     rwa = load_raw<2>(sa, sa.a0 + 32 * ch, 0);
     rwb = load_raw<2>(sb, sb.a0 + 32 * ch, 0);
   };

@@ -132,7 +132,7 @@ def keygen_config(profile, logB):
     outs = [o16(), o16(), o8(), o8(), o16(), o16()]
     vflags = torch.empty(B, dtype=torch.uint8, device=dev)
     vms = timed(lambda: eng.verify_keys_batch_dev(N, q, p, f.data_ptr(), g.data_ptr(), fq.data_ptr(), fp.data_ptr(), h.data_ptr(),
-                                                  B, *[t.data_ptr() for t in outs], vflags.data_ptr()), steps=3, warmup=1)
+                                                  B, *[t.data_ptr() for t in outs], vflags.data_ptr()), steps=10, warmup=5)
     bad = int(((vflags != 0) & (fl == 0)).sum())
     # the generated keys against the oracle: h = p fq g and the verify_keys witness of a strided sample (which holds f fq = 1, f fp = 1)
     rows = sample_rows(B)
