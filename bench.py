@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PK_MAC_PEAK_T = 75.6           # measured v_pk_mad_u16 roof, profiles/r01_microbench_valu_lds.txt (T MAC/s)
+PK_MAC_PEAK_T = 75.6           # measured v_pk_mad_u16 roof, profiles/archive/r01_microbench_valu_lds.txt (T MAC/s)
 MFMA_I8_PEAK_T = 5000.0        # dense int8 MFMA = 2 x bf16 (~2.5 PFLOP/s), MI355X_MICROARCH.md "Matrix cores"
 DOT8_PEAK_T = 302.0            # measured v_dot8_u32_u4 roof: 37.9 T lane-instr/s x 8 nibble MACs
 ADD_PEAK_T = 134.0             # measured v_add_u32 roof 67 T lane-adds/s x 2 packed 16-bit coefficients per add
@@ -283,7 +283,7 @@ def device_sysfs_dir(index):
 
 class PowerSampler(threading.Thread):
     """Socket power, power cap and shader clock of one device from its amdgpu hwmon files, every 20 ms (the kernels run AT the
-    power cap: profiles/r03_clock_power.txt -- their speed is their energy, so the line carries what the driver reports)."""
+    power cap: profiles/archive/r03_clock_power.txt -- their speed is their energy, so the line carries what the driver reports)."""
 
     def __init__(self, dev_dir):
         super().__init__(daemon=True)
@@ -657,7 +657,7 @@ def main():
                     "executed_frac": ops / dec_s / 1e12 / MFMA_I8_PEAK_T, "instructions_per_launch": n_mfma,
                     "note": "v_mfma_i32_32x32x32_i8 instructions actually issued (three digit-plane products on a 32-padded tile grid, "
                             "1.6x the algorithmic MACs): a utilisation figure, not a roofline fraction; = SQ_INSTS_MFMA of the PMC "
-                            "pass; the instruction's measured issue roof is 75.4 G/s = 4.94 POP/s (profiles/r03_clock_power.txt)"}
+                            "pass; the instruction's measured issue roof is 75.4 G/s = 4.94 POP/s (profiles/archive/r03_clock_power.txt)"}
             valu = {"kernel": dname, "note": "matrix-core path: see `mfma`"}
         elif "+dot8" in dname:
             # product 1 steps over f (adds), product 2 is all N^2 nibble MACs on v_dot8_u32_u4
@@ -667,7 +667,7 @@ def main():
                     "unit": "T ops/s (coefficient-adds of product 1 + nibble-MACs of product 2)",
                     "note": "peak = this mix at the measured issue roofs: v_add_u32 67 T/s x 2 coefficients for the "
                             "stepping product, v_dot8_u32_u4 302 T nibble-MAC/s for the dot8 product "
-                            "(profiles/r01_microbench_valu_lds.txt); frac = ideal issue time / measured time"}
+                            "(profiles/archive/r01_microbench_valu_lds.txt); frac = ideal issue time / measured time"}
         elif add_path:
             nz_f = float(np.count_nonzero(f_np)) / N
             nz_b = 2.0 / 3.0                                  # the lifted message is ~uniform over {0,1,2}
@@ -831,7 +831,7 @@ def main():
                                    "note": "floor = matrix instructions on live operands + HBM bytes only; frac = floor / measured: how "
                                            "close the step is to what the socket power cap allows for this instruction mix"}
             power["note"] = ("the workload's steps back to back; the matrix-core kernels run against the socket power cap with the shader "
-                             "clock pulled below its 2.4 GHz top (profiles/r03_clock_power.txt, r04_rowimage_encrypt.txt)")
+                             "clock pulled below its 2.4 GHz top (profiles/archive/r03_clock_power.txt, r04_rowimage_encrypt.txt)")
     if dist:
         # who took part, and how each rank fared: its own seconds for the K steps (up to its own synchronize, before the closing
         # barrier), its kernels' HIP-event times, socket power and shader clock of ITS device over the sustained phase -- the

@@ -191,7 +191,7 @@ int ntru_decrypt_batch_dev(ntru_engine_t *eng, int N, int q, int p, const int8_t
  * nor written.  ld == N is the dense layout of the entry points above.  A pitch that makes rows start on cache-line
  * boundaries (ld a multiple of 64) lets the result stores go out as whole lines: at N = 821 the store pattern alone
  * reaches 3.3 TB/s at ld = 832 against 2.4 TB/s at ld = 821; inside the kernels that is worth 5-7 % of encrypt and
- * 2-3 % of a round trip (EXPERIMENTS.md round 1, profiles/r01_bench_row_pitch_ab.jsonl).  The reference has no memory
+ * 2-3 % of a round trip (EXPERIMENTS.md round 1, profiles/archive/r01_bench_row_pitch_ab.jsonl).  The reference has no memory
  * layout of its own (JS arrays, index.js:87-140), so the pitch is purely the host binding's choice.
  * Only the matrix-core kernels take a pitch: with ld != N the call fails with NTRU_ERR_UNSUPPORTED where they do not
  * apply (kernel path 1-3 forced, q > 8192, N or ld > 1024, p != 3). */

@@ -43,7 +43,7 @@ struct GrowBuf {
 // Host-path staging (ntru_host.hip): a chunk moves through three STAGES, each with its own engine-owned stream -- upload (H2D),
 // compute (the *_dev launches), download (D2H) -- chained by events, so that at any time ONE upload, one set of kernels and ONE
 // download are in flight: chunk k+1 goes up while chunk k computes and chunk k-1 comes down (PCIe is full duplex: 57 GB/s one
-// way, 47 + 47 GB/s both ways on this box, profiles/r03_pcie_duplex.json).  Chunk k owns buffer set k % 3 (pinned host arena +
+// way, 47 + 47 GB/s both ways on this box, profiles/archive/r03_pcie_duplex.json).  Chunk k owns buffer set k % 3 (pinned host arena +
 // device arena + scratch) until its download has finished.  [Round 2 ran each chunk on the stream of one of TWO slots: the two
 // slots fell into lock-step -- both uploading, then both computing, then both downloading -- and the two directions never
 // overlapped: 56 GB/s in total.]
@@ -113,7 +113,7 @@ static inline int fail(int code, const std::string &msg) { return ntru_fail(code
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // Workgroups of 256 for an elementwise kernel.  Kernels that move 16 bytes per lane and access (streaming = true) get TWO per CU: more
 // resident waves lower the HBM rate (the add of two ciphertext batches: 5.0 TB/s with 8 per CU, 5.9 with 2, 4.8 with 1:
-// profiles/r03_ab_elementwise_grid.txt); element-per-lane kernels keep 8.  NTRU_EW_PER_CU overrides the streaming figure (experiments).
+// profiles/archive/r03_ab_elementwise_grid.txt); element-per-lane kernels keep 8.  NTRU_EW_PER_CU overrides the streaming figure (experiments).
 static inline dim3 elementwise_grid(const ntru_engine *eng, long total, bool streaming = false) {
   static const int ew_env = getenv("NTRU_EW_PER_CU") ? atoi(getenv("NTRU_EW_PER_CU")) : 0;
   const int per_cu = streaming ? (ew_env > 0 ? ew_env : 2) : 8;

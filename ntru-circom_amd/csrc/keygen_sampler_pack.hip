@@ -50,7 +50,7 @@ __global__ void k_add_mod(u32 mod, const u16 *__restrict__ a, const u16 *__restr
 // 16 per dword, laid out [word][lane]: whatever word a lane touches, it is in the lane's own bank.  13 KB per wave at
 // N = 821 -> 12 waves per CU, and the launcher asks for as much LDS as makes the resident count a MULTIPLE OF FOUR: the
 // kernel is bound by vector issue, every workgroup is one wave, and 9 waves on 4 SIMDs (what the round-2 layout with its
-// per-wave reciprocal table got) left three SIMDs idle a third of the time (profiles/r03_ablation_sampler.txt).
+// per-wave reciprocal table got) left three SIMDs idle a third of the time (profiles/archive/r03_ablation_sampler.txt).
 // i is wave-uniform: the word that holds position i stays in a register until i leaves it, u32 % (i+1) is a multiply by
 // a reciprocal floor(2^32 / d) that arrives through the scalar cache (constant table, d < 2048; an LDS table above),
 // one 24-bit multiply-subtract (the remainder is below 2d < 2^24, so the product is only needed modulo 2^24) and one
@@ -58,7 +58,7 @@ __global__ void k_add_mod(u32 mod, const u16 *__restrict__ a, const u16 *__restr
 struct ChaChaKey { u32 k[8]; };
 // A workgroup is WAVES = 4 independent waves (no barrier, private LDS regions) wherever four rows regions fit the LDS: as TWELVE
 // single-wave workgroups per CU the same kernel took 3.4 ms per 2^20 items at N = 821, as three four-wave workgroups 2.2 ms
-// (profiles/r03_ab_sampler.txt; the inversion kernel, eight single-wave workgroups per CU, does not care: more than eight workgroups
+// (profiles/archive/r03_ab_sampler.txt; the inversion kernel, eight single-wave workgroups per CU, does not care: more than eight workgroups
 // per CU do not seem to be resident together, whatever the occupancy query says).
 struct RecipTable {
   u32 v[2048];

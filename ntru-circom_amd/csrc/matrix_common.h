@@ -17,7 +17,7 @@
 // odd multiple of 16 bytes), key arrays reversed and cyclic, rev[y] = digit(sc[(32 NT - 1 - y) mod N]), in 4 byte-shifted
 // copies so that a lane's 16-byte Toeplitz fragment (which starts at an arbitrary byte) is 4 aligned dwords; each of the
 // 4 waves owns strips of <= 4 column tiles, its fragment window slides by one tile per contraction step (one new
-// fragment per step).  tools/mfma_model.py is the executable specification; profiles/r01_microbench_mfma_lds.txt holds
+// fragment per step).  tools/mfma_model.py is the executable specification; profiles/archive/r01_microbench_mfma_lds.txt holds
 // the measurements behind the layout choices.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -424,7 +424,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *p
 }
 
 // Reading rows whose pitch (N or 2N bytes, N odd) is not a multiple of 16: a per-lane 16-byte load at an unaligned
-// address runs at a fraction of the aligned rate (profiles/r01_ablation_mfma.txt: 0.8 of 2.5 ms), so rows are read as
+// address runs at a fraction of the aligned rate (profiles/archive/r01_ablation_mfma.txt: 0.8 of 2.5 ms), so rows are read as
 // ALIGNED 16-byte chunks and shifted in registers; the shift is wave-uniform because a wave stages one row at a time.
 // AlignedSrc: descriptor based at the 16-byte aligned address at or below p, a0 = p's offset in it; out-of-range
 // dwords read as zero (the range check is per dword, so the size is rounded up to whole dwords).

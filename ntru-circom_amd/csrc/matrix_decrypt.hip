@@ -523,7 +523,7 @@ int ntru_launch_decrypt_pack_matrix(ntru_engine *eng, int N, int q, int p, const
 
 // Kernel paths: 4 -> k_decrypt_m (two free-running workgroups per CU); 5 -> k_decrypt_m8 (one workgroup of two lock-step groups)
 // wherever its LDS fits; 0 = auto -> k_decrypt_m8 where a product takes two rounds of strips (N > 512) and every witness array is
-// asked for: 2.52 against 2.63 ms per 2^20 at N = 821 (profiles/r02_ab_lockstep_phase_masks.txt), 2.16 against 2.24 ms at N = 701;
+// asked for: 2.52 against 2.63 ms per 2^20 at N = 821 (profiles/archive/r02_ab_lockstep_phase_masks.txt), 2.16 against 2.24 ms at N = 701;
 // at N = 509 (one round) it is 6 % slower, and so it is without the witness arrays (shorter epilogues: 2.23 against 2.02 ms).
 // -DNTRU_EXPERIMENTS builds add 8 (k_decrypt_m8d: 5 with direct-to-LDS loads of the next row block; 1-3 % slower).
 int ntru_launch_decrypt_matrix(ntru_engine *eng, int N, int q, int p, int ld, const int8_t *d_f, const uint8_t *d_fp, const uint16_t *d_e,

@@ -203,7 +203,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
         // writes two 64-byte pieces of two rows.  v_permlane32_swap exchanges the upper half of tile t's register with the
         // lower half of tile t+1's: one register then is ONE row across both tiles, 128 contiguous bytes per store (a whole
         // cache line on rows pitched to 64 elements).  What the store path pays for is the number of lines touched, not
-        // the instruction count: 8-byte stores of four rows per lane group were 14 % SLOWER (profiles/r02_ablation_*).
+        // the instruction count: 8-byte stores of four rows per lane group were 14 % SLOWER (profiles/archive/r02_ablation_*).
         const int pv0 = 32 * kb0 + lane;                 // column of this lane in a tile pair starting at tile kb0
         auto out = [&](auto wq) {
 #pragma unroll
@@ -306,7 +306,7 @@ static __device__ __forceinline__ void encrypt_m_body(MGeom g, u32 q, const u16 
               }
               // The scalar offset is part of the vector offset: a buffer_store_dwordx4 with an SGPR soffset whose data
               // registers the NEXT instruction overwrites stores the overwritten first dword on gfx950 under load
-              // (profiles/r02_hazard_store_x4_soffset.txt); the compiler only separates the two when soffset is no
+              // (profiles/archive/r02_hazard_store_x4_soffset.txt); the compiler only separates the two when soffset is no
               // register (tests/test_build_quality.py scans the ISA for the pattern).
               {
                 __builtin_amdgcn_raw_buffer_store_b128(pv[0], rs, pvo[0], 0, ST_AUX);
@@ -659,7 +659,7 @@ int ntru_launch_encrypt_matrix(ntru_engine *eng, int N, int q, int ld, const uin
     }
   }
   // role-split kernel (one workgroup of 8 waves per CU): needs 16-byte aligned batch arrays and its LDS to fit: 1.9 ms per 2^20
-  // at N = 821 against 1.5 ms for k_encrypt_m (profiles/r02_*role_split*).
+  // at N = 821 against 1.5 ms for k_encrypt_m (profiles/archive/r02_*role_split*).
   if (eng->path == 6 && ((((uintptr_t)d_r | (uintptr_t)d_m | (uintptr_t)d_e | (uintptr_t)d_quotE) & 15) == 0)) {
     size_t lds2 = (size_t)32 * mg.tpitch + (size_t)64 * mg.pitchA;
     for (int w = 0; w < 4; w++) lds2 += (size_t)32 * m2_chunk_pitch(mg.NT, w);
@@ -682,7 +682,7 @@ int ntru_launch_encrypt_matrix(ntru_engine *eng, int N, int q, int ld, const uin
 #endif
   if (lds > 160 * 1024) return NTRU_NOT_TAKEN;
   // The default: the operands reach LDS by direct-to-LDS loads, r of the next row block ahead of the last epilogue's stores:
-  // 1.49-1.51 ms against 1.57-1.62 ms per 2^20 at N = 821 on the same device (profiles/r02_ab_direct_to_lds_rows.txt).
+  // 1.49-1.51 ms against 1.57-1.62 ms per 2^20 at N = 821 on the same device (profiles/archive/r02_ab_direct_to_lds_rows.txt).
   // One direct-to-LDS instruction moves 64 x 16 bytes from the dword at or below a row, and eight of them per thread the m
   // image: a row of (its byte phase) + N > 1024 bytes, or an image of (phase) + 32 ld > 32768 bytes, would lose its last 1-3
   // bytes.  Those shapes (N >= 1022, or ld = 1024, with rows that are not dword-aligned) take k_encrypt_m, whose register

@@ -3,7 +3,7 @@
 //
 // Why.  The result arrays are dense [B][N] rows with N odd, so no row starts on a 16-byte boundary and a tile of the accumulator
 // layout (lane = column, register = row) leaves as 2-byte stores, two 64-byte pieces per instruction: 2.4-2.7 TB/s and 260 pJ per
-// byte (profiles/r03_power_store_patterns.txt, pattern 0) -- 46 % of decrypt's and 60 % of encrypt's dynamic energy at the 1400 W
+// byte (profiles/archive/r03_power_store_patterns.txt, pattern 0) -- 46 % of decrypt's and 60 % of encrypt's dynamic energy at the 1400 W
 // cap.  But the 32 rows of a row block are ONE contiguous run of 32 * 2N bytes in every result array, and a contiguous run written
 // as aligned 16-byte pieces is the fastest and cheapest pattern there is (pattern 4: 4.9 TB/s, 135 pJ per byte).  These kernels
 // build an exact IMAGE of that run in LDS -- byte i of the image is byte i of the row block's slice of the array, shifted so that

@@ -14,7 +14,7 @@
 //   * the "window" operand b lives in LDS as EO[u] = { E[u] = (bc[2u], bc[2u+1]), O[u] = (bc[2u-1], bc[2u]) },
 //     bc = b extended cyclically with period N, so that for step i the K pairs a lane needs are K consecutive
 //     8-byte entries, and going from step i to i+2 slides that window by exactly one entry: one ds_read_b64 per
-//     lane per two steps, lane stride K entries (K odd => conflict-free, profiles/r01_microbench_valu_lds.txt).
+//     lane per two steps, lane stride K entries (K odd => conflict-free, profiles/archive/r01_microbench_valu_lds.txt).
 //   * the "broadcast" operand a is read from LDS two coefficients at a time and applied with op_sel splats.
 //   * T[k] = sum_i a[i] bc[k-i] is the cyclic product = remainder; the low half c[k] of the LINEAR product (needed
 //     for the quotient) is T's value just before the lane's own block of i plus an in-block
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_polymul_split(Geom g, u32 mod
 // Ternary-stepping kernels ("add path").
 //
 // Every product on the hot path has one TERNARY operand (r, f, g, the lifted message), and on gfx950 every packed /
-// multiply VALU op issues at 4 cycles per wave while a plain v_add_u32 issues at 2 (profiles/r01_microbench_valu_lds.txt).
+// multiply VALU op issues at 4 cycles per wave while a plain v_add_u32 issues at 2 (profiles/archive/r01_microbench_valu_lds.txt).
 // So the ternary operand becomes the stepping operand: it is turned into 2-bit codes (0 skip, 1 "+w into S1",
 // 2 "+w into S2"; the other symbol c = 2 or -1 is applied once at the end, T = S1 + c*S2), the codes of one block of
 // 2K steps live in one wave-uniform dword, zero steps are skipped by a scalar branch, and the windowed operand is
@@ -365,7 +365,7 @@ static __device__ __forceinline__ u32 step_bits(u32 v, int j) {
 }
 
 // Lane-conditional snapshot L1 <- S1, L2 <- S2 as an exec-masked block of in-place full-rate v_mov (hipcc would turn
-// plain assignments into v_cndmask, which is far slower on gfx950: profiles/r01_microbench_exec_rate.txt).
+// plain assignments into v_cndmask, which is far slower on gfx950: profiles/archive/r01_microbench_exec_rate.txt).
 template <int K>
 static __device__ __forceinline__ void snapshot_if(bool take, u32 (&L1)[K], u32 (&L2)[K], const u32 (&S1)[K],
                                                    const u32 (&S2)[K]) {
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_decrypt_t(Geom g, u32 q, u32 
 // Shared-stepping add path (decrypt).  Both products of decryptBits can step over a SHARED key operand (f, then fp),
 // so every wave of the launch follows the same step masks.  That allows two items per wave (32 lanes x K pairs each,
 // K = 9 / 11 / 13) under one scalar control stream -- the scalar unit, not the VALU, is what limits the add path
-// (profiles/r01_microbench_step_rate.txt).  The per-item operand (e, then the lifted message) is the window; it is kept
+// (profiles/archive/r01_microbench_step_rate.txt).  The per-item operand (e, then the lifted message) is the window; it is kept
 // in LDS as ONE cyclic array of aligned pairs E[u] = (bc[2u], bc[2u+1]); the odd-aligned pairs are derived on the fly,
 // O[u] = alignbit(E[u], E[u-1], 16).  N must be odd (so that the cyclic wrap turns aligned pairs into odd-aligned ones).
 // ================================================================================================================

@@ -47,7 +47,7 @@ def test_no_kernel_spills_to_scratch(build):
 
 @pytest.mark.parametrize("build", sorted(BUILDS))
 def test_no_wide_store_followed_by_a_write_of_its_data_registers(build):
-    """gfx950, measured (profiles/r02_hazard_store_x4_soffset.txt): a buffer_store_dwordx4 whose data registers the very next
+    """gfx950, measured (profiles/archive/r02_hazard_store_x4_soffset.txt): a buffer_store_dwordx4 whose data registers the very next
     instruction overwrites can store the NEW value of the first dword when the memory pipe is busy.  The compiler separates
     the two only when the store's soffset is not a register, so the kernels never pass a scalar offset to their 16-byte
     stores; this scans the generated ISA of every kernel translation unit for the pattern."""

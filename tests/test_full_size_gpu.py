@@ -210,7 +210,7 @@ def test_config4_encrypt_2e20(ctx):
         eng.encrypt_batch_dev(n, q, h.data_ptr(), r.data_ptr(), m1.data_ptr(), B, e.data_ptr(), qe.data_ptr())
         torch.cuda.synchronize()
         if path >= 5:        # direct-to-LDS operand loads / chunked 16-byte stores: twice each -- the store hazard of
-            # profiles/r02_hazard_store_x4_soffset.txt only showed at this size, and the early row loads rest on completion order
+            # profiles/archive/r02_hazard_store_x4_soffset.txt only showed at this size, and the early row loads rest on completion order
             assert eng.last_kernel() == {5: "k_encrypt_md", 7: "k_encrypt_mc"}[path]
             assert torch.equal(e, res[4][0]) and torch.equal(qe, res[4][1])
         else:

@@ -1,5 +1,5 @@
 """More than one rank on the HIP kernels.  The GPU box has ONE device and RCCL refuses two ranks on one device
-("Duplicate GPU detected", profiles/r02_rccl_2ranks_1gpu_refused.txt), so the two-rank runs use gloo with both ranks on device
+("Duplicate GPU detected", profiles/archive/r02_rccl_2ranks_1gpu_refused.txt), so the two-rank runs use gloo with both ranks on device
 0: the sharding, the launch path of bench.py, the barrier / max-over-ranks timing and the gather-to-root all execute with
 world_size 2 around the real kernels.  RCCL itself runs as a one-rank process group (--force-dist)."""
 import json
