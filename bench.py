@@ -184,15 +184,16 @@ def make_inputs(torch, dev, B, N, d, seed, ld=None):
     return r, m
 
 
-def generate_key_pairs(torch, eng, dev, o, B, first_item, max_redraws=8):
+def generate_key_pairs(torch, eng, dev, o, B, first_item, max_redraws=8, first_draw_minus=None):
     """B TRUE key pairs on the device (index.js:51-79): f, g from the on-device sampler (generateCustomArray's
     shuffle on a ChaCha20 stream: df ones and df - 1 minus ones / dg and dg), fq = f^-1 mod q and fp = f^-1 mod p from
     ntru_invert_key_batch_dev, h = p fq g from ntru_public_key_batch_dev.  Rows whose f is not a unit are drawn again (the
-    reference's generatePrivateKeyF retries the same way, index.js:51-66).  Returns (f, g, fq, fp, h, info)."""
+    reference's generatePrivateKeyF retries the same way, index.js:51-66).  Returns (f, g, fq, fp, h, info).
+    first_draw_minus (tests): minus ones of the FIRST draw only -- df of them make f(1) = 0, i.e. every first draw a non-unit."""
     N, q, p, df, dg = o["N"], o["q"], o["p"], o["df"], o["dg"]
     key = (np.arange(8, dtype=np.uint32) * 0x85EBCA6B + 7).astype(np.uint32)
     fs = torch.empty((B, N), dtype=torch.uint8, device=dev); gs = torch.empty((B, N), dtype=torch.uint8, device=dev)
-    eng.sample_ternary_dev(N, df, df - 1, 255, key, first_item, B, fs.data_ptr())                    # 255 = -1 as int8
+    eng.sample_ternary_dev(N, df, df - 1 if first_draw_minus is None else first_draw_minus, 255, key, first_item, B, fs.data_ptr())   # 255 = -1 as int8
     eng.sample_ternary_dev(N, dg, dg, 255, key, (1 << 40) + first_item, B, gs.data_ptr())
     f, g = fs.view(torch.int8), gs.view(torch.int8)
     fq = torch.empty((B, N), dtype=torch.int16, device=dev); fp = torch.empty((B, N), dtype=torch.uint8, device=dev)

@@ -365,3 +365,19 @@ def test_config5_true_keys_generated_on_the_device(ctx):
     assert ok
     for name, t in zip(names, arrs):
         assert np.array_equal(_host(t, rows), want[name]), name
+
+
+def test_generated_keys_redraw_non_units(ctx):
+    """bench.generate_key_pairs draws a private key again when its f is not a unit (index.js:51-66 retries the same way).  With
+    N = 821 that practically never happens, so the path is forced: a FIRST draw with df minus ones has f(1) = 0 -- no unit anywhere --
+    and every row must come out valid after one redraw with the reference's weights."""
+    import bench
+    torch, eng, dev = ctx
+    for profile, B in (("n167_q128", 300), ("n821_q4096", 1000)):
+        o, _, _, _ = bench.load_key(profile)
+        n, q, p = o["N"], o["q"], o["p"]
+        f, g, fq, fp, h, info = bench.generate_key_pairs(torch, eng, dev, o, B, 7, first_draw_minus=o["df"])
+        assert info["non_units_redrawn"] >= B                               # every first draw was rejected
+        assert bool(((f == 1).sum(1) == o["df"]).all()) and bool(((f == -1).sum(1) == o["df"] - 1).all())
+        ok, want = bench.check_keys_against_oracle(orc, n, q, p, [_host(t, slice(None)) for t in (f, g, fq, fp, h)])
+        assert ok and not want["flags"].any()
