@@ -1,5 +1,6 @@
 // Probe: v_cndmask_b32 with a DPP wave shift on gfx950 -- lane l takes lane l - 1's value, lanes 0 and 32 (VCC) take the second operand.
-// The building block of "chunk rows moved down one row per step in registers" (measured slower than the LDS reads).
+// The building block of round 3's "chunk rows moved down one row per step in registers" (a new row ENTERS at lanes 0 and 32 each step:
+// measured slower than the LDS reads).  Round 5 walks the distances so that nothing enters (bench_micro/peritem_step.hip): that form is the product's.
 // hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -o dpp_shift_probe dpp_shift_probe.hip
 #include <hip/hip_runtime.h>
 typedef int v4i __attribute__((ext_vector_type(4)));

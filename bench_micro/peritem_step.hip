@@ -1,5 +1,5 @@
 // Probe for the per-item matrix loops (k_verify_keys_m and friends, csrc/matrix_peritem.hip): what ONE contraction step costs when
-// the chunk rows (the MFMA A operand) are (a) read from LDS every step, as today, or (b) kept in registers and moved one row per
+// the chunk rows (the MFMA A operand) are (a) read from LDS every step, as the kernels did until round 5, or (b) kept in registers and moved one row per
 // step with ONE v_and_b32_dpp per dword (wave_shr / wave_shl + a lane mask that cuts the half-wave seam), and when NPL planes share
 // one Toeplitz fragment read.  No HBM traffic, operands random bytes; the loop shape (26 low + 25 high steps + split diagonal,
 // compile-time offsets) is the product's.  Prints SIMD clocks per step at 1-3 waves per SIMD.

@@ -64,6 +64,7 @@ static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 m
 // entering at lane 0 every step through a small LDS read and v_cndmask_b32_dpp: slower than reading the rows.]  The loops' LDS
 // traffic is the fragment reads alone, shared by every plane that multiplies the same Toeplitz operand: 1 KB per step for the three
 // planes of products 1 and 2 (fq lo / hi and fp against f) where the LDS-row form read 5 KB.  bench_micro/peritem_step.hip is the probe.
+
 // A fresh copy of a lane-dependent value that the compiler cannot trace back: everything derived from it is computed where it is used,
 // instead of being hoisted out of the item loop (per-lane addresses and masks of every phase: dozens of registers live for ever, i.e.
 // spilled at three waves per SIMD).
