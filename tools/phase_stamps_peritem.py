@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of one item in k_polymul_m from a -DNTRU_STAMPS build (diagnostic, never shipped):
+"""Phase timeline of one item in k_verify_keys_m and k_polymul_m from a -DNTRU_STAMPS build (diagnostic, never shipped):
      make -C ntru-circom_amd/csrc EXTRA=-DNTRU_STAMPS OBJDIR=../lib/ab/obj_stamps OUT=../lib/ab/libntru_stamps.so
      NTRU_ENGINE_LIB=$PWD/ntru-circom_amd/lib/ab/libntru_stamps.so python tools/phase_stamps_peritem.py
 Median duration of each phase (shader clocks of s_memtime) over workgroups x waves for the 3rd-5th item of every wave."""
@@ -15,8 +15,8 @@ dev = torch.device("cuda:0")
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 N, B = 821, 1 << 16
 buf = np.zeros((1024, 8, 6, 24), np.uint64)
-labels = [(0, 1, "operands arrive + shift"), (1, 2, "digit planes"), (2, 3, "reversed arrays"), (3, 4, "chunk matrices + fence"),
-          (4, 5, "matrix loops"), (5, 6, "result stores issued + fence")]
+labels = [(0, 1, "operands arrive + shift"), (1, 2, "digit planes"), (2, 3, "reversed arrays"), (3, 4, "matrix loops"),
+          (4, 5, "result stores issued + fence")]
 def show(name, st, labels, last):
     print("==", name)
     for it in (2, 3, 4):
