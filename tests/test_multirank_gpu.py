@@ -191,3 +191,15 @@ def test_bench_exits_non_zero_when_the_process_group_does_not_come_up():
                           env=env, timeout=300)
     assert proc.returncode != 0 and not proc.stdout.strip()
     assert b"did not come up" in proc.stderr or b"Duplicate GPU" in proc.stderr
+
+
+def test_bench_four_ranks_report_each_rank():
+    """Four ranks (gloo, all on device 0: the box has one GPU and allows six processes on it) through the same launcher the 8-GPU run
+    uses: the line carries four rank records with distinct pids, each with its own time and kernel times, and the whole-job value."""
+    d = _run_bench(["--gpus", "4", "--dist-backend", "gloo", "--device", "0", "--batch-log2", "14", "--power-seconds", "0"])
+    ranks = d["dist"]["ranks"]
+    assert d["n_gpus"] == 4 and [r["rank"] for r in ranks] == [0, 1, 2, 3] and len({r["pid"] for r in ranks}) == 4
+    assert all(r["ms_per_step"] > 0 and r["items_per_step"] == 1 << 14 and len(r["kernels_ms"]) == 2 for r in ranks)
+    assert d["dist"]["straggler"]["ms_per_step_max"] <= d["ms_per_step"] * 1.0001
+    assert d["gather"]["ranks"] == 4 and d["gather"]["rows"] == 4 << 14 and d["gather"]["every_shard_checksum_matches_its_owner"]
+    assert abs(d["value"] - 4 * (1 << 14) / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

@@ -32,7 +32,7 @@ def _worker(rank, world, port, q_out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import ntru_oracle as orc
-        N, q, d, total = 17, 32, 2, 10
+        N, q, d, total = 17, 32, 2, 12                      # equal shards for world 2 and 4: gather_rows takes equal rows per rank
         rng = np.random.default_rng(3)                      # same global batch on every rank
         h = rng.integers(0, q, N)
         r = np.zeros((total, N), np.uint8)
@@ -64,17 +64,20 @@ def _worker(rank, world, port, q_out):
         dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather_matches_single_process():
+@pytest.mark.parametrize("world", [2, 4])
+def test_shard_and_gather_over_gloo_matches_single_process(world):
+    """world_size 2 and 4 over gloo on the CPU: shard ranges, max-over-ranks timing, per-rank reports with the straggler named, checksums
+    and the gather-to-root -- the plumbing bench.py runs over RCCL with one rank per GPU."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q_out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q_out)) for r in range(world)]
     [p.start() for p in procs]
-    res = q_out.get(timeout=120)
+    res = q_out.get(timeout=180)
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     same, slow, ok, span = res
-    assert same and slow == 2.0 and ok and span == (0, 5)
+    assert same and slow == float(world) and ok and span == sh.shard_range(12, 0, world)
 
 
 # ---- bench.py's own launch logic (no GPU, no torch.distributed needed) -------------------------------------------------
