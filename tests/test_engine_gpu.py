@@ -762,6 +762,39 @@ def test_verify_keys_matrix_core_kernel_sweep(eng):
     assert eng.last_kernel() == "k_verify_keys_m"
 
 
+def test_verify_keys_h_comparison_boundaries_and_unreduced_fp(eng):
+    """index.js:165 compares h with the remainder below h's TRIMMED length: the kernel finds h's last non-zero coefficient and its
+    first difference from the remainder (one ballot + one v_readlane each) -- exercised at the boundaries: h equal to the remainder,
+    truncated at every kind of position (chunk and lane boundaries, 0, 1, N - 1), a single coefficient changed below / at / above
+    the top, the zero polynomial.  fp arrives unreduced (bytes 0..255: the byte-wise mod 3 behind the wave-wide test)."""
+    rng = np.random.default_rng(77)
+    p = 3
+    for N, q in ((821, 4096), (509, 2048), (64, 8192), (1024, 4096), (167, 128)):
+        d = N // 3
+        cuts = sorted({0, 1, 2, 15, 16, 17, 31, 32, 33, 255, 256, 257, N // 2, N - 17, N - 16, N - 2, N - 1, N} & set(range(N + 1)))
+        B = 4 * len(cuts) + 2
+        f = ternary_rows(rng, B, N, d, max(d - 1, 0), two=-1); g = ternary_rows(rng, B, N, d, d, two=-1)
+        fq = rng.integers(0, q, (B, N)); fp = rng.integers(0, 256, (B, N))
+        base = eng.verify_keys_batch(N, q, p, f, g, fq, fp % 3, np.zeros((B, N), np.int64))
+        rem = base["rem_h"].astype(np.int64)
+        h = rem.copy()
+        for i, c in enumerate(cuts):
+            h[4 * i, c:] = 0                                   # truncated at c: equal below its own length -> valid
+            h[4 * i + 1, c:] = 0
+            if c > 0: h[4 * i + 1, rng.integers(0, c)] ^= 1     # ... with one coefficient below the cut changed
+            h[4 * i + 2, min(c, N - 1)] = (h[4 * i + 2, min(c, N - 1)] + 1) % q     # one coefficient changed, everything else equal
+            h[4 * i + 3, c:] = 0
+            if c < N: h[4 * i + 3, rng.integers(c, N)] = 1      # a lone non-zero coefficient above a matching prefix
+        h[B - 1] = 0                                          # the zero polynomial: length 1, compares index 0
+        got = eng.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+        want = orc.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (N, q, k, np.nonzero(got[k] != want[k]))
+        assert (want["flags"][0::4][1:len(cuts)] & 4 == 0).all()            # the truncated copies are valid h (cut 0 = the zero
+                                                                             # polynomial, which still compares index 0)
+        assert np.array_equal(got["rem_fp"], base["rem_fp"])                 # unreduced fp = reduced fp
+
+
 def test_verify_keys_device_pointers_at_any_alignment(eng):
     """ntru_verify_keys_batch_dev with every array at an odd byte offset (uint16 arrays stay 2-aligned): the matrix-core
     kernel reads rows through aligned chunks + shifts and must neither read garbage nor write outside its rows."""
