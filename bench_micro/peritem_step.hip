@@ -109,6 +109,74 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// ---- the same work on the 16-row tile (v_mfma_i32_16x16x64_i8: two distances per instruction, two 16-column halves) -------------------
+// Output tiles in two row groups of 16 (NT = 26: rows 0-15, 16-25); a (group, distance pair) is issued only while it has rows in range:
+// low part pairs (0,1) .. (24,25): group 0 for the first 8, group 1 for all 13; high part: group 0 for all 13, group 1 for the first 5
+// -> 78 instructions of 16 clocks per plane instead of 52 of 32.  Lane (row, kq): kq 0,1 = the two K halves of distance d, kq 2,3 of
+// distance d + 1 (one row further): a pair step moves every 16-lane row by TWO rows (row_shr:2); group 1 takes its entering rows
+// from group 0's top two (row_ror:2 as the `old` operand): 3 lane shifts per dword and pair step, no seam mask.
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+template <int NPL>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_steps16(int iters, const int *__restrict__ seed, int *__restrict__ out, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
+  unsigned char *base = lds + (size_t)wave * lds_per_wave;
+  u32 *T = (u32 *)base;
+  unsigned char *fa = base + T_BYTES;
+  for (int i = lane; i < lds_per_wave / 4; i += 64) ((u32 *)base)[i] = (u32)seed[(i + 64 * wave) & 1023];
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  // fragment of distance pair starting at d, column half c: byte position as in the 32-wide scheme with column 16 c + col, K half kq & 1,
+  // distance d + (kq >> 1)
+  auto frag = [&](int d, int c) {
+    const int y = 32 * NT - 1 - (16 * c + col) + 16 * (kq & 1) - 32 * (d + (kq >> 1)) + 32 * NT;      // (+32 NT: positive for every d in range)
+    const u32 *p = T + (y & 3) * TPITCH + ((y >> 2) % (TPITCH - 4));
+    return (v4i){(int)p[0], (int)p[1], (int)p[2], (int)p[3]};
+  };
+  auto rows0 = [&](int p, int g) { return *(const v4i *)(fa + p * FA_BYTES + 32 * PAD + 32 * (16 * g + col - (kq >> 1)) + 16 * (kq & 1)); };
+  auto shift2 = [&](v4i &g0, v4i &g1) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int enter = __builtin_amdgcn_update_dpp(0, g0[c], 0x122, 0xf, 0xf, false);        // row_ror:2: lanes 0, 1 <- lanes 14, 15
+      g1[c] = __builtin_amdgcn_update_dpp(enter, g1[c], 0x112, 0xf, 0xf, false);              // row_shr:2, lanes 0, 1 keep `enter`
+      g0[c] = __builtin_amdgcn_update_dpp(0, g0[c], 0x112, 0xf, 0xf, true);                   // row_shr:2, zeros enter
+    }
+  };
+  v4i acc[NPL][2][2][2];                                   // [plane][low / high][group][column half]
+  for (int p = 0; p < NPL; p++) for (int h = 0; h < 2; h++) for (int g = 0; g < 2; g++) for (int c = 0; c < 2; c++) acc[p][h][g][c] = (v4i){0, 0, 0, 0};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {                          // low part, then high part (the shift direction does not matter to the probe)
+      v4i A[NPL][2];
+#pragma unroll
+      for (int p = 0; p < NPL; p++) { A[p][0] = rows0(p, 0); A[p][1] = rows0(p, 1); }
+      v4i w0 = frag(0, 0), w1 = frag(0, 1);
+#pragma unroll
+      for (int pr = 0; pr < 13; pr++) {
+        const v4i c0 = w0, c1 = w1;
+        w0 = frag(2 * pr + 2, 0); w1 = frag(2 * pr + 2, 1);
+        const bool g0_on = h == 0 ? pr < 8 : true, g1_on = h == 0 ? true : pr < 5;
+#pragma unroll
+        for (int p = 0; p < NPL; p++) {
+          if (g0_on) {
+            acc[p][h][0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p][0], c0, acc[p][h][0][0], 0, 0, 0);
+            acc[p][h][0][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p][0], c1, acc[p][h][0][1], 0, 0, 0);
+          }
+          if (g1_on) {
+            acc[p][h][1][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p][1], c0, acc[p][h][1][0], 0, 0, 0);
+            acc[p][h][1][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p][1], c1, acc[p][h][1][1], 0, 0, 0);
+          }
+          shift2(A[p][0], A[p][1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  int s = 0;
+  for (int p = 0; p < NPL; p++) for (int h = 0; h < 2; h++) for (int g = 0; g < 2; g++) for (int c = 0; c < 2; c++) for (int i = 0; i < 4; i++) s ^= acc[p][h][g][c][i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_sem(int *out) {
   const int lane = threadIdx.x;
   v4i a = {100 + lane, 0, 0, 0}, mup, mdn;
@@ -140,7 +208,26 @@ static void run(int cus, const int *d_seed, int *d_out) {
   }
 }
 
-int main() {
+template <class K>
+static void sustain(const char *name, K kern, int cus, int wps, double seconds, const int *d_seed, int *d_out, double mfma_clocks_per_iter) {
+  const int lds_per_wave = T_BYTES + 3 * FA_BYTES, iters = 200, blocks = cus * 2 * wps;
+  CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_per_wave));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), 2 * lds_per_wave, 0, 2, d_seed, d_out, lds_per_wave);
+  CK(hipDeviceSynchronize());
+  double total_ms = 0; long n = 0;
+  while (total_ms < seconds * 1e3) {
+    CK(hipEventRecord(e0));
+    for (int k = 0; k < 10; k++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), 2 * lds_per_wave, 0, iters, d_seed, d_out, lds_per_wave);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); total_ms += ms; n += 10;
+  }
+  const double ms = total_ms / n, products = (double)iters * blocks * 2;      // one "product set" (all planes) per iteration and wave
+  printf("%s waves/SIMD %d: %.3f ms per launch = %.2f ns per product set and CU; matrix pipe %.0f %% (at 2.4 GHz)\n", name, wps, ms,
+         ms * 1e6 / (products / cus), 100.0 * iters * wps * mfma_clocks_per_iter / (ms * 1e-3 * 2.4e9));
+}
+
+int main(int argc, char **argv) {
   CK(hipSetDevice(0));
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
@@ -149,6 +236,13 @@ int main() {
   int *d_seed, *d_out;
   CK(hipMalloc(&d_seed, 4096)); CK(hipMemcpy(d_seed, h.data(), 4096, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_out, (size_t)cus * 8 * 128 * 4));
+  if (argc > 1) {            // sustained mode for tools/power_sample.py: peritem_step <32|16> <waves per SIMD> <seconds>   (three planes, one fragment stream)
+    char pci[64]; CK(hipDeviceGetPCIBusId(pci, sizeof pci, 0)); printf("pci_bus_id %s\n", pci); fflush(stdout);
+    const int wps = argc > 2 ? atoi(argv[2]) : 2; const double sec = argc > 3 ? atof(argv[3]) : 3.0;
+    if (atoi(argv[1]) == 16) sustain("16x16x64, rows in registers", k_steps16<3>, cus, wps, sec, d_seed, d_out, 3 * 78 * 16.0);
+    else sustain("32x32x32, rows in registers", k_steps<3, 3>, cus, wps, sec, d_seed, d_out, 3 * 52 * 32.0);
+    return 0;
+  }
   {                                                        // semantics of the two shifts
     hipLaunchKernelGGL(k_sem, dim3(1), dim3(64), 0, 0, d_out);
     int o[128]; CK(hipMemcpy(o, d_out, sizeof o, hipMemcpyDeviceToHost));

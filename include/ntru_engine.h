@@ -83,8 +83,9 @@ int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream);
  * whose matrix-loop and epilogue phases are interleaved by barriers (k_decrypt_m8; k_decrypt_m where 160 KB of LDS do not hold
  * two groups), encrypt with direct-to-LDS operand loads (k_encrypt_md; k_encrypt_m for rows that do not fit one such
  * instruction).  0 picks k_encrypt_md and, for N > 512 with every witness array, k_decrypt_m8.  Results are identical on every
- * path.  Paths 6-11 (role-split / chunked-store / lock-step / row-image encrypt, direct-to-LDS decrypt, decrypt with an fp4 second product: built,
- * bit-exact, measured slower or equal; path 11's timing includes 52-80 bytes per lane of scratch spills outside its loops)
+ * path.  Paths 6-12 (role-split / chunked-store / lock-step / row-image encrypt, direct-to-LDS decrypt, decrypt with an fp4 second product,
+ * verify_keys on the 16-row matrix tile: built, bit-exact, measured slower or equal; the timings of paths 11 and 12 include scratch spills
+ * outside their loops)
  * exist only in a library built with -DNTRU_EXPERIMENTS (`make -C ntru-circom_amd/csrc experiments`); this call refuses them
  * otherwise.
  * Streams: the *_dev calls that need temporaries (key inversion, the generic family) share one engine-owned scratch buffer.

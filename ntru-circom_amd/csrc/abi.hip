@@ -154,7 +154,7 @@ extern "C" int ntru_engine_set_stream(ntru_engine_t *eng, void *hip_stream) {
 }
 
 #ifdef NTRU_EXPERIMENTS
-static const int kMaxKernelPath = 11;
+static const int kMaxKernelPath = 12;
 #else
 static const int kMaxKernelPath = 5;
 #endif
@@ -164,7 +164,7 @@ extern "C" int ntru_engine_set_kernel_path(ntru_engine_t *eng, int path) {
   if (path < 0 || path > kMaxKernelPath)
     return fail(NTRU_ERR_ARG, "kernel path must be 0 (auto), 1 (MAC), 2 (add), 3 (add without dot8), 4 (matrix cores, two workgroups per CU) or "
                               "5 (matrix cores, lock-step decrypt); 6 (role-split encrypt), 7 (chunked encrypt stores), 8 (direct-to-LDS decrypt), "
-                              "9 (lock-step encrypt), 10 (row-image encrypt) and 11 (decrypt with an fp4 second product) exist only in a library built with -DNTRU_EXPERIMENTS (make experiments)");
+                              "9 (lock-step encrypt), 10 (row-image encrypt), 11 (decrypt with an fp4 second product) and 12 (verify_keys on the 16-row matrix tile) exist only in a library built with -DNTRU_EXPERIMENTS (make experiments)");
   eng->path = path;
   return NTRU_OK;
 }

@@ -472,6 +472,356 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(2
   }
 }
 
+#ifdef NTRU_EXPERIMENTS
+// ---- EXPERIMENT (kernel path 12, `make experiments` only): the same kernel on the 16-row tile, v_mfma_i32_16x16x64_i8 (K = 64: TWO tile
+// distances per instruction, two 16-column halves).  Bit-exact, measured SLOWER: 2.49 against 2.07 ms per 2^18 key pairs on one device
+// (EXPERIMENTS.md round 5, item 9): its loop issues 0.73x the matrix clocks but 1.5x the vector instructions around them (17-20 k against
+// 12.5 k clocks per key pair), and its result stores leave as 32-byte segments, four per instruction (epilogues 11 k against 6.4 k). ----
+// With 32 rows per instruction only NT - |d| of them carry data (41 % at N = 821) and the instruction costs what it costs whatever its
+// rows hold (bench_micro/mfma_rows_energy: 18.5 nJ with 32 live rows, 16.8 with 13, 15.3 with none).  With 16 rows the output tiles
+// form two row groups (kb = 16 g + m) and a (group, distance pair) is only issued while it holds rows: per plane 78 instructions of 16
+// clocks instead of 52 of 32 at NT = 26, HALF the matrix clocks for NT <= 16 (tools/peritem_mfma_model.py replays the scheme lane for
+// lane).  Lane l = (m, kq), m = l & 15, kq = l >> 4: kq 0, 1 hold the two 16-byte K halves of the pair's first distance, kq 2, 3 of its
+// second, i.e. of the chunk one row further.
+//   low walk, pairs (0, 1), (2, 3), ...:   A = chunk kb - d - (kq >> 1); a pair step moves every 16-lane row by two rows (row_shr:2),
+//                                           group 1 takes its two entering rows from group 0's top two (row_ror:2 as the DPP `old`);
+//   high walk, pairs (0h, -1), (-2, -3), ..: A = chunk kb + e + (kq >> 1); row_shl:2, group 0 takes its entering rows from group 1.
+// No seam masks (row operations stay inside 16 lanes).  The planes reach this layout through a natural-order byte image in the LDS
+// (chunks -1 .. 33, zero outside the operand): six 16-byte reads per walk.  Accumulators [low / high][group][column half] x 4 registers:
+// 160 for the five plane products, as before.  Result index of register j of lane (n, rq): 32 (16 g + 4 rq + j) + 16 c + n.
+constexpr int PI16_PLANE = 35 * 32;                         // bytes of one plane's image: chunks -1 .. 33
+static __host__ __device__ inline size_t pi_verify16_area(const PGeom &g) {
+  const size_t a = pi_nat_bytes(g), b = (3 * PI16_PLANE + 15) & ~(size_t)15;
+  return a > b ? a : b;
+}
+static __host__ __device__ inline size_t pi_verify16_wave_bytes(const PGeom &g) { return pi_verify16_area(g) + (size_t)32 * g.tpitch; }
+
+__global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_verify_keys_m16(
+    PGeom g, u32 q, const int8_t *__restrict__ f, const int8_t *__restrict__ gg, const u16 *__restrict__ fq,
+    const uint8_t *__restrict__ fp, const u16 *__restrict__ h, long B, u16 *__restrict__ quot_fq,
+    u16 *__restrict__ rem_fq, uint8_t *__restrict__ quot_fp, uint8_t *__restrict__ rem_fp, u16 *__restrict__ quot_h,
+    u16 *__restrict__ rem_h, uint8_t *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char *nat = lds + (size_t)wave * pi_verify16_wave_bytes(g);
+  u32 *Tf = (u32 *)(nat + pi_verify16_area(g)), *Tg = Tf + 4 * g.tpitch;
+  const int N = g.N, NT = g.NT;
+  const long item_step = (long)gridDim.x * PI_WAVES;
+  RawChunks<2> r_fq;
+  RawChunks<1> r_f, r_fp, r_g;
+  auto request_rows = [&](long it) {                       // natural lane order: lane l holds coefficients 16 l .. 16 l + 15 (one-row descriptors)
+    const long row = it * N;
+    const int ln = opaque(lane);
+    const AlignedSrc s_fq = aligned_src(fq + row, 2L * N), s_f = aligned_src(f + row, (long)N), s_fp = aligned_src(fp + row, (long)N),
+                     s_g = aligned_src(gg + row, (long)N);
+    r_fq = load_raw<2>(s_fq, s_fq.a0 + 32 * ln, 0); r_f = load_raw<1>(s_f, s_f.a0 + 16 * ln, 0);
+    r_g = load_raw<1>(s_g, s_g.a0 + 16 * ln, 0); r_fp = load_raw<1>(s_fp, s_fp.a0 + 16 * ln, 0);
+  };
+  if ((long)blockIdx.x * PI_WAVES + wave < B) request_rows((long)blockIdx.x * PI_WAVES + wave);
+  [[maybe_unused]] int stamp_iter = -1;
+  for (long item = (long)blockIdx.x * PI_WAVES + wave; item < B; item += item_step) {
+    const long row = item * N;
+    u32 fl = 0;
+    stamp_iter++;
+    STAMP(0);
+    auto bytes_of = [&](const RawChunks<1> &rw, const void *p) {
+      v4i v[1];
+      shift_raw<1>(rw, __builtin_amdgcn_readfirstlane((int)((unsigned long long)p & 15)), v);
+      return v[0];
+    };
+    auto ternary = [&](v4i v, const v4i &cmask) {          // any negative byte is -1 (ValTernary), bytes at and beyond N are zero
+      v4i o;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const u32 w = (u32)(v[c] & cmask[c]);
+        o[c] = (int)(w | ((w >> 7) & 0x01010101u) * 0xFFu);
+      }
+      return o;
+    };
+    // ---- operands: the reversed arrays of f and g; then the planes fq lo / fq hi / fp mod 3 as natural-order byte images
+    {
+      const int ln = opaque(lane);
+      const v4i cmask = col_mask16(16 * ln, N);
+      pi_build_array_ch(nat, Tf, g, lane, ln, ternary(bytes_of(r_f, f + row), cmask));
+      pi_build_array_ch(nat, Tg, g, lane, ln, ternary(bytes_of(r_g, gg + row), cmask));
+      STAMP(1);
+      u32 xq[8];
+      {
+        v4i v[2];
+        shift_raw<2>(r_fq, __builtin_amdgcn_readfirstlane((int)((unsigned long long)(fq + row) & 15)), v);
+#pragma unroll
+        for (int c = 0; c < 4; c++) { xq[c] = (u32)v[0][c]; xq[4 + c] = (u32)v[1][c]; }
+      }
+      v4i d0, d1;
+      pi_digits(xq, q, 1u, 16 * ln, N, d0, d1);
+      union { v4i v; unsigned char c[16]; } u; u.v = bytes_of(r_fp, fp + row) & cmask;
+      u32 big = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) big |= ((((u32)u.v[c] & 0x7F7F7F7Fu) + 0x7D7D7D7Du) | (u32)u.v[c]) & 0x80808080u;
+      if (__ballot(big != 0) != 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) u.c[j] = (unsigned char)((u32)u.c[j] % 3u);
+      }
+      // chunk ch lies at byte 32 (ch + 1) of its plane: the 64 lanes fill chunks 0 .. 31 (zeros at and beyond N); chunks -1, 32, 33
+      // were overwritten by the arrays' staging and are zeroed again (18 lanes)
+      *(v4i *)(nat + 0 * PI16_PLANE + 32 + 16 * ln) = d0;
+      *(v4i *)(nat + 1 * PI16_PLANE + 32 + 16 * ln) = d1;
+      *(v4i *)(nat + 2 * PI16_PLANE + 32 + 16 * ln) = u.v;
+      if (ln < 18) {
+        const int pl = ln / 6, k6 = ln - 6 * pl;           // per plane: bytes 0 .. 31 and 1056 .. 1119 = six 16-byte pieces
+        *(v4i *)(nat + pl * PI16_PLANE + (k6 < 2 ? 16 * k6 : 1056 + 16 * (k6 - 2))) = (v4i){0, 0, 0, 0};
+      }
+      wave_lds_fence();
+    }
+    STAMP(2);
+    // ---- the two walks.  acc1 / acc3: [plane][low, high][group][column half] for fq * f / fq * g; acc2: fp * f
+    v4i acc1[2][2][2][2], acc2[2][2][2], acc3[2][2][2][2];
+    {
+      const int ln = opaque(lane), n = ln & 15, kq = ln >> 4;
+      const v4i zero4 = {0, 0, 0, 0};
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b_ = 0; b_ < 2; b_++)
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            acc2[a][b_][c] = zero4;
+#pragma unroll
+            for (int p = 0; p < 2; p++) { acc1[p][a][b_][c] = zero4; acc3[p][a][b_][c] = zero4; }
+          }
+      // this lane's fragment of f, column half 0, distance 0 (half 1: 4 dwords below; distance d: 8 d dwords below; g: 4 tpitch dwords above)
+      const int y0 = 32 * NT - 1 - n + 16 * (kq & 1);
+      const u32 *tb = Tf + (y0 & 3) * g.tpitch + (y0 >> 2);
+      const int tstep = 4 * g.tpitch;
+      struct Fr { v4i f[2], g[2]; };                       // fragments of one distance pair: [column half]
+      const int pairs = (NT + 1) >> 1;
+      auto walk = [&](auto high_tag) {
+        constexpr bool HIGH = decltype(high_tag)::value;
+        const u32 *tw = HIGH ? tb + 8 * (kq >> 1) : tb - 8 * (kq >> 1);          // the lane's second-distance offset folded in
+        auto frag = [&](int pr) {
+          pr = pr < pairs ? pr : pairs - 1;                // requests past the last pair read it again (never used)
+          const u32 *p = HIGH ? tw + 16 * pr : tw - 16 * pr;
+          Fr fr;
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const u32 *pc = p - 4 * c, *pg = pc + tstep;
+            fr.f[c] = (v4i){(int)pc[0], (int)pc[1], (int)pc[2], (int)pc[3]};
+            fr.g[c] = (v4i){(int)pg[0], (int)pg[1], (int)pg[2], (int)pg[3]};
+          }
+          return fr;
+        };
+        // rows of the planes in the walk's layout: chunk 16 g + m -+ (kq >> 1), K half kq & 1
+        v4i A[3][2];
+        {
+          const int chunk = (ln & 15) + (HIGH ? (kq >> 1) : -(kq >> 1));
+#pragma unroll
+          for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int gr = 0; gr < 2; gr++) A[p][gr] = *(const v4i *)(nat + p * PI16_PLANE + 32 * (16 * gr + chunk + 1) + 16 * (kq & 1));
+        }
+        Fr fa = frag(0), fb;
+        {                                                  // the pair with distance 0: only its low (high) part counts on lanes kq < 2:
+#pragma unroll                                             // byte j of column half c is LOW iff 16 c + n >= 16 (kq & 1) + j
+          for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+              const int cnt = min(max(16 * c + n - 16 * (kq & 1) + 1 - 4 * w, 0), 4);
+              const u32 ml = cnt >= 4 ? 0xFFFFFFFFu : ((1u << (8 * cnt)) - 1u);
+              const u32 keep = kq >= 2 ? 0xFFFFFFFFu : (HIGH ? ~ml : ml);
+              fa.f[c][w] = (int)((u32)fa.f[c][w] & keep); fa.g[c][w] = (int)((u32)fa.g[c][w] & keep);
+            }
+        }
+        auto pair_step = [&](const Fr &w, auto g0_tag, auto g1_tag) {
+          constexpr bool G0 = decltype(g0_tag)::value, G1 = decltype(g1_tag)::value;
+#pragma unroll
+          for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int gr = 0; gr < 2; gr++) {
+              if ((gr == 0 && !G0) || (gr == 1 && !G1)) continue;
+#pragma unroll
+              for (int c = 0; c < 2; c++) {
+                if (p < 2) {
+                  acc1[p][HIGH][gr][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p][gr], w.f[c], acc1[p][HIGH][gr][c], 0, 0, 0);
+                  acc3[p][HIGH][gr][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p][gr], w.g[c], acc3[p][HIGH][gr][c], 0, 0, 0);
+                } else {
+                  acc2[HIGH][gr][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[p][gr], w.f[c], acc2[HIGH][gr][c], 0, 0, 0);
+                }
+              }
+            }
+            // the plane's rows move by two: towards higher rows in the low walk (group 1 takes group 0's top two), towards lower rows in
+            // the high walk (group 0 takes group 1's bottom two); a group that holds no rows any more is not moved
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) {
+              if (!HIGH) {
+                if (G0 && G1) {
+                  const int enter = __builtin_amdgcn_update_dpp(0, A[p][0][w4], 0x122, 0xf, 0xf, false);       // row_ror:2
+                  A[p][1][w4] = __builtin_amdgcn_update_dpp(enter, A[p][1][w4], 0x112, 0xf, 0xf, false);       // row_shr:2, rows 0, 1 keep `enter`
+                } else if (G1) {
+                  A[p][1][w4] = __builtin_amdgcn_update_dpp(0, A[p][1][w4], 0x112, 0xf, 0xf, true);
+                }
+                if (G0) A[p][0][w4] = __builtin_amdgcn_update_dpp(0, A[p][0][w4], 0x112, 0xf, 0xf, true);      // zeros enter
+              } else {
+                if (G0 && G1) {
+                  const int enter = __builtin_amdgcn_update_dpp(0, A[p][1][w4], 0x12E, 0xf, 0xf, false);       // row_ror:14: rows 14, 15 <- rows 0, 1
+                  A[p][0][w4] = __builtin_amdgcn_update_dpp(enter, A[p][0][w4], 0x102, 0xf, 0xf, false);       // row_shl:2, rows 14, 15 keep `enter`
+                } else if (G0) {
+                  A[p][0][w4] = __builtin_amdgcn_update_dpp(0, A[p][0][w4], 0x102, 0xf, 0xf, true);
+                }
+                if (G1) A[p][1][w4] = __builtin_amdgcn_update_dpp(0, A[p][1][w4], 0x102, 0xf, 0xf, true);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        // pairs [0, n_both) with both groups, then [n_both, pairs) with the one that still holds rows
+        //   low:  group 0 holds rows while 2 pr <= 15; group 1 (NT > 16) to the end
+        //   high: group 0 to the end; group 1 holds rows while 16 + 2 pr <= NT - 1
+        const int n_both = NT <= 16 ? 0 : (HIGH ? (NT - 15) >> 1 : 8);
+        auto segment = [&](int first, int last, auto g0_tag, auto g1_tag) {       // pairs first .. last - 1; fa holds pair `first`
+          int pr = first;
+          for (; pr + 1 < last; pr += 2) {
+            fb = frag(pr + 1);
+            pair_step(fa, g0_tag, g1_tag);
+            fa = frag(pr + 2);
+            pair_step(fb, g0_tag, g1_tag);
+          }
+          if (pr < last) {
+            fb = frag(pr + 1);
+            pair_step(fa, g0_tag, g1_tag);
+            fa = fb;
+          }
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
+        if (NT <= 16) segment(0, pairs, T_{}, F_{});
+        else {
+          const int nb = n_both < pairs ? n_both : pairs;
+          segment(0, nb, T_{}, T_{});
+          if (HIGH) segment(nb, pairs, T_{}, F_{}); else segment(nb, pairs, F_{}, T_{});
+        }
+      };
+      walk(std::false_type{});
+      walk(std::true_type{});
+    }
+    STAMP(3);
+    // h is requested here (the loop has no register to spare for it): the three epilogues are its flight time
+    const AlignedSrc s_h = aligned_src(h + row, 2L * N);
+    const RawChunks<2> r_h = load_raw<2>(s_h, s_h.a0 + 32 * opaque(lane), 0);
+    const int kl = 128 * (opaque(lane) >> 4) + (opaque(lane) & 15);       // register j of (group g, column half c) holds index 512 g + 32 j + 16 c + kl
+    {
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fq + row, 2L * N), rs_q = rows_rsrc(quot_fq + row, 2L * N);
+      u32 any_hi = 0, c0 = 0;
+      const int lim = N - kl;
+#pragma unroll
+      for (int gr = 0; gr < 2; gr++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int ko = 512 * gr + 32 * j + 16 * c;
+            const int lo = acc1[0][0][gr][c][j] + 128 * acc1[1][0][gr][c][j], hi = acc1[0][1][gr][c][j] + 128 * acc1[1][1][gr][c][j];
+            const u32 rv = (u32)(lo + hi) & (q - 1);
+            __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+            if (ko == 0) { c0 = rv; any_hi |= kl == 0 ? 0u : rv; }
+            else any_hi |= ko < lim ? rv : 0u;
+          }
+      const bool nz_hi = any_hi != 0, first_not_one = kl == 0 && c0 != 1;
+      if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FQ;   // length !== 1 && [0] !== 1
+    }
+    STAMP(4);
+    {
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_fp + row, (long)N), rs_q = rows_rsrc(quot_fp + row, (long)N);
+      u32 any_hi = 0, c0 = 0;
+      const int lim = N - kl;
+#pragma unroll
+      for (int gr = 0; gr < 2; gr++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int ko = 512 * gr + 32 * j + 16 * c;
+            const u32 x = (u32)(acc2[0][gr][c][j] + acc2[1][gr][c][j] + 3 * 131072), y = (u32)(3 * 131072 - acc2[1][gr][c][j]);
+            const u32 rv = x % 3u, qv = y % 3u;
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rv, rs_r, kl, ko, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)qv, rs_q, kl, ko, 0);
+            if (ko == 0) { c0 = rv; any_hi |= kl == 0 ? 0u : rv; }
+            else any_hi |= ko < lim ? rv : 0u;
+          }
+      const bool nz_hi = any_hi != 0, first_not_one = kl == 0 && c0 != 1;
+      if (__ballot(nz_hi) != 0 && __ballot(first_not_one) != 0) fl |= NTRU_FLAG_INVALID_FP;
+    }
+    STAMP(5);
+    {
+      const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem_h + row, 2L * N), rs_q = rows_rsrc(quot_h + row, 2L * N);
+      u16 *remx = (u16 *)nat;
+#pragma unroll
+      for (int gr = 0; gr < 2; gr++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int ko = 512 * gr + 32 * j + 16 * c;
+            const int lo = acc3[0][0][gr][c][j] + 128 * acc3[1][0][gr][c][j], hi = acc3[0][1][gr][c][j] + 128 * acc3[1][1][gr][c][j];
+            const u32 rv = (u32)(3 * (lo + hi)) & (q - 1);
+            __builtin_amdgcn_raw_buffer_store_b16((u16)rv, rs_r, 2 * kl, 2 * ko, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((u16)((u32)(0 - 3 * hi) & (q - 1)), rs_q, 2 * kl, 2 * ko, 0);
+            remx[ko + kl] = (u16)rv;                       // ko + kl <= 624 + 399: inside the area
+          }
+      if (item + item_step < B) request_rows(item + item_step);
+      wave_lds_fence();
+      STAMP(6);
+      // index.js:165: h[k] must equal the remainder for every k below h's trimmed length
+      v4i hc[2];
+      shift_raw<2>(r_h, __builtin_amdgcn_readfirstlane(s_h.a0), hc);
+      const int i0 = 16 * opaque(lane);
+      // Per lane two 16-bit sets in a SPLIT layout (coefficient i0 + 2 c in bit c, i0 + 2 c + 1 in bit 16 + c: what one packed
+      // 16-bit minimum and one shift-or per dword give): nz = h is non-zero there, df = h differs from the remainder there;
+      // coefficients at and beyond N are cut off the sets, not off the data.  h is invalid iff its FIRST difference from the
+      // remainder lies at or below its LAST non-zero coefficient (index.js:165 compares below h's trimmed length); both are
+      // found on the scalar side from one ballot and one v_readlane each.
+      u32 nz = 0, df = 0;
+      if (i0 < 32 * NT) {
+        const v4i rc0 = *(const v4i *)(nat + 2 * i0), rc1 = *(const v4i *)(nat + 2 * i0 + 16);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const u32 hx = (u32)(c < 4 ? hc[0][c] : hc[1][c - 4]), rx = (u32)(c < 4 ? rc0[c] : rc1[c - 4]);
+          nz |= as_u32(__builtin_elementwise_min(as_pair(hx), (u16x2){1, 1})) << c;
+          df |= as_u32(__builtin_elementwise_min(as_pair(hx ^ rx), (u16x2){1, 1})) << c;
+        }
+        const int left = N - i0;                           // coefficients of this lane's chunk that exist
+        const u32 ne = left >= 16 ? 0xFFu : (1u << ((left + 1) >> 1)) - 1u, no = left >= 16 ? 0xFFu : (1u << (left >> 1)) - 1u;
+        const u32 valid = left <= 0 ? 0u : (ne | no << 16);
+        nz &= valid; df &= valid;
+      }
+      auto last_of = [](u32 m) {                           // highest coefficient (0..15) of a non-empty split set
+        const u32 ev = m & 0xFFFFu, od = m >> 16;
+        const int te = ev ? 2 * (31 - __builtin_clz(ev)) : -1, to = od ? 2 * (31 - __builtin_clz(od)) + 1 : -1;
+        return te > to ? te : to;
+      };
+      auto first_of = [](u32 m) {                          // lowest coefficient of a non-empty split set
+        const u32 ev = m & 0xFFFFu, od = m >> 16;
+        const int fe = ev ? 2 * __builtin_ctz(ev) : 64, fo = od ? 2 * __builtin_ctz(od) + 1 : 64;
+        return fe < fo ? fe : fo;
+      };
+      const unsigned long long has = __ballot(nz != 0), dif = __ballot(df != 0);
+      if (dif) {
+        const int lf = __builtin_ctzll(dif);
+        const int first_diff = 16 * lf + first_of((u32)__builtin_amdgcn_readlane((int)df, lf));
+        int top = 0;                                       // the zero polynomial has trimmed length 1: index 0 is compared
+        if (has) {
+          const int lt = 63 - __builtin_clzll(has);
+          top = 16 * lt + last_of((u32)__builtin_amdgcn_readlane((int)nz, lt));
+        }
+        if (first_diff <= top) fl |= NTRU_FLAG_INVALID_H;
+      }
+    }
+    if (lane == 0) flags[item] = (uint8_t)fl;
+    wave_lds_fence();
+    STAMP(7);
+  }
+}
+#endif   // NTRU_EXPERIMENTS (verify_keys on the 16-row tile)
+
 // One per-item product on the matrix cores: rem (and quot) of ((mul a) mod q) * s split by 1 - x^N, a < 2^16 per item,
 // s ternary per item: generatePublicKeyH (index.js:72-79, mul = p).  Same machinery as product 3 of k_verify_keys_m.
 // ONE: a single int8 digit plane (q <= 256): half the accumulators.
@@ -813,6 +1163,18 @@ int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const 
                                    uint8_t *d_quot_fp, uint8_t *d_rem_fp, uint16_t *d_quot_h, uint16_t *d_rem_h, uint8_t *d_flags) {
   if (p != 3 || !peritem_applies(eng, N, q)) return NTRU_NOT_TAKEN;
   const PGeom pg = make_pgeom(N);
+#ifdef NTRU_EXPERIMENTS
+  if (eng->path == 12) {                                   // the 16-row tile (measured slower)
+    const size_t lds16 = PI_WAVES * pi_verify16_wave_bytes(pg);
+    dim3 grid16;
+    if (int rc = peritem_grid(eng, k_verify_keys_m16, lds16, (long)B, &grid16)) return rc;
+    snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_verify_keys_m16");
+    hipLaunchKernelGGL(k_verify_keys_m16, grid16, dim3(64 * PI_WAVES), lds16, eng->stream, pg, (u32)q, d_f, d_g, d_fq, d_fp, d_h, (long)B,
+                       d_quot_fq, d_rem_fq, d_quot_fp, d_rem_fp, d_quot_h, d_rem_h, d_flags);
+    HIP_TRY(hipGetLastError());
+    return NTRU_OK;
+  }
+#endif
   const size_t lds = PI_WAVES * pi_verify_wave_bytes(pg);
   dim3 grid;
   if (int rc = peritem_grid(eng, k_verify_keys_m, lds, (long)B, &grid)) return rc;

@@ -33,7 +33,7 @@ def scheme_golden(request):
 
 def has_experiments(eng):
     """True when the loaded library was built with -DNTRU_EXPERIMENTS (`make -C ntru-circom_amd/csrc experiments`, then
-    NTRU_ENGINE_LIB=ntru-circom_amd/lib/libntru_engine_experiments.so): kernel paths 6-11 exist only there."""
+    NTRU_ENGINE_LIB=ntru-circom_amd/lib/libntru_engine_experiments.so): kernel paths 6-12 exist only there."""
     try:
         eng.set_kernel_path(6)
     except Exception:
@@ -43,12 +43,12 @@ def has_experiments(eng):
 
 
 def set_path_or_skip(eng, path):
-    """ntru_engine_set_kernel_path(path); the measured-slower variants (paths 6-11) are skipped on the default library."""
+    """ntru_engine_set_kernel_path(path); the measured-slower variants (paths 6-12) are skipped on the default library."""
     if path >= 6 and not has_experiments(eng):
         pytest.skip("kernel path %d needs the -DNTRU_EXPERIMENTS library (make experiments + NTRU_ENGINE_LIB)" % path)
     eng.set_kernel_path(path)
 
 
-# Kernel paths 6-11 are compiled only into lib/libntru_engine_experiments.so: they join the parametrisations when that is the library
+# Kernel paths 6-12 are compiled only into lib/libntru_engine_experiments.so: they join the parametrisations when that is the library
 # under test (NTRU_ENGINE_LIB=.../libntru_engine_experiments.so), and are not collected otherwise.
 EXPERIMENT_PATHS = [6, 7, 8, 9, 10, 11] if "experiments" in os.path.basename(os.environ.get("NTRU_ENGINE_LIB", "")) else []

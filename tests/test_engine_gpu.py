@@ -795,6 +795,30 @@ def test_verify_keys_h_comparison_boundaries_and_unreduced_fp(eng):
         assert np.array_equal(got["rem_fp"], base["rem_fp"])                 # unreduced fp = reduced fp
 
 
+def test_verify_keys_on_the_16_row_tile_experiment(eng):
+    """Kernel path 12 (experiments library only): verifyKeysInputs on v_mfma_i32_16x16x64_i8 -- two tile distances per instruction, two
+    row groups, rows moved two at a time inside 16-lane rows.  Bit-exact against the oracle and the default kernel; measured slower."""
+    set_path_or_skip(eng, 12)
+    try:
+        rng = np.random.default_rng(12)
+        p = 3
+        for N, q in ((821, 4096), (509, 2048), (512, 8192), (513, 64), (64, 4), (1024, 8192), (167, 128), (701, 8192), (95, 2048)):
+            B = int(rng.integers(1, 70)); d = N // 3
+            f = ternary_rows(rng, B, N, d, max(d - 1, 0), two=-1); g = ternary_rows(rng, B, N, d, d, two=-1)
+            fq = rng.integers(0, q, (B, N)); fp = rng.integers(0, p, (B, N)); h = rng.integers(0, q, (B, N))
+            if B > 2:
+                h[1, N // 3:] = 0; h[2] = 0
+                fq[0, :] = 0; fq[0, 0] = 1; f[0, :] = 0; f[0, 0] = 1
+            eng.set_kernel_path(12)
+            got = eng.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+            assert eng.last_kernel() == "k_verify_keys_m16", (N, q, eng.last_kernel())
+            want = orc.verify_keys_batch(N, q, p, f, g, fq, fp, h)
+            for k in want:
+                assert np.array_equal(got[k], want[k]), (N, q, k)
+    finally:
+        eng.set_kernel_path(0)
+
+
 def test_verify_keys_device_pointers_at_any_alignment(eng):
     """ntru_verify_keys_batch_dev with every array at an odd byte offset (uint16 arrays stay 2-aligned): the matrix-core
     kernel reads rows through aligned chunks + shifts and must neither read garbage nor write outside its rows."""

@@ -108,6 +108,78 @@ def product_split_registers(a_planes, s, N):
     return out, reads
 
 
+def product_split_tile16(a_planes, s, N):
+    """The same product on the 16-row tile v_mfma_i32_16x16x64_i8 (K = 64: TWO distances per instruction, two 16-column halves),
+    lane for lane as a kernel would run it.  Lane l = (m, kq), m = l & 15 a row of the row group g (output tile kb = 16 g + m), kq = l >> 4:
+    kq 0, 1 hold the two 16-byte K halves of the pair's first distance, kq 2, 3 of its second (one chunk row further).  Low walk: pairs
+    (0, 1), (2, 3), ...: A = chunk kb - d - (kq >> 1); a pair step moves every 16-lane row by two rows (row_shr:2), group 1 takes its two
+    entering rows from group 0's top two.  High walk: pairs (0h, -1), (-2, -3), ...: A = chunk kb + e + (kq >> 1); row_shl:2, group 0
+    takes its entering rows from group 1's bottom two.  B lane (n, kq) = bytes sc[32 dist + (16 c + n) - (16 (kq & 1) + j)], the diagonal
+    distance split by k' >= i'.  D lane (n, rq): rows 4 rq + j.  Returns (low, high) per plane and the instruction count per plane."""
+    NT = tiles(N)
+    sN = np.asarray(s, np.int64)
+    F = []
+    for a in a_planes:
+        ap = np.zeros(32 * 36, np.int64); ap[32:32 + N] = a                # chunk index + 1: chunks -1 and NT .. 34 are zero
+        F.append(ap.reshape(36, 32))
+    lanes_m, lanes_kq = np.arange(64) & 15, np.arange(64) >> 4
+    def rows(p, g, sign):                                                   # [64 lanes][16 bytes]
+        ch = 16 * g + lanes_m + sign * (lanes_kq >> 1)
+        return np.stack([F[p][ch[l] + 1][16 * (lanes_kq[l] & 1): 16 * (lanes_kq[l] & 1) + 16] for l in range(64)])
+    def frag(dist0, sign, c, high):                                         # fragment of the pair whose first distance is dist0
+        out = np.zeros((64, 16), np.int64)
+        for l in range(64):
+            n, kq = lanes_m[l], lanes_kq[l]
+            dist = dist0 + sign * (kq >> 1)
+            kp = 16 * c + n
+            for j in range(16):
+                ip = 16 * (kq & 1) + j
+                v = sN[(32 * dist + kp - ip) % N]
+                if dist == 0: v = v if ((kp >= ip) != high) else 0
+                out[l, j] = v
+        return out
+    def mfma16(A, B):
+        Am = np.zeros((16, 64), np.int64); Bm = np.zeros((64, 16), np.int64)
+        for l in range(64):
+            Am[lanes_m[l], 16 * lanes_kq[l]:16 * lanes_kq[l] + 16] = A[l]
+            Bm[16 * lanes_kq[l]:16 * lanes_kq[l] + 16, lanes_m[l]] = B[l]
+        return Am @ Bm                                                     # [m][n]
+    def shift(A0, A1, up):                                                  # one pair step on a plane's two row groups
+        N0, N1 = np.zeros_like(A0), np.zeros_like(A1)
+        for l in range(64):
+            m = lanes_m[l]
+            if up:                                                          # row m <- row m - 2; group 1 rows 0, 1 <- group 0 rows 14, 15
+                N0[l] = A0[l - 2] if m >= 2 else 0
+                N1[l] = A1[l - 2] if m >= 2 else A0[l + 14]
+            else:                                                           # row m <- row m + 2; group 0 rows 14, 15 <- group 1 rows 0, 1
+                N1[l] = A1[l + 2] if m <= 13 else 0
+                N0[l] = A0[l + 2] if m <= 13 else A1[l - 14]
+        return N0, N1
+    n_pairs, G = (NT + 1) // 2, (NT + 15) // 16
+    res, n_instr = [], 0
+    for p in range(len(a_planes)):
+        acc = np.zeros((2, 2, 2, 16, 16), np.int64)                         # [low / high][group][column half][m][n]
+        for high in (0, 1):
+            sign = -1 if not high else 1                                    # chunk index moves down in the low walk, up in the high walk
+            A = [rows(p, 0, sign), rows(p, 1, sign)]
+            for pr in range(n_pairs):
+                d0 = 2 * pr
+                for g in range(G):
+                    if not A[g].any(): continue                             # (the kernel knows from NT and pr which groups still hold rows)
+                    for c in range(2):
+                        acc[high, g, c] += mfma16(A[g], frag(d0 if not high else -d0, 1 if not high else -1, c, bool(high)))
+                        n_instr += 1 if p == 0 else 0
+                A[0], A[1] = shift(A[0], A[1], up=not high)
+        low = np.zeros(32 * 32, np.int64); hi = np.zeros(32 * 32, np.int64)
+        for g in range(2):
+            for c in range(2):
+                for m in range(16):
+                    k0 = 32 * (16 * g + m) + 16 * c
+                    low[k0:k0 + 16] = acc[0, g, c, m]; hi[k0:k0 + 16] = acc[1, g, c, m]
+        res.append((low[:N], hi[:N]))
+    return res, n_instr
+
+
 def tile_shapes(N):
     """Go / no-go on paper for the 16-row tile (v_mfma_i32_16x16x64_i8) against the 32-row one, per digit plane and product:
     matrix work issued, the useful share of it, operand bytes an instruction needs and lane shifts per plane when the rows live
@@ -155,6 +227,12 @@ def main():
         lo = planes[0][0] + 128 * planes[1][0]; hi = planes[0][1] + 128 * planes[1][1]
         assert np.array_equal((lo + hi) % q, (lin[:N] + lin[N:]) % q) and np.array_equal((-hi) % q, (-lin[N:]) % q), (N, q, "registers")
         assert np.array_equal(planes[2][0], low3) and np.array_equal(planes[2][1], high3), (N, "registers, mod p")
+        if N in (821, 167, 33, 509):                        # the 16-row tile, lane for lane (not built: EXPERIMENTS.md round 5)
+            p16, n16 = product_split_tile16([v & 127, v >> 7, fp], f, N)
+            lo16 = p16[0][0] + 128 * p16[1][0]; hi16 = p16[0][1] + 128 * p16[1][1]
+            assert np.array_equal(lo16, lo) and np.array_equal(hi16, hi), (N, q, "16-row tile")
+            assert np.array_equal(p16[2][0], low3) and np.array_equal(p16[2][1], high3), (N, "16-row tile, mod p")
+            print("N=%d: 16-row tile: %d instructions of 16 clocks per plane (%d of 32 clocks on the 32-row tile)  OK" % (N, n16, 2 * tiles(N)))
         print("N=%d q=%d: %d + %d matrix instructions per item for (f * fq, f * fp); rows in registers: %d fragment reads for the three "
               "planes and no row reads (rows in the LDS: %d fragment + %d row reads); packed-MAC wave instructions of the vector-ALU family: %d  OK"
               % (N, q, n, n3, reads, 2 * reads, 3 * reads, 2 * ((N * N + 127) // 128)))
