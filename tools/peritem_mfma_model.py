@@ -200,8 +200,14 @@ def tile_shapes(N):
     print("  16x16x64: %3d instructions (%5d clocks), useful MACs %.0f %%; operand bytes per instruction: 1 KB fragment per (distance pair, "
           "column half) shared by the row groups; 4 + 8 lane shifts per distance PAIR and plane (two row groups, the second takes its entering rows "
           "from the first: 6 per distance)" % (instr16, instr16 * 16, 100.0 * useful / (units * 16.0)))
-    print("  -> matrix clocks %.2fx, lane shifts 1.5x: with the vector port as loaded as the matrix pipe (round 5 counters: 0.9 against 0.67) the "
-          "16-row tile is not built" % (instr16 * 16 / (2 * NT * 32.0)))
+    tpitch = ((16 * NT + 31) // 32) * 32 + 8
+    arr, nat = 16 * tpitch, max((3 * N + 64 + 15) // 16 * 16, 2304)
+    print("  LDS per wave: rows in the LDS (until round 4) %d B = two padded chunk matrices + one reversed array; rows in registers %d B "
+          "(one array + the natural-order area), k_verify_keys_m %d B (two arrays), on the 16-row tile %d B (+ the planes' byte image)"
+          % (2 * 32 * (NT + 64) + arr, nat + arr, nat + 2 * arr, max(nat, 3 * 35 * 32 + 32) + 2 * arr))
+    print("  -> matrix clocks %.2fx, lane shifts 1.5x.  Built in round 5 as k_verify_keys_m16 (experiments build): bit-exact and 20 %% SLOWER "
+          "as a whole kernel -- more vector instructions per matrix clock, 32-byte store segments (EXPERIMENTS.md round 5 item 9)"
+          % (instr16 * 16 / (2 * NT * 32.0)))
 
 
 def main():
