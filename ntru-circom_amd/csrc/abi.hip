@@ -312,7 +312,7 @@ extern "C" int ntru_public_key_batch_dev(ntru_engine_t *eng, int N, int q, int p
   HIP_TRY(hipSetDevice(eng->device));
   if (ntru_product_tern_matrix_applies(eng, N, q)) {
     snprintf(eng->last_kernel, sizeof eng->last_kernel, "k_public_key_m");
-    return ntru_launch_product_tern_matrix(eng, N, q, (uint32_t)p, d_fq, d_g, (long)B, nullptr, d_h);
+    return ntru_launch_product_tern_matrix(eng, N, q, (uint32_t)p, d_fq, d_g, (long)B, d_h);
   }
   return ntru_launch_public_key_valu(eng, N, q, p, d_fq, d_g, B, d_h);
 }

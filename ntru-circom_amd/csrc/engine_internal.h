@@ -155,7 +155,7 @@ NTRU_HIDDEN int ntru_launch_polymul_valu(ntru_engine *eng, int N, int mod, const
 NTRU_HIDDEN bool ntru_product_tern_matrix_applies(const ntru_engine *eng, int N, int q);
 // ((mul * a) mod q) * s with s ternary per item; d_quot may be NULL
 NTRU_HIDDEN int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s,
-                                                long B, uint16_t *d_quot, uint16_t *d_rem);
+                                                long B, uint16_t *d_rem);
 NTRU_HIDDEN int ntru_launch_public_key_valu(ntru_engine *eng, int N, int q, int p, const uint16_t *d_fq, const int8_t *d_g, int64_t B,
                                             uint16_t *d_h);
 NTRU_HIDDEN int ntru_launch_verify_keys_matrix(ntru_engine *eng, int N, int q, int p, const int8_t *d_f, const int8_t *d_g,

@@ -48,7 +48,7 @@ int ntru_launch_polymul_matrix(ntru_engine *eng, int N, int mod, const uint16_t 
 int ntru_launch_polymul_valu(ntru_engine *, int, int, const uint16_t *, const uint16_t *, int64_t, uint16_t *, uint16_t *) { return NTRU_ERR_UNSUPPORTED; }
 bool ntru_product_tern_matrix_applies(const ntru_engine *, int, int) { return true; }
 int ntru_launch_product_tern_matrix(ntru_engine *eng, int N, int q, uint32_t mul, const uint16_t *d_a, const int8_t *d_s, long B,
-                                    uint16_t *, uint16_t *d_rem) {
+                                    uint16_t *d_rem) {
   fake_enqueue(eng->stream, [=] { fake_public_key(N, q, (int)mul, d_a, d_s, B, d_rem); });
   return NTRU_OK;
 }

@@ -584,6 +584,43 @@ def test_key_inversion_captured_cases_and_random_keys(eng):
         assert all(np.array_equal(rem3[i], one) for i in range(B) if ok[i])
 
 
+def test_products_modulo_x_n_minus_1_on_one_matrix_instruction_per_distance(eng):
+    """`pi_product_cyc` (k_product_tern_m: the public key; k_newton_round_m: the lifting of the inverse modulo 2): every class of N --
+    two tiles, a multiple of 32 (nothing moved), one past it (31 places), one short of it, 1024 -- on one and on two digit planes.
+    Public keys against the oracle and the vector-ALU kernel; inverses through f * fq = 1 (the split product) and the oracle's polyInv."""
+    from oracle import ntru_keygen as kg
+    rng = np.random.default_rng(55)
+    one_of = lambda N: np.eye(1, N, dtype=np.int64)[0]
+    for N in (64, 65, 95, 96, 97, 127, 128, 167, 509, 640, 677, 701, 821, 992, 993, 1023, 1024):
+        for q in (128, 2048, 8192):
+            B = int(rng.integers(3, 70)); d = N // 3
+            fq = rng.integers(0, q, (B, N)); g = ternary_rows(rng, B, N, d, d, two=-1)
+            fq[0] = q - 1; g[0] = -1; fq[1] = 0; fq[1, N - 1] = q - 1; g[1] = 0; g[1, N - 1] = 1      # extremes; x^(N-1) * x^(N-1) wraps to x^(N-2)
+            eng.set_kernel_path(4)
+            got = eng.public_key_batch(N, q, 3, fq, g)
+            assert eng.last_kernel() == "k_public_key_m", (N, q, eng.last_kernel())
+            eng.set_kernel_path(1)
+            alt = eng.public_key_batch(N, q, 3, fq, g)
+            eng.set_kernel_path(0)
+            want = orc.public_key_batch(N, q, 3, fq, g)
+            assert np.array_equal(got, want), (N, q)
+            assert np.array_equal(alt, want), (N, q, "vector-ALU kernel")
+        q = 4096
+        B = 40
+        f = ternary_rows(rng, B, N, N // 3, N // 3 - 1, two=-1)
+        eng.set_kernel_path(4)
+        fq, fp, flags = eng.invert_key_batch(N, q, 3, f)
+        eng.set_kernel_path(0)
+        ok = flags == 0
+        assert ok.sum() >= (1 if N % 2 == 0 else 5), (N, int(ok.sum()))
+        _, rem = orc.polymul_split_batch(N, q, f % q, fq)
+        assert all(np.array_equal(rem[i], one_of(N)) for i in range(B) if ok[i]), N
+        i = int(np.nonzero(ok)[0][0])
+        if N <= 200:                                         # the oracle's polyInv (slow): one key per small size
+            wq, wp = kg.load_private_key(f[i], N, q, 3)
+            assert np.array_equal(fq[i], wq % q) and np.array_equal(fp[i], wp % 3), N
+
+
 def test_key_inversion_whole_block_output_equals_the_per_coefficient_path(eng):
     """k_invert_key writes a whole block of 64 keys through LDS as one contiguous run when the outputs are 16-byte aligned, and one
     coefficient at a time otherwise (unaligned outputs, the partial last block, N < 32): both on the same keys -- with non-units

@@ -38,3 +38,19 @@ def test_rows_in_registers_model_matches_the_convolution():
         lo3 = 3 * (pg[0][0] + 128 * pg[1][0]); hi3 = 3 * (pg[0][1] + 128 * pg[1][1])
         ref = np.convolve(g, (3 * fq) % q); ref = np.concatenate([ref, np.zeros(2 * N - len(ref), np.int64)])
         assert np.array_equal((lo3 + hi3) % q, (ref[:N] + ref[N:]) % q) and np.array_equal((-hi3) % q, (-ref[N:]) % q), (N, q)
+
+
+def test_cyclic_rows_model_matches_the_convolution_modulo_x_n_minus_1():
+    """`pi_product_cyc` (Newton rounds, public key): one matrix instruction per tile distance, the wrapped terms through rows of the
+    copy moved up by 32 NT - N places that enter at row 0; every N class (multiple of 32, one short of it, one past it, two tiles)."""
+    sys.path.insert(0, os.path.join(ge.ROOT, "tools"))
+    import numpy as np
+    import peritem_mfma_model as pm
+    rng = np.random.default_rng(6)
+    for N in (64, 65, 95, 96, 97, 127, 167, 509, 677, 701, 821, 992, 993, 1023, 1024):
+        a = rng.integers(0, 128, N); b = rng.integers(-64, 64, N); s = rng.integers(-1, 2, N)
+        (c, c2), n = pm.product_cyclic_registers([a, b], s, N)
+        assert n == pm.tiles(N)
+        for x, got in ((a, c), (b, c2)):
+            lin = np.convolve(x, s); lin = np.concatenate([lin, np.zeros(2 * N - len(lin), np.int64)])
+            assert np.array_equal(got, lin[:N] + lin[N:]), N

@@ -108,6 +108,50 @@ def product_split_registers(a_planes, s, N):
     return out, reads
 
 
+def product_cyclic_registers(a_planes, s, N):
+    """Products whose QUOTIENT nobody wants (the Newton rounds of polyInv, the public key h): c = a * s modulo x^N - 1 with ONE matrix
+    instruction per tile distance d = 0 .. NT - 1 and ONE accumulator (`pi_product_cyc`, csrc/matrix_peritem.hip).  The wrapped terms
+    a[i] s[k - i + N] (i > k) have the SAME Toeplitz fragment as the unwrapped ones of distance d when their rows come from a copy of
+    `a` moved up by P = 32 NT - N places (a2[i + P] = a[i]): with j = i + P = 32 (kb - d + NT) + j1 (chunk kb - d + NT of a2),
+        k - i + N = 32 kb + k1 - 32 (kb - d + NT) - j1 + P + N = 32 d + k1 - j1.
+    So row kb of distance d holds chunk kb - d of a (kb >= d) or chunk kb - d + NT of a2 (kb < d): the rows walk UP one lane per
+    distance and chunk NT - d of a2 ENTERS at row 0 (two lanes, from a byte image of a2 in the LDS, by v_cndmask_b32_dpp).  The tile
+    of distance 0 is taken whole (its entries above the diagonal are the wrapped terms inside the tile), so the P coefficients that
+    chunk kb + 1 of a2 shares with chunk kb of a are cut from the rows of the LAST distance, where that chunk sits at row kb.
+    Returns the products modulo x^N - 1 per plane and the number of matrix instructions per plane."""
+    NT = tiles(N)
+    P = 32 * NT - N
+    lanes, images = [], []
+    for a in a_planes:
+        ap = np.zeros(32 * 32, np.int64); ap[:N] = a
+        lanes.append(np.stack([ap[32 * r + 16 * hh: 32 * r + 16 * hh + 16] for hh in (0, 1) for r in range(32)]))
+        img = np.zeros(32 * NT, np.int64); img[P:] = a                   # the LDS image: byte P + i = a[i]
+        images.append(img)
+    def as_matrix(L):
+        return np.concatenate([L[:32], L[32:]], axis=1)
+    def up_enter(L, e):                                                 # wave_shr:1; lanes 0 and 32 (row 0) take the entering row's halves
+        M = np.zeros_like(L); M[1:] = L[:-1]
+        M[0] = e[:16]; M[32] = e[16:]
+        return M
+    cut = np.zeros((64, 16), bool)                                      # last distance: bytes 16 hh + j < P of rows <= NT - 2
+    for hh in (0, 1):
+        for r in range(NT - 1):
+            cut[32 * hh + r] = 16 * hh + np.arange(16) < P
+    acc, A = [], [L.copy() for L in lanes]
+    G0 = toeplitz_tile(s, N, 0)
+    for p in range(len(lanes)):
+        acc.append(as_matrix(A[p]) @ G0)
+    for d in range(1, NT):
+        G = toeplitz_tile(s, N, d)
+        for p in range(len(lanes)):
+            j = NT - d
+            A[p] = up_enter(A[p], images[p][32 * j: 32 * j + 32])
+            if d == NT - 1:
+                A[p] = np.where(cut, 0, A[p])
+            acc[p] = acc[p] + as_matrix(A[p]) @ G
+    return [c.reshape(-1)[:N] for c in acc], NT
+
+
 def product_split_tile16(a_planes, s, N):
     """The same product on the 16-row tile v_mfma_i32_16x16x64_i8 (K = 64: TWO distances per instruction, two 16-column halves),
     lane for lane as a kernel would run it.  Lane l = (m, kq), m = l & 15 a row of the row group g (output tile kb = 16 g + m), kq = l >> 4:
@@ -233,6 +277,10 @@ def main():
         lo = planes[0][0] + 128 * planes[1][0]; hi = planes[0][1] + 128 * planes[1][1]
         assert np.array_equal((lo + hi) % q, (lin[:N] + lin[N:]) % q) and np.array_equal((-hi) % q, (-lin[N:]) % q), (N, q, "registers")
         assert np.array_equal(planes[2][0], low3) and np.array_equal(planes[2][1], high3), (N, "registers, mod p")
+        if N >= 64:                                         # quotient not wanted: one matrix instruction per distance, one accumulator
+            cyc, ncyc = product_cyclic_registers([v & 127, v >> 7], f, N)
+            assert np.array_equal((cyc[0] + 128 * cyc[1]) % q, (lin[:N] + lin[N:]) % q), (N, q, "cyclic")
+            print("N=%d: modulo x^N - 1 only: %d matrix instructions per plane (%d with the split)  OK" % (N, ncyc, 2 * tiles(N)))
         if N in (821, 167, 33, 509):                        # the 16-row tile, lane for lane (not built: EXPERIMENTS.md round 5)
             p16, n16 = product_split_tile16([v & 127, v >> 7, fp], f, N)
             lo16 = p16[0][0] + 128 * p16[1][0]; hi16 = p16[0][1] + 128 * p16[1][1]

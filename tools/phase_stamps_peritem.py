@@ -62,3 +62,15 @@ for mod in (16, 4096):
             row.append("%s %d" % (lab, int(np.median(d)) if d.size else -1))
         tot = st[:, :, it + 1, 0] - st[:, :, it, 0]
         print(" item", it, "|", " | ".join(row), "| whole item", int(np.median(tot[tot > 0])))
+
+# k_newton_round_m: the last round of the N = 821, q = 4096 schedule (6 -> 12 bits) on synthetic rows (values do not matter)
+f8 = torch.randint(-1, 2, (B, N), dtype=torch.int8, device=dev)
+v16 = torch.randint(0, 64, (B, N), dtype=torch.int32, device=dev).to(torch.int16)
+lib.ntru_debug_newton_round.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+for _ in range(2):
+    assert lib.ntru_debug_newton_round(eng._h, N, 6, 12, f8.data_ptr(), v16.data_ptr(), B) == 0
+torch.cuda.synchronize()
+assert lib.ntru_debug_read_stamps_pi(buf.ctypes.data_as(C.c_void_p)) == 0
+show("k_newton_round_m, N = %d, 6 -> 12 bits (four waves per SIMD)" % N, buf[:1024, :2].astype(np.int64),
+     [(0, 1, "operands + digits"), (1, 2, "array of f + image of v"), (2, 3, "f v (26 distances)"), (3, 4, "e, array of v, image of e"),
+      (4, 5, "e v (26 distances)"), (5, 6, "lift + stores")], 6)
