@@ -14,7 +14,8 @@ operand is the same Toeplitz fragment family 4 reads from the reversed cyclic ar
 item: 2 NT - 1 matrix instructions per digit plane.  An operand wider than int8 uses digit planes as in family 4.
 
 This model reproduces that loop structure with numpy and checks it against a direct convolution for the verify_keys
-operand shapes (ternary x 13-bit, ternary x 2-bit)."""
+operand shapes (ternary x 13-bit, ternary x 2-bit); `product_split_registers` replays the lane shifts of the rows-in-registers
+kernels, `product_cyclic_registers` the one-instruction-per-distance form of the products modulo x^N - 1 (Newton rounds, public key)."""
 import numpy as np
 
 
