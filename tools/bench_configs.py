@@ -122,10 +122,30 @@ def keygen_config(profile, logB):
     fq = torch.empty((B, N), dtype=torch.int16, device=dev); fp = torch.empty((B, N), dtype=torch.uint8, device=dev)
     fl = torch.empty(B, dtype=torch.uint8, device=dev); h = torch.empty((B, N), dtype=torch.int16, device=dev)
 
-    def gen():
+    def gen():                                               # EVERYTHING a key pair takes: both draws, both inversions, h
+        eng.sample_ternary_dev(N, df, df - 1, 255, key, 0, B, fs.data_ptr())
+        eng.sample_ternary_dev(N, dg, dg, 255, key, 1 << 40, B, gs.data_ptr())
         eng.invert_key_batch_dev(N, q, p, f.data_ptr(), B, fq.data_ptr(), fp.data_ptr(), fl.data_ptr())
         eng.public_key_batch_dev(N, q, p, fq.data_ptr(), g.data_ptr(), B, h.data_ptr())
+
+    def inv_h():
+        eng.invert_key_batch_dev(N, q, p, f.data_ptr(), B, fq.data_ptr(), fp.data_ptr(), fl.data_ptr())
+        eng.public_key_batch_dev(N, q, p, fq.data_ptr(), g.data_ptr(), B, h.data_ptr())
+    main_stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=dev)
+    eng2 = pkg.Engine(0) if "--no-pipeline" not in sys.argv else None
+
+    def gen_side():                                          # g drawn by a second engine on a side stream, beside f's draw and inversions
+        side.wait_stream(main_stream)
+        eng2.set_stream(side.cuda_stream)
+        eng2.sample_ternary_dev(N, dg, dg, 255, key, 1 << 40, B, gs.data_ptr())
+        eng.sample_ternary_dev(N, df, df - 1, 255, key, 0, B, fs.data_ptr())
+        eng.invert_key_batch_dev(N, q, p, f.data_ptr(), B, fq.data_ptr(), fp.data_ptr(), fl.data_ptr())
+        main_stream.wait_stream(side)
+        eng.public_key_batch_dev(N, q, p, fq.data_ptr(), g.data_ptr(), B, h.data_ptr())
+    ms_inv_h = timed(inv_h, steps=3, warmup=1)
     ms = timed(gen, steps=3, warmup=1)
+    ms_side = timed(gen_side, steps=3, warmup=1) if "--no-pipeline" not in sys.argv else None     # (second stream: kept out of the rocprofv3 passes)
     units = int((fl == 0).sum())
     o16 = lambda: torch.empty((B, N), dtype=torch.int16, device=dev)
     o8 = lambda: torch.empty((B, N), dtype=torch.uint8, device=dev)
@@ -141,7 +161,8 @@ def keygen_config(profile, logB):
     got = [host(t, rows) for t in outs] + [host(vflags, rows)]
     ok = bool(np.array_equal(host(h, rows), h_o)) and all(np.array_equal(a, b) for a, b in zip(got, want))
     return {"config": "N=%d q=%d key generation batch=2^%d (sample f, g; invert mod q and mod p; h) then verifyKeysInputs on the "
-                      "generated keys, 1 GPU" % (N, q, logB), "keygen_ms": ms, "keys_per_s": B / (ms * 1e-3), "units": units,
+                      "generated keys, 1 GPU" % (N, q, logB), "keygen_ms": ms, "keys_per_s": B / (ms * 1e-3), "invert_and_h_ms": ms_inv_h,
+            "g_drawn_on_a_side_stream_ms": ms_side, "units": units,
             "verify_ms": vms, "verify_keys_per_s": B / (vms * 1e-3), "verify_flags_on_valid_keys": bad,
             "rows_equal_oracle": ok, "rows_checked": int(rows.numel())}
 
