@@ -54,6 +54,17 @@ static __device__ __forceinline__ void pi_digits(const u32 (&x)[8], u32 q, u32 m
   }
 }
 
+// Ternary operand bytes: any negative byte is -1 (ValTernary), bytes outside the mask (at and beyond N) are zero -- four at a time.
+static __device__ __forceinline__ v4i pi_ternary(v4i v, const v4i &cmask) {
+  v4i o;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const u32 w = (u32)(v[c] & cmask[c]);
+    o[c] = (int)(w | ((w >> 7) & 0x01010101u) * 0xFFu);    // (1 in every negative byte, spread to 0xFF: no carries)
+  }
+  return o;
+}
+
 // ---- chunk rows in REGISTERS (k_verify_keys_m) -----------------------------------------------------------------------------------
 // The A operand of tile distance d is the chunk matrix moved down by d rows: lane (r, hh) holds bytes 16 hh .. 16 hh + 15 of chunk
 // r - d.  Going from d to d + 1 (d >= 0) every lane takes its lower neighbour's 16 bytes and nothing enters at row 0; going from d to
@@ -223,9 +234,19 @@ static __device__ __forceinline__ void pi_store_image(unsigned char *img, const 
 
 // NPL planes F[p] (this lane's unshifted chunk rows) whose images lie at img + p PI_IMG, against the fragments of T: C[p] = plane p's
 // product modulo x^N - 1.  Fragment and entering rows are requested one trip ahead, unrolled by two so that the sets rotate without moves.
+// The byte mask of the last distance (pi_product_cyc): rows <= NT - 2 lose their bytes 16 hh + j < P = 32 NT - N.  Once per item.
+static __device__ __forceinline__ void pi_cyc_keep(const PGeom &g, int lane_, u32 (&keep)[4]) {
+  const int lane = opaque(lane_), P = 32 * g.NT - g.N, u = (lane & 31) <= g.NT - 2 ? P - 16 * (lane >> 5) : 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int n = min(max(u - 4 * c, 0), 4);
+    keep[c] = n >= 4 ? 0u : ~((1u << (8 * n)) - 1u);
+  }
+}
+
 template <int NPL>
 static __device__ __forceinline__ void pi_product_cyc(const v4i (&F)[NPL], const unsigned char *img, const u32 *T, const PGeom &g, int lane_,
-                                                      v16i (&C)[NPL]) {
+                                                      const u32 (&keep)[4], v16i (&C)[NPL]) {
   const int lane = opaque(lane_), NT = g.NT;
   const int y0 = 32 * NT - 1 - (lane & 31) + 16 * (lane >> 5);
   const u32 *tb = T + (y0 & 3) * g.tpitch + (y0 >> 2);     // this lane's fragment of distance 0; distance d lies 8 d dwords below
@@ -260,13 +281,6 @@ static __device__ __forceinline__ void pi_product_cyc(const v4i (&F)[NPL], const
     }
   };
   auto last = [&](const v4i &w, const Rows &e) {           // distance NT - 1: rows <= NT - 2 lose their bytes 16 hh + j < P
-    const int P = 32 * NT - g.N, u = (lane & 31) <= NT - 2 ? P - 16 * (lane >> 5) : 0;
-    u32 keep[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int n = min(max(u - 4 * c, 0), 4);
-      keep[c] = n >= 4 ? 0u : ~((1u << (8 * n)) - 1u);
-    }
 #pragma unroll
     for (int p = 0; p < NPL; p++) {
       A[p] = and4(rows_up_enter(A[p], e.e[p]), keep);
@@ -999,10 +1013,7 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
       u32 xa[8];
 #pragma unroll
       for (int c = 0; c < 4; c++) { xa[c] = (u32)va[0][c]; xa[4 + c] = (u32)va[1][c]; }
-      union { v4i v; signed char c[16]; } u; u.v = vs[0] & col_mask16(16 * ch, N);      // any negative byte is -1 (ValTernary)
-#pragma unroll
-      for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
-      pi_build_array_half(nat, T, g, lane, ch, u.v);         // (its last fence: nat is free for the planes' images)
+      pi_build_array_half(nat, T, g, lane, ch, pi_ternary(vs[0], col_mask16(16 * ch, N)));     // (its last fence: nat is free for the planes' images)
       v4i o0, o1;
       pi_digits(xa, q, mul, 16 * ch, N, o0, o1);
       F[0] = o0;
@@ -1011,7 +1022,9 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(O
       wave_lds_fence();
     }
     v16i C[NPL];
-    pi_product_cyc<NPL>(F, nat, T, g, lane, C);
+    u32 keep[4];
+    pi_cyc_keep(g, lane, keep);
+    pi_product_cyc<NPL>(F, nat, T, g, lane, keep, C);
     {
       const int ln = opaque(lane), kl = 128 * (ln >> 5) + (ln & 31);     // see k_verify_keys_m: indices >= N are dropped
       const __amdgpu_buffer_rsrc_t rs_r = rows_rsrc(rem + row, 2L * N);
@@ -1071,26 +1084,23 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(4
       pi_digits(xv, me, 1u, 16 * ch, N, b0, o1);
       pi_digits(xv, 256u, 1u, 16 * ch, N, F[0], o1);      // v < 2^kb <= 128: its own centred representative modulo 256
       STAMP(1);                                            // operands arrived, digits
-      union { v4i v; signed char c[16]; } u; u.v = vf[0] & col_mask16(16 * ch, N);        // any negative byte is -1 (ValTernary)
-#pragma unroll
-      for (int j = 0; j < 16; j++) u.c[j] = u.c[j] < 0 ? (signed char)-1 : u.c[j];
-      pi_build_array_half(nat, T, g, lane, ch, u.v);         // (its last fence: nat is free for v's image)
+      pi_build_array_half(nat, T, g, lane, ch, pi_ternary(vf[0], col_mask16(16 * ch, N)));       // (its last fence: nat is free for v's image)
       pi_store_image(nat, g, ch, F[0]);
       wave_lds_fence();
     }
     STAMP(2);                                              // f's reversed array, v's image
     v16i C[1];
-    pi_product_cyc<1>(F, nat, T, g, lane, C);              // f v
+    u32 keep[4];
+    pi_cyc_keep(g, lane, keep);
+    pi_product_cyc<1>(F, nat, T, g, lane, keep, C);        // f v
     STAMP(3);
     if (item + item_step < B) request(item + item_step);   // the next item's rows (nobody lifts them before this wave does): a product ahead
     {
       const int ln = opaque(lane), kl = 128 * (ln >> 5) + (ln & 31), ch = chunk_of(ln);
-      u32 e[16];
+      u32 e[16];                                           // e = (f v - 1) / 2^kb modulo 2^(m - kb): bits kb .. m - 1 of f v - 1
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const u32 fv = (u32)C[0][i] & (mr - 1);
-        e[i] = ((fv - (i == 0 && kl == 0 ? 1u : 0u)) & (mr - 1)) >> kb;   // e = (f v - 1) / 2^kb, below 2^(m - kb) <= 128
-      }
+      for (int i = 0; i < 16; i++)
+        e[i] = __builtin_amdgcn_ubfe((u32)C[0][i] - (i == 0 && kl == 0 ? 1u : 0u), kb, m - kb);
       pi_build_array_half(nat, T, g, lane, ch, b0);          // (over f's array; its last fence orders the reads of nat before the writes below)
       unsigned char *img = nat + (32 * g.NT - N);          // e's image for the entering rows IS its natural-order byte image, P bytes up
 #pragma unroll
@@ -1105,13 +1115,14 @@ __global__ __launch_bounds__(64 * PI_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
     for (int i = 0; i < 16; i++) vold[i] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_v, 2 * kl2, 2 * 32 * ((i & 3) + 8 * (i >> 2)), 0);
     STAMP(4);                                              // e, v's reversed array, e's image and rows
-    pi_product_cyc<1>(F, nat, T, g, lane, C);              // e v
+    pi_product_cyc<1>(F, nat, T, g, lane, keep, C);        // e v
     STAMP(5);
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int ko = 32 * ((i & 3) + 8 * (i >> 2));
-      const u32 w = (u32)C[0][i] & (me - 1);
-      __builtin_amdgcn_raw_buffer_store_b16((u16)(((u32)vold[i] - (w << kb)) & (mr - 1)), rs_v, 2 * kl2, 2 * ko, 0);
+      u32 nv;                                              // vold - 2^kb (e v): of e v only its residue modulo 2^(m - kb) reaches the low m bits
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(nv) : "v"(C[0][i]), "s"(0 - (int)(1u << kb)), "v"(vold[i]));   // |e v| < 2^23; vold's upper half: masked below
+      __builtin_amdgcn_raw_buffer_store_b16((u16)(nv & (mr - 1)), rs_v, 2 * kl2, 2 * ko, 0);
     }
     wave_lds_fence();
     STAMP(6);                                              // the lift's stores issued
